@@ -1,0 +1,137 @@
+/* nerfart_hip.h - C ABI of libnerfart_hip.so: the MI355X (gfx950) hot path of cassiePython/NeRF-Art.
+ *
+ * The reference (pure Python/PyTorch, no FFI of its own) exposes this path as Python callables;
+ * each entry point below names the reference callable (file:line under the reference tree) it
+ * replaces.  SURVEY.md section 8b lists the boundaries B1-B3; INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 (int32 / int64 where typed so) unless a
+ *     parameter is documented as host; outputs are caller-allocated; nothing is retained.
+ *   - `stream` is a hipStream_t (0 = default stream); all work is enqueued on it.  Entry points
+ *     with a data-dependent loop (fine_sample, render) synchronise that stream internally.
+ *   - return value 0 = success; non-zero = failure, message via nerfart_last_error() (thread local).
+ *   - `blob` arguments are weight blobs produced by nerf-art_amd/packing.py (layout documented
+ *     there and in DESIGN.md): `surf_blob` = program 1 (SDF net), `rad_blob` = program 2
+ *     (geometry-feature rows + radiance net).
+ *   - point sources: either an explicit array pts[M,3], or ("_rays" variants) rays + per-ray depths:
+ *     point m = slot m / n_per_ray, sample m % n_per_ray, ray = ray_idx ? ray_idx[slot] : slot,
+ *     x = rays_o[ray] + rays_d[ray] * depth[slot * depth_stride + sample]  (two roundings, as the
+ *     reference's separate mul and add).
+ */
+#ifndef NERFART_HIP_H
+#define NERFART_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int nerfart_abi_version(void);
+const char* nerfart_last_error(void);
+
+/* host helper: torch.linspace(start, end, n) in fp32, bit for bit (out is a HOST array). */
+void nerfart_linspace(float start, float end, int n, float* out);
+
+/* ---- B3: SDF query.  ImplicitSurface.forward (models/base.py:243-263) + VolSDF.forward_surface
+ * sphere clamp sdf = min(sdf, R_bg - |x|) (models/frameworks/volsdf.py:341-347); R_bg <= 0: no clamp
+ * (NeuS, neus.py:277,299). */
+int nerfart_sdf_fwd(const float* surf_blob, const float* pts, long long M, float R_bg, float* sdf_out, void* stream);
+int nerfart_sdf_fwd_rays(const float* surf_blob, const float* rays_o, const float* rays_d, const int* ray_idx,
+                         const float* depth, int n_slots, int n_per_ray, int depth_stride, float R_bg,
+                         float* sdf_out, int out_stride, void* stream);
+
+/* ---- B2 (first half): ImplicitSurface.forward_with_nablas (models/base.py:265-282) + the clamp of
+ * VolSDF.forward_surface_with_nablas (volsdf.py:349-357; nabla is NOT replaced).  Outputs sdf[M],
+ * nabla[M,3] and, if h7_out != NULL, the layer-7 activation h7[M,256] consumed by nerfart_radiance_fwd. */
+int nerfart_sdf_nabla_fwd(const float* surf_blob, const float* pts, long long M, float R_bg, float* sdf_out,
+                          float* nabla_out, float* h7_out, void* stream);
+int nerfart_sdf_nabla_fwd_rays(const float* surf_blob, const float* rays_o, const float* rays_d, const int* ray_idx,
+                               const float* depth, int n_slots, int n_per_ray, int depth_stride, float R_bg,
+                               float* sdf_out, float* nabla_out, float* h7_out, void* stream);
+
+/* ---- B2 (second half): geometry feature (last SDF layer rows 1..256, base.py:253-256) + RadianceNet.forward
+ * (models/base.py:372-391) on [x, view (raw: view_tiles=1 | embed 4: view_tiles=3), nabla, feat]. */
+int nerfart_radiance_fwd(const float* rad_blob, int view_tiles, const float* pts, const float* view, long long M,
+                         const float* nabla, const float* h7, float* rgb_out, void* stream);
+int nerfart_radiance_fwd_rays(const float* rad_blob, int view_tiles, const float* rays_o, const float* rays_d,
+                              const int* ray_idx, const float* depth, int n_slots, int n_per_ray, int depth_stride,
+                              const float* nabla, const float* h7, float* rgb_out, void* stream);
+
+/* ---- rays.  rend_util.get_rays (utils/rend_util.py:112-165) for one camera: pose/K are row-major 4x4
+ * on the device; select (int64, may be NULL = all H*W pixels in row-major order) picks pixel indices. */
+int nerfart_get_rays(const float* pose_dev, const float* K_dev, int H, int W, const long long* select_dev, int n,
+                     float* rays_o, float* rays_d, void* stream);
+/* F.normalize(rays_d, dim=-1) (volsdf.py:442, neus.py:196) */
+int nerfart_normalize_dirs(const float* in, float* out, int n, void* stream);
+/* out[r, k] = near[r]*(1 - t[k]) + far[r]*t[k] (volsdf.py:472-484, neus.py:235-236); near/far NULL -> scalars */
+int nerfart_linspace_depths(const float* t_dev, int n, const float* near, const float* far, float near_s, float far_s,
+                            int n_rays, float* out, int stride, void* stream);
+
+/* ---- VolSDF sampler stages (models/frameworks/volsdf.py fine_sample :97-302; error_bound :56-94;
+ * utils/rend_util.py sample_pdf :256-293, sample_cdf :295-328).  Exposed one by one for parity tests;
+ * nerfart_volsdf_fine_sample chains them. */
+int nerfart_volsdf_first_check(int n_rays, int n, int cap, int n_final, float eps, float alpha_net, float beta_net,
+                               const float* dA, const float* sA, const float* u_final, float beta_plus0_denom,
+                               const float* far, float far_s, float* d_fine, float* beta_plus, float* beta_map,
+                               float* iter_usage, int* act_out, int* act_count, void* stream);
+int nerfart_volsdf_upsample(int n_active, int n, int cap, int n_up, const float* dA, const float* sA, const int* act,
+                            const float* beta_plus, const float* u_up, int clamp_bounds, float* d_new, void* stream);
+int nerfart_volsdf_merge_check(int n_active, int n, int cap, int n_up, int n_final, int max_bisect, int it, float eps,
+                               float alpha_net, float beta_net, const float* dA, const float* sA, float* dB, float* sB,
+                               const int* act, const float* d_new, const float* s_new, const float* u_final,
+                               float* d_fine, float* beta_plus, float* beta_map, float* iter_usage, int* act_out,
+                               int* act_count, void* stream);
+int nerfart_volsdf_finalize(int n_active, int n, int cap, int n_final, const float* dA, const float* sA, const int* act,
+                            const float* u_final, const float* beta_plus, float* d_fine, float* beta_map,
+                            float* iter_usage, void* stream);
+long long nerfart_volsdf_sampler_workspace_bytes(int n_rays, int n_init, int n_up, int n_final, int max_iter);
+int nerfart_volsdf_fine_sample(const float* surf_blob, const float* rays_o, const float* rays_dn, int n_rays,
+                               const float* near, const float* far, float near_s, float far_s, float R_bg,
+                               float alpha_net, float beta_net, float eps, int n_init, int n_up, int n_final,
+                               int max_iter, int max_bisect, float* d_fine, float* beta_map, float* iter_usage,
+                               void* workspace, long long workspace_bytes, void* stream);
+
+/* out[r] = sort(cat(a[r, :na], b[r, :nb]))  (volsdf.py:501-502) */
+int nerfart_sort_concat(int n_rays, const float* a, int na, int a_stride, const float* b, int nb, int b_stride,
+                        float* out, int out_stride, void* stream);
+
+/* sdf_to_sigma + ray integration (volsdf.py:34-53, :544-576).  normals / sigma_out / p_out / tau_out may be NULL. */
+int nerfart_volsdf_composite(int n_rays, int P, const float* d_all, const float* sdf, const float* radiance,
+                             const float* nabla, float alpha, float beta, int white_bkgd, float* rgb, float* depth,
+                             float* acc, float* normals, float* sigma_out, float* p_out, float* tau_out, void* stream);
+
+/* ---- B1: VolSDF volume_render (volsdf.py:389-615) for one chunk of rays (rays_d un-normalised). */
+long long nerfart_volsdf_render_workspace_bytes(int n_rays, int n_samples, int n_importance, int max_upsample_steps,
+                                                int k3_rays_chunk);
+int nerfart_volsdf_render_fwd(const float* surf_blob, const float* rad_blob, int view_tiles, const float* rays_o,
+                              const float* rays_d, int n_rays, float near_s, float far_s, float R_bg, float alpha,
+                              float beta, float eps, int n_samples, int n_importance, int max_upsample_steps,
+                              int max_bisection_steps, int white_bkgd, int k3_rays_chunk, float* rgb, float* depth,
+                              float* acc, float* normals, float* d_all_out, float* sdf_out, float* nabla_out,
+                              float* radiance_out, float* sigma_out, float* p_out, float* tau_out, float* beta_map_out,
+                              float* iter_usage_out, void* workspace, long long workspace_bytes, void* stream);
+
+/* ---- NeuS (models/frameworks/neus.py): up-sampling 'official_solution' :275-303, helpers :29-78,
+ * volume_render :142-424; near_far_from_sphere utils/rend_util.py:168-186. */
+int nerfart_near_far_from_sphere(const float* rays_o, const float* rays_dn, int n_rays, float r, float* near,
+                                 float* far, void* stream);
+int nerfart_neus_upsample_step(int n_rays, int n, int cap, int n_new, float inv_s, const float* d, const float* sdf,
+                               const float* u_new, float* d_new, void* stream);
+int nerfart_merge_sorted_pairs(int n_rays, int n, int cap, int n_new, float* d, float* sdf, const float* d_new,
+                               const float* s_new, void* stream);
+int nerfart_neus_composite(int n_rays, int P, const float* d_all, const float* sdf, const float* radiance_mid,
+                           const float* nabla, float s, int white_bkgd, float* rgb, float* depth, float* acc,
+                           float* normals, float* cdf_out, float* alpha_out, float* w_out, float* d_mid_out,
+                           void* stream);
+long long nerfart_neus_render_workspace_bytes(int n_rays, int n_samples, int n_importance, int k3_rays_chunk);
+int nerfart_neus_render_fwd(const float* surf_blob, const float* rad_blob, int view_tiles, const float* rays_o,
+                            const float* rays_d, int n_rays, float obj_bounding_radius, float s, int n_samples,
+                            int n_importance, int n_upsample_iters, int white_bkgd, int k3_rays_chunk, float* rgb,
+                            float* depth, float* acc, float* normals, float* d_all_out, float* sdf_out,
+                            float* nabla_out, float* radiance_out, float* cdf_out, float* alpha_out, float* w_out,
+                            float* d_mid_out, void* workspace, long long workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERFART_HIP_H */

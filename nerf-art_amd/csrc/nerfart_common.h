@@ -1,0 +1,98 @@
+// nerfart_common.h - shared device helpers for the gfx950 (CDNA4) kernels.
+//
+// Conventions used by every kernel in this directory:
+//   * wave = 64 lanes; lane = threadIdx.x & 63; wave id = threadIdx.x >> 6
+//   * MFMA used on the fp32 path: v_mfma_f32_16x16x4_f32 (exact f32, 32 cycles/SIMD)
+//       A: lane l holds A[i = l&15][k = l>>4]      (one VGPR)
+//       B: lane l holds B[k = l>>4][j = l&15]      (one VGPR)
+//       C/D: lane l, reg r holds C[row = 4*(l>>4) + r][col = l&15]
+//   * "g" = lane >> 4 (lane group 0..3), "j" = lane & 15 (column within the wave's tile)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define NERFART_MAGIC 0x4e414631  // 'NAF1'
+#define NERFART_HDR_INTS 512      // blob header size in 32-bit words (2 KiB)
+#define NERFART_HDR_OFFS 16       // header[16 + c] = float offset of chunk c (NC+1 entries)
+
+namespace nerfart {
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
+
+// Broadcast lane 0 of every quad (4 consecutive lanes) to the whole quad: one VALU op with DPP.
+__device__ __forceinline__ float quad_bcast0(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0 /*quad_perm:[0,0,0,0]*/, 0xF, 0xF, false));
+}
+
+// Sum over the 4 lane groups (lanes j, j+16, j+32, j+48): every lane ends with the total.
+__device__ __forceinline__ float sum_over_groups(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// One 16-byte-per-lane asynchronous global -> LDS copy (LDS-DMA).  The LDS destination is
+// wave-uniform base (M0) + lane*16, the global source is per lane.  Invisible to hipcc's
+// waitcnt bookkeeping on purpose: the caller drains it with wait_glds() before the barrier
+// that publishes the buffer (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void glds16(const float* gsrc_lane, unsigned lds_byte_addr_wave_uniform) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc_lane), "s"(lds_byte_addr_wave_uniform)
+        : "memory");
+}
+__device__ __forceinline__ void wait_glds() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return __builtin_amdgcn_readfirstlane((unsigned)(size_t)p);
+}
+
+// nn.Softplus(beta=100, threshold=20): x if 100x > 20 else log1p(exp(100x))/100
+// (reference models/base.py:202), evaluated in the overflow-free form
+//     y = max(z, 0) + log(1 + exp(-|100 z|)) / 100
+// with the hardware transcendentals (v_exp_f32 / v_log_f32, 1 ulp each).  Above the threshold the
+// correction term is < exp(-20)/100 = 2.1e-11, i.e. y == z to far below one ulp, so no compare/
+// select is needed; log(1+e) instead of log1p(e) costs at most 6e-8 absolute in the log = 6e-10
+// in y.  (The libm expf/log1pf forms cost ~200 instructions per value and would make the
+// epilogue, not the MFMAs, the bound of the kernel.)
+__device__ __forceinline__ float softplus100(float z) {
+    const float en = __builtin_amdgcn_exp2f(fabsf(z) * -144.269504088896340736f);     // exp(-|100 z|)
+    return fmaxf(z, 0.f) + __builtin_amdgcn_logf(1.0f + en) * (0.69314718055994530942f / 100.0f);
+}
+// value and derivative.  d = sigmoid(100 z) = 1/(1+en) for z >= 0, en/(1+en) for z < 0; for
+// 100 z > 20 this rounds to exactly 1.0f like torch's thresholded softplus_backward.
+__device__ __forceinline__ void softplus100_vd(float z, float& v, float& d) {
+    const float en = __builtin_amdgcn_exp2f(fabsf(z) * -144.269504088896340736f);
+    const float ope = 1.0f + en;
+    v = fmaxf(z, 0.f) + __builtin_amdgcn_logf(ope) * (0.69314718055994530942f / 100.0f);
+    const float r = __builtin_amdgcn_rcpf(ope);
+    d = (z >= 0.f) ? r : en * r;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// o + d * t with the two roundings of the reference's separate mul and add kernels
+// (volsdf.py:119 / :504), i.e. no FMA contraction.
+__device__ __forceinline__ float ray_point(float o, float d, float t) { return __fadd_rn(o, __fmul_rn(d, t)); }
+
+}  // namespace nerfart
+
+// ---- host side -----------------------------------------------------------------------
+namespace nerfart {
+void set_last_error(const char* s);
+int check_hip(hipError_t e, const char* what);
+}
+#define NERFART_HIP(expr)                                                   \
+    do {                                                                    \
+        int _rc = nerfart::check_hip((expr), #expr);                        \
+        if (_rc) return _rc;                                                \
+    } while (0)

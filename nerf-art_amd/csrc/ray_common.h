@@ -1,0 +1,154 @@
+// ray_common.h - wave-per-ray building blocks shared by the VolSDF / NeuS sampler and compositor
+// kernels.  One 64-lane wave owns one ray; the ray's samples live in LDS; prefix sums are
+// "sequential inside a lane's contiguous segment + shuffle scan across the 64 lanes".
+#pragma once
+#include "nerfart_common.h"
+#include <math.h>
+
+namespace nerfart {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// exclusive prefix sum over lanes (lane 0 gets 0)
+__device__ __forceinline__ float wave_excl_sum(float v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    const float e = __shfl_up(v, 1, 64);
+    return lane == 0 ? 0.f : e;
+}
+// exclusive prefix product over lanes (lane 0 gets 1)
+__device__ __forceinline__ float wave_excl_prod(float v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_up(v, o, 64);
+        if (lane >= o) v *= t;
+    }
+    const float e = __shfl_up(v, 1, 64);
+    return lane == 0 ? 1.f : e;
+}
+
+// a11 sdf_to_sigma (reference models/frameworks/volsdf.py:34-53)
+__device__ __forceinline__ float sdf_to_sigma(float s, float alpha, float beta) {
+    const float e = 0.5f * expf(-fabsf(s) / beta);
+    return alpha * ((s >= 0.f) ? e : 1.f - e);
+}
+
+// first index i in [0, n] with c[i] >= u  (torch.searchsorted(..., right=False))
+__device__ __forceinline__ int lower_bound(const float* c, int n, float u) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (c[mid] < u) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// first index i in [0, n] with c[i] > u
+__device__ __forceinline__ int upper_bound(const float* c, int n, float u) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (c[mid] <= u) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// Piece-wise linear inverse CDF of one sample (utils/rend_util.py:276-291): bracket by lower
+// bound, clamp to the array, a denominator below 1e-5 becomes 1.
+__device__ __forceinline__ float invert_cdf_at(const float* bins, const float* cdf, int n, float u) {
+    const int idx = lower_bound(cdf, n, u);
+    const int below = idx - 1 < 0 ? 0 : idx - 1;
+    const int above = idx > n - 1 ? n - 1 : idx;
+    const float c0 = cdf[below], c1 = cdf[above];
+    float denom = c1 - c0;
+    if (denom < 1e-5f) denom = 1.f;
+    const float t = (u - c0) / denom;
+    const float b0 = bins[below], b1 = bins[above];
+    return b0 + t * (b1 - b0);
+}
+
+// a12 error_bound (volsdf.py:56-94) of the n-1 intervals of one ray held in LDS.
+// Returns the maximum bound (wave-uniform).  If w_out != nullptr, bound k is also written to
+// w_out[k] (after NaN -> +inf and, if clamp, clamp to [0, 1e5] as volsdf.py:282).
+__device__ __forceinline__ float error_bound_scan(const float* d, const float* s, int n, float alpha, float beta,
+                                                  float* w_out, bool clamp) {
+    const int lane = threadIdx.x & 63;
+    const int nint = n - 1;
+    const int seg = (nint + 63) >> 6;
+    const int k0 = lane * seg;
+    const int k1 = (k0 + seg < nint) ? k0 + seg : nint;
+    const float a4b = alpha / (4.f * beta);
+    float sR = 0.f, sE = 0.f;
+    for (int k = k0; k < k1; ++k) {
+        const float delta = d[k + 1] - d[k];
+        sR += sdf_to_sigma(s[k], alpha, beta) * delta;
+        const float dstar = fmaxf(0.5f * (fabsf(s[k]) + fabsf(s[k + 1]) - delta), 0.f);
+        sE += a4b * (delta * delta) * expf(-dstar / beta);
+    }
+    float R = wave_excl_sum(sR), E = wave_excl_sum(sE);
+    float mx = -INFINITY;
+    for (int k = k0; k < k1; ++k) {
+        const float delta = d[k + 1] - d[k];
+        const float sd = sdf_to_sigma(s[k], alpha, beta) * delta;
+        const float dstar = fmaxf(0.5f * (fabsf(s[k]) + fabsf(s[k + 1]) - delta), 0.f);
+        E += a4b * (delta * delta) * expf(-dstar / beta);
+        float b = expf(-R) * (expf(E) - 1.f);
+        if (isnan(b)) b = INFINITY;
+        if (clamp) b = fminf(fmaxf(b, 0.f), 1e5f);
+        if (w_out) w_out[k] = b;
+        mx = fmaxf(mx, b);
+        R += sd;
+    }
+    return wave_max(mx);
+}
+
+// cdf[0] = 0, cdf[k+1] = 1 - exp(-R_t[k]) with R_t[k] = sum_{i<k} sigma_i delta_i, k = 0..n-2
+// (opacity_invert_cdf_sample, volsdf.py:122-136 + the leading zero of sample_cdf, rend_util.py:298-300)
+__device__ __forceinline__ void opacity_cdf(const float* d, const float* s, int n, float alpha, float beta, float* cdf) {
+    const int lane = threadIdx.x & 63;
+    const int nint = n - 1;
+    const int seg = (nint + 63) >> 6;
+    const int k0 = lane * seg;
+    const int k1 = (k0 + seg < nint) ? k0 + seg : nint;
+    float sR = 0.f;
+    for (int k = k0; k < k1; ++k) sR += sdf_to_sigma(s[k], alpha, beta) * (d[k + 1] - d[k]);
+    float R = wave_excl_sum(sR);
+    if (lane == 0) cdf[0] = 0.f;
+    for (int k = k0; k < k1; ++k) {
+        cdf[k + 1] = 1.f - expf(-R);
+        R += sdf_to_sigma(s[k], alpha, beta) * (d[k + 1] - d[k]);
+    }
+}
+
+// In-LDS bitonic sort (ascending) of n = power-of-two floats by one wave.
+__device__ __forceinline__ void bitonic_sort(float* a, int n) {
+    const int lane = threadIdx.x & 63;
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            for (int i = lane; i < n; i += 64) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const float x = a[i], y = a[p];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) { a[i] = y; a[p] = x; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+}  // namespace nerfart

@@ -1,0 +1,233 @@
+"""ctypes binding of libnerfart_hip.so (include/nerfart_hip.h) for PyTorch-ROCm tensors.
+
+PyTorch supplies device memory and the current HIP stream; every arithmetic step of the hot path
+runs in the library.  If the library is missing this module raises at import - there is no
+fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("NERFART_HIP_LIB", os.path.join(_HERE, "csrc", "libnerfart_hip.so"))
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build the gfx950 kernels first "
+        f"(python -c 'import __graft_entry__ as g; g.build()'  or  python -m nerfart_amd.build). "
+        f"nerf-art_amd has no CPU / eager-PyTorch fallback.")
+
+lib = C.CDLL(LIB_PATH)
+
+_p, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+_SIGS = {
+    "nerfart_abi_version": (_i, []),
+    "nerfart_last_error": (C.c_char_p, []),
+    "nerfart_linspace": (None, [_f, _f, _i, _p]),
+    "nerfart_sdf_fwd": (_i, [_p, _p, _ll, _f, _p, _p]),
+    "nerfart_sdf_fwd_rays": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _i, _p]),
+    "nerfart_sdf_nabla_fwd": (_i, [_p, _p, _ll, _f, _p, _p, _p, _p]),
+    "nerfart_sdf_nabla_fwd_rays": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p]),
+    "nerfart_radiance_fwd": (_i, [_p, _i, _p, _p, _ll, _p, _p, _p, _p]),
+    "nerfart_radiance_fwd_rays": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
+    "nerfart_get_rays": (_i, [_p, _p, _i, _i, _p, _i, _p, _p, _p]),
+    "nerfart_normalize_dirs": (_i, [_p, _p, _i, _p]),
+    "nerfart_linspace_depths": (_i, [_p, _i, _p, _p, _f, _f, _i, _p, _i, _p]),
+    "nerfart_volsdf_first_check": (_i, [_i, _i, _i, _i, _f, _f, _f, _p, _p, _p, _f, _p, _f, _p, _p, _p, _p, _p, _p, _p]),
+    "nerfart_volsdf_upsample": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p]),
+    "nerfart_volsdf_merge_check": (_i, [_i, _i, _i, _i, _i, _i, _i, _f, _f, _f] + [_p] * 15),
+    "nerfart_volsdf_finalize": (_i, [_i, _i, _i, _i] + [_p] * 9),
+    "nerfart_volsdf_sampler_workspace_bytes": (_ll, [_i, _i, _i, _i, _i]),
+    "nerfart_volsdf_fine_sample": (_i, [_p, _p, _p, _i, _p, _p, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _p, _p, _p, _p, _ll, _p]),
+    "nerfart_sort_concat": (_i, [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p]),
+    "nerfart_volsdf_composite": (_i, [_i, _i, _p, _p, _p, _p, _f, _f, _i] + [_p] * 8),
+    "nerfart_volsdf_render_workspace_bytes": (_ll, [_i, _i, _i, _i, _i]),
+    "nerfart_volsdf_render_fwd": (_i, [_p, _p, _i, _p, _p, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i] + [_p] * 13 + [_p, _ll, _p]),
+    "nerfart_near_far_from_sphere": (_i, [_p, _p, _i, _f, _p, _p, _p]),
+    "nerfart_neus_upsample_step": (_i, [_i, _i, _i, _i, _f, _p, _p, _p, _p, _p]),
+    "nerfart_merge_sorted_pairs": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "nerfart_neus_composite": (_i, [_i, _i, _p, _p, _p, _p, _f, _i] + [_p] * 9),
+    "nerfart_neus_render_workspace_bytes": (_ll, [_i, _i, _i, _i]),
+    "nerfart_neus_render_fwd": (_i, [_p, _p, _i, _p, _p, _i, _f, _f, _i, _i, _i, _i, _i] + [_p] * 12 + [_p, _ll, _p]),
+}
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)          # AttributeError here = header / library mismatch
+    _fn.restype, _fn.argtypes = _res, _args
+
+ABI_VERSION = lib.nerfart_abi_version()
+
+
+class NerfartHipError(RuntimeError):
+    pass
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise NerfartHipError(f"{what} failed (code {rc}): {lib.nerfart_last_error().decode(errors='replace')}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, dtype=torch.float32, name="tensor") -> int:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise NerfartHipError(f"{name} must live on the GPU (got {t.device}); nerf-art_amd has no CPU path")
+    if t.dtype != dtype:
+        raise NerfartHipError(f"{name} must be {dtype} (got {t.dtype})")
+    if not t.is_contiguous():
+        raise NerfartHipError(f"{name} must be contiguous")
+    return t.data_ptr()
+
+
+def linspace(start: float, end: float, n: int) -> torch.Tensor:
+    """Host helper: the library's restatement of torch.linspace (used for its own tables)."""
+    out = torch.empty(n, dtype=torch.float32)
+    lib.nerfart_linspace(start, end, n, out.data_ptr())
+    return out
+
+
+# ---- point queries -----------------------------------------------------------------------
+def sdf_fwd(surf_blob, pts, R_bg: float):
+    M = pts.shape[0]
+    out = torch.empty(M, dtype=torch.float32, device=pts.device)
+    _check(lib.nerfart_sdf_fwd(_dev(surf_blob, name="surf_blob"), _dev(pts, name="pts"), M, float(R_bg), _dev(out), _stream()),
+           "nerfart_sdf_fwd")
+    return out
+
+
+def sdf_nabla_fwd(surf_blob, pts, R_bg: float, want_h7: bool = True):
+    M = pts.shape[0]
+    sdf = torch.empty(M, dtype=torch.float32, device=pts.device)
+    nab = torch.empty(M, 3, dtype=torch.float32, device=pts.device)
+    h7 = torch.empty(M, 256, dtype=torch.float32, device=pts.device) if want_h7 else None
+    _check(lib.nerfart_sdf_nabla_fwd(_dev(surf_blob), _dev(pts, name="pts"), M, float(R_bg), _dev(sdf), _dev(nab),
+                                     _dev(h7), _stream()), "nerfart_sdf_nabla_fwd")
+    return sdf, nab, h7
+
+
+def radiance_fwd(rad_blob, view_tiles: int, pts, view, nabla, h7):
+    M = pts.shape[0]
+    rgb = torch.empty(M, 3, dtype=torch.float32, device=pts.device)
+    _check(lib.nerfart_radiance_fwd(_dev(rad_blob), int(view_tiles), _dev(pts, name="pts"), _dev(view, name="view"), M,
+                                    _dev(nabla, name="nabla"), _dev(h7, name="h7"), _dev(rgb), _stream()),
+           "nerfart_radiance_fwd")
+    return rgb
+
+
+def sdf_fwd_rays(surf_blob, rays_o, rays_dn, depth, R_bg: float, ray_idx=None, n_per_ray=None):
+    """depth [n_slots, stride >= n_per_ray] -> sdf [n_slots, n_per_ray]"""
+    n_slots, stride = depth.shape
+    n_per_ray = stride if n_per_ray is None else n_per_ray
+    out = torch.empty(n_slots, n_per_ray, dtype=torch.float32, device=depth.device)
+    _check(lib.nerfart_sdf_fwd_rays(_dev(surf_blob), _dev(rays_o), _dev(rays_dn), _dev(ray_idx, torch.int32),
+                                    _dev(depth), n_slots, n_per_ray, stride, float(R_bg), _dev(out), n_per_ray, _stream()),
+           "nerfart_sdf_fwd_rays")
+    return out
+
+
+# ---- rays ------------------------------------------------------------------------------------
+def get_rays(pose, K, H: int, W: int, select=None):
+    n = H * W if select is None else select.numel()
+    o = torch.empty(n, 3, dtype=torch.float32, device=pose.device)
+    d = torch.empty(n, 3, dtype=torch.float32, device=pose.device)
+    _check(lib.nerfart_get_rays(_dev(pose, name="pose"), _dev(K, name="K"), H, W, _dev(select, torch.int64), n, _dev(o), _dev(d),
+                                _stream()), "nerfart_get_rays")
+    return o, d
+
+
+def normalize_dirs(d):
+    out = torch.empty_like(d)
+    _check(lib.nerfart_normalize_dirs(_dev(d), _dev(out), d.shape[0], _stream()), "nerfart_normalize_dirs")
+    return out
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    """One cached byte buffer per device, grown on demand (288 GB of HBM: keep it resident)."""
+    key = str(device)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        _ws_cache[key] = None
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def volsdf_fine_sample(surf_blob, rays_o, rays_dn, near: float, far: float, R_bg: float, alpha: float, beta: float,
+                       eps: float, n_init: int, n_up: int, n_final: int, max_iter: int, max_bisect: int):
+    R = rays_o.shape[0]
+    dev = rays_o.device
+    d_fine = torch.empty(R, n_final, dtype=torch.float32, device=dev)
+    beta_map = torch.empty(R, dtype=torch.float32, device=dev)
+    usage = torch.empty(R, dtype=torch.float32, device=dev)
+    nb = lib.nerfart_volsdf_sampler_workspace_bytes(R, n_init, n_up, n_final, max_iter)
+    ws = _workspace(nb, dev)
+    _check(lib.nerfart_volsdf_fine_sample(_dev(surf_blob), _dev(rays_o), _dev(rays_dn), R, None, None, float(near), float(far),
+                                          float(R_bg), float(alpha), float(beta), float(eps), n_init, n_up, n_final, max_iter,
+                                          max_bisect, _dev(d_fine), _dev(beta_map), _dev(usage), ws.data_ptr(), ws.numel(),
+                                          _stream()), "nerfart_volsdf_fine_sample")
+    return d_fine, beta_map, usage
+
+
+def volsdf_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, near, far, R_bg, alpha, beta, eps=0.1,
+                  n_samples=128, n_importance=64, max_upsample_steps=5, max_bisection_steps=10, white_bkgd=False,
+                  calc_normal=True, detailed=False, k3_rays_chunk=8192):
+    """One chunk of rays through nerfart_volsdf_render_fwd.  Returns a dict of flat [R, ...] tensors."""
+    R = rays_o.shape[0]
+    dev = rays_o.device
+    P = n_samples + n_importance
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    out = {"rgb": f(R, 3), "depth_volume": f(R), "mask_volume": f(R)}
+    if calc_normal:
+        out["normals_volume"] = f(R, 3)
+    det = {}
+    if detailed:
+        det = {"d_vals": f(R, P), "implicit_surface": f(R, P), "implicit_nablas": f(R, P, 3), "radiance": f(R, P, 3),
+               "sigma": f(R, P), "p_i": f(R, P - 1), "visibility_weights": f(R, P - 1), "beta_map": f(R), "iter_usage": f(R)}
+    nb = lib.nerfart_volsdf_render_workspace_bytes(R, n_samples, n_importance, max_upsample_steps, k3_rays_chunk)
+    ws = _workspace(nb, dev)
+    g = lambda k: _dev(det.get(k))
+    _check(lib.nerfart_volsdf_render_fwd(
+        _dev(surf_blob), _dev(rad_blob), int(view_tiles), _dev(rays_o, name="rays_o"), _dev(rays_d, name="rays_d"), R,
+        float(near), float(far), float(R_bg), float(alpha), float(beta), float(eps), n_samples, n_importance,
+        max_upsample_steps, max_bisection_steps, int(bool(white_bkgd)), k3_rays_chunk,
+        _dev(out["rgb"]), _dev(out["depth_volume"]), _dev(out["mask_volume"]), _dev(out.get("normals_volume")),
+        g("d_vals"), g("implicit_surface"), g("implicit_nablas"), g("radiance"), g("sigma"), g("p_i"),
+        g("visibility_weights"), g("beta_map"), g("iter_usage"), ws.data_ptr(), ws.numel(), _stream()),
+        "nerfart_volsdf_render_fwd")
+    out.update(det)
+    return out
+
+
+def neus_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, obj_bounding_radius, s, n_samples=64, n_importance=64,
+                n_upsample_iters=4, white_bkgd=False, calc_normal=True, detailed=False, k3_rays_chunk=8192):
+    R = rays_o.shape[0]
+    dev = rays_o.device
+    P = n_samples + n_importance
+    f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+    out = {"rgb": f(R, 3), "depth_volume": f(R), "mask_volume": f(R)}
+    if calc_normal:
+        out["normals_volume"] = f(R, 3)
+    det = {}
+    if detailed:
+        det = {"d_all": f(R, P), "implicit_surface": f(R, P), "implicit_nablas": f(R, P, 3), "radiance": f(R, P - 1, 3),
+               "cdf": f(R, P), "alpha": f(R, P - 1), "visibility_weights": f(R, P - 1), "d_final": f(R, P - 1)}
+    nb = lib.nerfart_neus_render_workspace_bytes(R, n_samples, n_importance, k3_rays_chunk)
+    ws = _workspace(nb, dev)
+    g = lambda k: _dev(det.get(k))
+    _check(lib.nerfart_neus_render_fwd(
+        _dev(surf_blob), _dev(rad_blob), int(view_tiles), _dev(rays_o, name="rays_o"), _dev(rays_d, name="rays_d"), R,
+        float(obj_bounding_radius), float(s), n_samples, n_importance, n_upsample_iters, int(bool(white_bkgd)), k3_rays_chunk,
+        _dev(out["rgb"]), _dev(out["depth_volume"]), _dev(out["mask_volume"]), _dev(out.get("normals_volume")),
+        g("d_all"), g("implicit_surface"), g("implicit_nablas"), g("radiance"), g("cdf"), g("alpha"),
+        g("visibility_weights"), g("d_final"), ws.data_ptr(), ws.numel(), _stream()), "nerfart_neus_render_fwd")
+    out.update(det)
+    return out

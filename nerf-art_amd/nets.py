@@ -1,0 +1,237 @@
+"""Host-side model containers with the reference's checkpoint layout.
+
+Mirrors the reference classes (models/base.py: ImplicitSurface :131-282, RadianceNet :312-391;
+models/frameworks/volsdf.py: VolSDF :304-370; neus.py: NeuS :80-123) at the level the hot path
+needs: same constructor arguments, same ``state_dict`` keys / shapes / order
+(``ln_beta`` | ``ln_s``, ``implicit_surface.obj_bounding_size``,
+``implicit_surface.surface_fc_layers.{i}.{bias,weight_g,weight_v}``,
+``radiance_net.layers.{i}.{bias,weight_g,weight_v}``), same geometric initialisation drawn from
+the same RNG calls, and the same query methods - ``forward``, ``forward_surface``,
+``forward_surface_with_nablas``, ``forward_ab`` / ``forward_s`` - whose arithmetic runs in the HIP
+library (csrc/mlp_chain.hip) on packed weights.  There is no eager-PyTorch compute path here.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import packing
+from . import hip
+
+
+def embed_dim(multires: int, c: int = 3) -> int:
+    return c if multires < 0 else c * (1 + 2 * multires)
+
+
+class WNLinear(nn.Module):
+    """A weight-normed linear layer as it sits in a reference checkpoint: parameters
+    ``bias[out]``, ``weight_g[out,1]``, ``weight_v[out,in]`` in that order
+    (``nn.utils.weight_norm(nn.Linear)``, models/base.py:226-227, :365-366)."""
+
+    def __init__(self, weight: torch.Tensor, bias: torch.Tensor):
+        super().__init__()
+        self.bias = nn.Parameter(bias.detach().clone())
+        self.weight_g = nn.Parameter(weight.detach().norm(dim=1, keepdim=True))
+        self.weight_v = nn.Parameter(weight.detach().clone())
+
+    @property
+    def in_features(self):
+        return self.weight_v.shape[1]
+
+    @property
+    def out_features(self):
+        return self.weight_v.shape[0]
+
+
+class ImplicitSurface(nn.Module):
+    """SDF MLP container (models/base.py:131-231).  Initialisation reproduces :207-224 call for call."""
+
+    def __init__(self, W=256, D=8, skips=(4,), W_geo_feat=256, input_ch=3, radius_init=1.0,
+                 obj_bounding_size=2.0, geometric_init=True, embed_multires=6, weight_norm=True,
+                 use_siren=False):
+        super().__init__()
+        if use_siren or not weight_norm:
+            raise NotImplementedError("SIREN / un-normed surfaces are outside the hot-path scope (SURVEY.md 2, row 19)")
+        self.radius_init, self.D, self.W, self.W_geo_feat = radius_init, D, W, W_geo_feat
+        self.skips = list(skips)
+        self.embed_multires = embed_multires
+        self.register_buffer("obj_bounding_size", torch.tensor([obj_bounding_size]).float())
+        in0 = embed_dim(embed_multires, input_ch)
+        layers = []
+        for l in range(D + 1):
+            if l == D:
+                out_dim = 1 + W_geo_feat if W_geo_feat > 0 else 1
+            elif (l + 1) in self.skips:
+                out_dim = W - in0
+            else:
+                out_dim = W
+            in_dim = in0 if l == 0 else W
+            lin = nn.Linear(in_dim, out_dim)            # consumes the same RNG draws as the reference
+            if geometric_init:
+                if l == D:
+                    nn.init.normal_(lin.weight, mean=np.sqrt(np.pi) / np.sqrt(in_dim), std=0.0001)
+                    nn.init.constant_(lin.bias, -radius_init)
+                elif embed_multires > 0 and l == 0:
+                    nn.init.constant_(lin.bias, 0.0)
+                    nn.init.constant_(lin.weight[:, 3:], 0.0)
+                    nn.init.normal_(lin.weight[:, :3], 0.0, np.sqrt(2) / np.sqrt(out_dim))
+                elif embed_multires > 0 and l in self.skips:
+                    nn.init.constant_(lin.bias, 0.0)
+                    nn.init.normal_(lin.weight, 0.0, np.sqrt(2) / np.sqrt(out_dim))
+                    nn.init.constant_(lin.weight[:, -(in0 - 3):], 0.0)
+                else:
+                    nn.init.constant_(lin.bias, 0.0)
+                    nn.init.normal_(lin.weight, 0.0, np.sqrt(2) / np.sqrt(out_dim))
+            layers.append(WNLinear(lin.weight.data, lin.bias.data))
+        self.surface_fc_layers = nn.ModuleList(layers)
+
+
+class RadianceNet(nn.Module):
+    """Radiance MLP container (models/base.py:312-370)."""
+
+    def __init__(self, D=4, W=256, skips=(), W_geo_feat=256, embed_multires=-1, embed_multires_view=-1,
+                 use_view_dirs=True, weight_norm=True, use_siren=False):
+        super().__init__()
+        if use_siren or not weight_norm or len(skips) or not use_view_dirs:
+            raise NotImplementedError("radiance variants outside the four reference configs (SURVEY.md 2, row 19)")
+        self.D, self.W = D, W
+        self.embed_multires, self.embed_multires_view = embed_multires, embed_multires_view
+        in0 = embed_dim(embed_multires) + embed_dim(embed_multires_view) + 3 + W_geo_feat
+        layers = []
+        for l in range(D + 1):
+            lin = nn.Linear(in0 if l == 0 else W, 3 if l == D else W)
+            layers.append(WNLinear(lin.weight.data, lin.bias.data))
+        self.layers = nn.ModuleList(layers)
+
+
+class _PackedModel(nn.Module):
+    """Shared machinery: folded + packed weight blobs, refreshed when parameters change."""
+
+    def _init_packing(self):
+        s, r = self.implicit_surface, self.radiance_net
+        self._surf_plan = packing.surface_plan(s.W, s.D, tuple(s.skips), s.embed_multires, s.W_geo_feat)
+        if r.embed_multires != -1 or r.embed_multires_view not in (-1, 4):
+            raise NotImplementedError("radiance embed_multires must be -1 and embed_multires_view in (-1, 4)")
+        self.view_tiles = 1 if r.embed_multires_view == -1 else 3
+        self._rad_plan = packing.radiance_plan(self.view_tiles, r.W, r.D, s.W_geo_feat)
+        self._blobs = None
+        self._blob_key = None
+
+    def _param_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def packed(self):
+        """(surface_blob, radiance_blob) for the current parameters; re-packed only after an
+        in-place update (optimizer step / load_state_dict) - the reference re-folds weight_norm on
+        every forward, 77x per ray chunk."""
+        key = self._param_key()
+        if self._blobs is None or key != self._blob_key:
+            sd = {k: v.detach() for k, v in self.state_dict().items()}
+            with torch.no_grad():
+                self._blobs = (self._surf_plan.pack(packing.surface_tensors(sd, D=self.implicit_surface.D)),
+                               self._rad_plan.pack(packing.radiance_tensors(sd, D_surf=self.implicit_surface.D,
+                                                                            D=self.radiance_net.D)))
+            self._blob_key = key
+        return self._blobs
+
+    # ---- point queries (boundaries B2 / B3 of SURVEY.md 8b) -------------------------------
+    def _flat(self, x):
+        return x.reshape(-1, 3).contiguous().float()
+
+    def _surface_query(self, x, R_bg, with_nablas, want_h7):
+        blob, _ = self.packed()
+        xf = self._flat(x)
+        if with_nablas:
+            sdf, nab, h7 = hip.sdf_nabla_fwd(blob, xf, R_bg, want_h7=want_h7)
+            return sdf.reshape(x.shape[:-1]), nab.reshape(x.shape), h7
+        sdf = hip.sdf_fwd(blob, xf, R_bg)
+        return sdf.reshape(x.shape[:-1])
+
+    def _radiance_query(self, x, view_dirs, nablas, h7):
+        _, rblob = self.packed()
+        rgb = hip.radiance_fwd(rblob, self.view_tiles, self._flat(x), self._flat(view_dirs),
+                               self._flat(nablas), h7)
+        return rgb.reshape(x.shape)
+
+
+class VolSDF(_PackedModel):
+    """(models/frameworks/volsdf.py:304-370)"""
+
+    def __init__(self, beta_init=0.1, speed_factor=1.0, input_ch=3, W_geo_feat=-1, obj_bounding_radius=3.0,
+                 use_nerfplusplus=False, surface_cfg=None, radiance_cfg=None):
+        super().__init__()
+        if use_nerfplusplus:
+            raise NotImplementedError("outside_scene: nerf++ is outside the hot-path scope (SURVEY.md 2, row 19)")
+        self.speed_factor = speed_factor
+        self.ln_beta = nn.Parameter(torch.Tensor([np.log(beta_init) / speed_factor]))
+        self.use_sphere_bg = True
+        self.obj_bounding_radius = obj_bounding_radius
+        self.implicit_surface = ImplicitSurface(W_geo_feat=W_geo_feat, input_ch=input_ch,
+                                                obj_bounding_size=obj_bounding_radius, **(surface_cfg or {}))
+        if W_geo_feat < 0:
+            W_geo_feat = self.implicit_surface.W
+        self.radiance_net = RadianceNet(W_geo_feat=W_geo_feat, **(radiance_cfg or {}))
+        self._init_packing()
+
+    def forward_ab(self):
+        beta = torch.exp(self.ln_beta * self.speed_factor)
+        return 1.0 / beta, beta
+
+    def forward_surface(self, x: torch.Tensor):
+        """sdf = min(net(x), R - |x|) (volsdf.py:341-347).  The reference also returns the 256-d
+        feature and drops it at every call site on this path; it is not
+        materialised here - the second tuple element is None."""
+        return self._surface_query(x, self.obj_bounding_radius, False, False), None
+
+    def forward_surface_with_nablas(self, x: torch.Tensor):
+        sdf, nab, h7 = self._surface_query(x, self.obj_bounding_radius, True, True)
+        return sdf, nab, h7
+
+    def forward(self, x: torch.Tensor, view_dirs: torch.Tensor = None, return_nablas=False):
+        """(radiance, sdf, nablas) (volsdf.py:359-370)."""
+        if view_dirs is None:
+            raise NotImplementedError("use_view_dirs=False is not used by any reference config")
+        sdf, nab, h7 = self._surface_query(x, self.obj_bounding_radius, True, True)
+        rad = self._radiance_query(x, view_dirs, nab, h7)
+        return rad, sdf, nab
+
+
+class NeuS(_PackedModel):
+    """(models/frameworks/neus.py:80-123)"""
+
+    def __init__(self, variance_init=0.05, speed_factor=1.0, input_ch=3, W_geo_feat=-1, use_outside_nerf=False,
+                 obj_bounding_radius=1.0, surface_cfg=None, radiance_cfg=None):
+        super().__init__()
+        if use_outside_nerf:
+            raise NotImplementedError("NeRF++ outside net is outside the hot-path scope (SURVEY.md 2, row 19)")
+        self.ln_s = nn.Parameter(torch.Tensor([-np.log(variance_init) / speed_factor]))
+        self.speed_factor = speed_factor
+        self.obj_bounding_radius = obj_bounding_radius
+        self.implicit_surface = ImplicitSurface(W_geo_feat=W_geo_feat, input_ch=input_ch,
+                                                obj_bounding_size=obj_bounding_radius, **(surface_cfg or {}))
+        if W_geo_feat < 0:
+            W_geo_feat = self.implicit_surface.W
+        self.radiance_net = RadianceNet(W_geo_feat=W_geo_feat, **(radiance_cfg or {}))
+        self._init_packing()
+
+    def forward_s(self):
+        return torch.exp(self.ln_s * self.speed_factor)
+
+    def forward_sdf(self, x):
+        """implicit_surface.forward(x) (no sphere clamp; neus.py:277,299)."""
+        return self._surface_query(x, 0.0, False, False)
+
+    def forward_sdf_with_nablas(self, x):
+        sdf, nab, _ = self._surface_query(x, 0.0, True, False)
+        return sdf, nab
+
+    def forward_radiance(self, x, view_dirs, return_nablas=False):
+        _, nab, h7 = self._surface_query(x, 0.0, True, True)
+        return self._radiance_query(x, view_dirs, nab, h7)
+
+    def forward(self, x, view_dirs, return_nablas=False):
+        sdf, nab, h7 = self._surface_query(x, 0.0, True, True)
+        return self._radiance_query(x, view_dirs, nab, h7), sdf, nab

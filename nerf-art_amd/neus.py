@@ -1,0 +1,100 @@
+"""NeuS renderer with the reference's boundary (models/frameworks/neus.py:142-432), on the HIP library.
+
+``volume_render(rays_o, rays_d, model, **kw) -> (rgb, depth, extras)``; ``extras`` carries the reference's
+keys (:384-407).  upsample_algo must be 'official_solution' (the only one the configs use) and
+N_outside = 0 (configs: ``outside_scene`` absent, ``with_mask: True``).
+"""
+from __future__ import annotations
+
+import copy
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import hip
+from .nets import NeuS
+
+DEFAULT_RAYSCHUNK = 65536
+
+
+def volume_render(rays_o, rays_d, model: NeuS, obj_bounding_radius=1.0, batched=False, batched_info=None,
+                  calc_normal=False, use_view_dirs=True, rayschunk=None, netchunk=1048576, white_bkgd=False,
+                  near_bypass=None, far_bypass=None, detailed_output=True, show_progress=False, perturb=False,
+                  fixed_s_recp=1 / 64., N_samples=64, N_importance=64, N_outside=0, upsample_algo="official_solution",
+                  N_nograd_samples=2048, N_upsample_iters=4, k3_rays_chunk=8192, **dummy_kwargs):
+    if upsample_algo != "official_solution" or N_outside > 0 or near_bypass is not None or far_bypass is not None:
+        raise NotImplementedError("NeuS render: only upsample_algo='official_solution', N_outside=0, no near/far "
+                                  "bypass (the reference configs) are on the HIP path")
+    if perturb:
+        raise NotImplementedError("perturb=True belongs to the reconstruction-training sampler (SURVEY.md 8f)")
+    if not use_view_dirs:
+        raise NotImplementedError("use_view_dirs=False is not used by any reference config")
+    lead = rays_o.shape[:-1]
+    ro = rays_o.reshape(-1, 3).float().contiguous()
+    rd = rays_d.reshape(-1, 3).float().contiguous()
+    N = ro.shape[0]
+    surf_blob, rad_blob = model.packed()
+    s = float(model.forward_s())
+    chunk = int(rayschunk) if rayschunk else DEFAULT_RAYSCHUNK
+    parts = []
+    for i in range(0, N, chunk):
+        parts.append(hip.neus_render(
+            surf_blob, rad_blob, model.view_tiles, ro[i:i + chunk], rd[i:i + chunk],
+            obj_bounding_radius=obj_bounding_radius, s=s, n_samples=N_samples, n_importance=N_importance,
+            n_upsample_iters=N_upsample_iters, white_bkgd=white_bkgd, calc_normal=calc_normal,
+            detailed=detailed_output, k3_rays_chunk=k3_rays_chunk))
+    ret = OrderedDict()
+    for k in ["rgb", "depth_volume", "mask_volume", "normals_volume", "implicit_nablas", "implicit_surface", "radiance",
+              "alpha", "cdf", "visibility_weights", "d_final"]:
+        if k in parts[0]:
+            v = torch.cat([p[k] for p in parts], 0) if len(parts) > 1 else parts[0][k]
+            ret[k] = v.reshape(*lead, *v.shape[1:])
+    return ret["rgb"], ret["depth_volume"], ret
+
+
+class SingleRenderer(nn.Module):
+    def __init__(self, model: NeuS):
+        super().__init__()
+        self.model = model
+
+    def forward(self, rays_o, rays_d, **kwargs):
+        return volume_render(rays_o, rays_d, self.model, **kwargs)
+
+
+def get_model(args, render_target=None):
+    """(neus.py:693-750)"""
+    m, t = args.model, args.training
+    model_config = {
+        "obj_bounding_radius": m.obj_bounding_radius,
+        "W_geo_feat": m.setdefault("W_geometry_feature", 256),
+        "use_outside_nerf": False,
+        "speed_factor": t.setdefault("speed_factor", 1.0),
+        "variance_init": m.setdefault("variance_init", 0.05),
+    }
+    s, r = m.surface, m.radiance
+    model_config["surface_cfg"] = {
+        "embed_multires": s.setdefault("embed_multires", 6), "radius_init": s.setdefault("radius_init", 1.0),
+        "geometric_init": s.setdefault("geometric_init", True), "D": s.setdefault("D", 8), "W": s.setdefault("W", 256),
+        "skips": s.setdefault("skips", [4]),
+    }
+    model_config["radiance_cfg"] = {
+        "embed_multires": r.setdefault("embed_multires", -1),
+        "embed_multires_view": r.setdefault("embed_multires_view", -1),
+        "use_view_dirs": r.setdefault("use_view_dirs", True),
+        "D": r.setdefault("D", 4), "W": r.setdefault("W", 256), "skips": r.setdefault("skips", []),
+    }
+    model = NeuS(**model_config)
+    render_kwargs_train = {
+        "upsample_algo": m.setdefault("upsample_algo", "official_solution"),
+        "N_nograd_samples": m.setdefault("N_nograd_samples", 2048),
+        "N_upsample_iters": m.setdefault("N_upsample_iters", 4),
+        "N_outside": m.setdefault("N_outside", 0),
+        "obj_bounding_radius": args.data.setdefault("obj_bounding_radius", 1.0),     # (sic) data, not model: neus.py:738
+        "batched": args.data.batch_size is not None,
+        "perturb": m.setdefault("perturb", True), "white_bkgd": m.setdefault("white_bkgd", False),
+    }
+    render_kwargs_test = copy.deepcopy(render_kwargs_train)
+    render_kwargs_test["rayschunk"] = args.data.val_rayschunk
+    render_kwargs_test["perturb"] = False
+    return model, None, render_kwargs_train, render_kwargs_test, SingleRenderer(model)

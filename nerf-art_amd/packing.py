@@ -1,0 +1,259 @@
+"""Weight packing for the chained-MLP HIP kernels (csrc/mlp_chain.hip).
+
+The kernels keep activations in MFMA C-layout registers: lane (g, i) of a wave holds, for tile
+t and register r, feature *slot* 16t + 4g + r of its column.  A layer is
+``out^T = W . h^T`` evaluated k-outer: for every 16-wide k tile, for every 16-wide output
+tile T, four ``v_mfma_f32_16x16x4_f32`` whose A fragment for k-step r is
+``A[lane=(g,i)] = W[16T + i][16t + 4g + r]``.  This module lays the folded
+(``w = g * v / ||v||``, reference models/base.py:226-227) weights out in exactly that order so
+that the kernel's weight stream is a linear copy and each lane reads its four k-steps with one
+``ds_read_b128``:
+
+    blob  = int32 header[512] | chunk 0 | chunk 1 | ... | aux
+    chunk = 1 or 2 k tiles;  k tile = float[T=16][lane=64][r=4]  (16 KiB)
+
+Slots are the reference's feature indices except where the kernel is free to choose:
+  * the 39 positional-encoding features occupy 48 slots ordered per lane group
+    (``enc_slot_feature``), because lane group g computes the sin/cos of coordinate g;
+  * the radiance net's first-layer inputs are ordered [feat(256) | x, view, normal] because
+    the 256 geometry features arrive as 16 full tiles.
+
+Nothing here is numerics: packing is a gather (``packed = flat_weights[index]``).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+MAGIC = 0x4E414631
+HDR_INTS = 512
+HDR_OFFS = 16
+KT = 16 * 64 * 4          # floats per k tile
+PROG_SURFACE = 1
+PROG_RADIANCE = 2
+
+SURF_AUX_ROW = 2048
+SURF_AUX_B8 = 2304
+SURF_AUX_FLOATS = 2308
+RAD_AUX_ROWS = 1280
+RAD_AUX_BF = 2048
+RAD_AUX_FLOATS = 2052
+
+
+def enc_slot_feature(slot: int, multires: int = 6) -> int:
+    """Slot (0..47) of the SDF-net encoding -> reference feature index (0..38) or -1 (padding).
+
+    Reference order (models/base.py:53-61): [x(3), sin(2^0 x)(3), cos(2^0 x)(3), sin(2^1 x)(3), ...].
+    Slot order: lane group g < 3 owns coordinate g: m = 0 raw, m = 1+2k sin(2^k .), m = 2+2k cos(2^k .)
+    for k < 5, m = 11 pad; lane group 3 owns the last band k = 5: m = 2i sin(32 x_i), m = 2i+1 cos.
+    """
+    assert multires == 6, "the gfx950 kernels are built for embed_multires = 6 (39 features)"
+    t, rem = divmod(slot, 16)
+    g, r = divmod(rem, 4)
+    m = 4 * t + r
+    if g < 3:
+        if m == 0:
+            return g
+        if m == 11:
+            return -1
+        k, is_cos = divmod(m - 1, 2)
+        return 3 + 6 * k + 3 * is_cos + g
+    if m < 6:
+        i, is_cos = divmod(m, 2)
+        return 3 + 6 * 5 + 3 * is_cos + i
+    return -1
+
+
+ENC_SLOTS = np.array([enc_slot_feature(s) for s in range(48)], dtype=np.int64)
+
+
+class _Flat:
+    """Flat concatenation of the source tensors (folded weights, biases) plus one trailing zero."""
+
+    def __init__(self):
+        self.names, self.base, self.shape, self.n = [], {}, {}, 0
+
+    def add(self, name, shape):
+        self.names.append(name)
+        self.base[name] = self.n
+        self.shape[name] = tuple(shape)
+        self.n += int(np.prod(shape))
+
+    @property
+    def zero(self):
+        return self.n
+
+    def mat_index(self, name, rows, cols):
+        """rows[R], cols[C] (int, -1 = zero) -> [R, C] flat indices."""
+        R, C = self.shape[name]
+        idx = self.base[name] + rows[:, None] * C + cols[None, :]
+        idx = np.where((rows[:, None] < 0) | (cols[None, :] < 0), self.zero, idx)
+        return idx
+
+    def vec_index(self, name, sel):
+        idx = self.base[name] + sel
+        return np.where(sel < 0, self.zero, idx)
+
+
+def _ktile_index(midx, t):
+    """midx [256 out slots, K in slots] flat indices -> k tile t as [T=16][lane=64][r=4]."""
+    out = np.empty((16, 64, 4), dtype=np.int64)
+    lane = np.arange(64)
+    g, i = lane // 16, lane % 16
+    for T in range(16):
+        for r in range(4):
+            out[T, :, r] = midx[16 * T + i, 16 * t + 4 * g + r]
+    return out.reshape(-1)
+
+
+def _layer_chunks(midx, nt_base, nt_extra):
+    """Chunk sequence of one layer: ceil(nt_base/2) chunks of base k tiles, then ceil(nt_extra/2)
+    chunks of extra k tiles (must match run_layer in mlp_chain.hip)."""
+    chunks = []
+    for c in range((nt_base + 1) // 2):
+        tiles = [2 * c] + ([2 * c + 1] if 2 * c + 1 < nt_base else [])
+        chunks.append(np.concatenate([_ktile_index(midx, t) for t in tiles]))
+    for c in range((nt_extra + 1) // 2):
+        tiles = [nt_base + 2 * c] + ([nt_base + 2 * c + 1] if 2 * c + 1 < nt_extra else [])
+        chunks.append(np.concatenate([_ktile_index(midx, t) for t in tiles]))
+    return chunks
+
+
+def _pad(a, n, fill=-1):
+    out = np.full(n, fill, dtype=np.int64)
+    out[: len(a)] = a
+    return out
+
+
+class PackPlan:
+    """Gather plan for one program: ``index`` into the flat source vector, header words."""
+
+    def __init__(self, prog, flat, chunks, aux):
+        self.prog = prog
+        self.flat = flat
+        offs = [HDR_INTS]
+        for c in chunks:
+            offs.append(offs[-1] + len(c))
+        self.nc = len(chunks)
+        assert self.nc + 1 <= 128, "chunk table is 128 entries in the kernel"
+        self.aux_off = offs[-1]
+        self.index = np.concatenate(chunks + [aux])
+        self.total = HDR_INTS + len(self.index)
+        hdr = np.zeros(HDR_INTS, dtype=np.int32)
+        hdr[0], hdr[1], hdr[2], hdr[3], hdr[4], hdr[5] = MAGIC, prog, self.nc, self.total, self.aux_off, len(aux)
+        hdr[HDR_OFFS: HDR_OFFS + self.nc + 1] = offs
+        self.header = hdr
+        self._index_t = {}
+
+    def pack(self, tensors: dict) -> torch.Tensor:
+        """tensors: name -> tensor (any device, fp32).  Returns the fp32 blob on that device."""
+        dev = tensors[self.flat.names[0]].device
+        parts = []
+        for n in self.flat.names:
+            t = tensors[n]
+            assert tuple(t.shape) == self.flat.shape[n], (n, tuple(t.shape), self.flat.shape[n])
+            parts.append(t.detach().reshape(-1).to(torch.float32))
+        parts.append(torch.zeros(1, dtype=torch.float32, device=dev))
+        src = torch.cat(parts)
+        key = str(dev)
+        if key not in self._index_t:
+            self._index_t[key] = torch.from_numpy(self.index).to(dev)
+        body = src[self._index_t[key]]
+        hdr = torch.from_numpy(self.header.copy()).view(torch.float32).to(dev)
+        return torch.cat([hdr, body]).contiguous()
+
+
+def surface_plan(W: int = 256, D: int = 8, skips=(4,), multires: int = 6, W_geo_feat: int = 256) -> PackPlan:
+    """SDF net (reference ImplicitSurface, models/base.py:131-263) -> program for k_sdf_only / k_sdf_nabla."""
+    if not (W == 256 and D == 8 and tuple(skips) == (4,) and multires == 6 and W_geo_feat == 256):
+        raise NotImplementedError("gfx950 surface kernels are built for W=256, D=8, skips=[4], embed_multires=6, "
+                                  "W_geo_feat=256 (the four reference configs)")
+    enc = 39
+    flat = _Flat()
+    dims = []
+    for l in range(D + 1):
+        out_dim = (1 + W_geo_feat) if l == D else (W - enc if (l + 1) in skips else W)
+        in_dim = enc if l == 0 else W
+        dims.append((out_dim, in_dim))
+        flat.add(f"w{l}", (out_dim, in_dim))
+        flat.add(f"b{l}", (out_dim,))
+    chunks = []
+    ar = np.arange
+    for l in range(D):
+        out_dim, in_dim = dims[l]
+        rows = _pad(ar(out_dim), 256)
+        if l == 0:
+            cols, nb, ne = ENC_SLOTS, 3, 0
+        elif l in skips:
+            hw = W - enc                                           # 217 -> 14 tiles
+            cols = np.concatenate([_pad(ar(hw), 224), np.where(ENC_SLOTS >= 0, hw + ENC_SLOTS, -1)])
+            nb, ne = 16, 1
+        else:
+            cols, nb, ne = _pad(ar(in_dim), 256), 16, 0
+        midx = flat.mat_index(f"w{l}", rows, cols)
+        chunks += _layer_chunks(midx, nb, ne)
+    aux = []
+    for l in range(D):
+        aux.append(flat.vec_index(f"b{l}", _pad(ar(dims[l][0]), 256)))
+    aux.append(flat.mat_index(f"w{D}", np.array([0]), ar(256)).reshape(-1))      # sdf row
+    aux.append(flat.vec_index(f"b{D}", _pad(np.array([0]), 4)))
+    aux = np.concatenate(aux)
+    assert len(aux) == SURF_AUX_FLOATS
+    return PackPlan(PROG_SURFACE, flat, chunks, aux)
+
+
+def radiance_plan(view_tiles: int, W: int = 256, D: int = 4, W_geo_feat: int = 256) -> PackPlan:
+    """Geometry-feature rows of the SDF net's last layer + RadianceNet (models/base.py:312-391)
+    -> program for k_radiance<view_tiles>.  view_tiles = 1: raw view dirs (VolSDF configs, input
+    [x, v, n, feat] = 265); 3: embed_multires_view = 4 (NeuS configs, 289)."""
+    if not (W == 256 and D == 4 and W_geo_feat == 256 and view_tiles in (1, 3)):
+        raise NotImplementedError("gfx950 radiance kernel is built for W=256, D=4, W_geo_feat=256, "
+                                  "embed_multires=-1, embed_multires_view in (-1, 4)")
+    n_extra = 9 if view_tiles == 1 else 33
+    flat = _Flat()
+    flat.add("w8", (1 + W_geo_feat, 256)); flat.add("b8", (1 + W_geo_feat,))
+    in0 = n_extra + W_geo_feat
+    rdims = [(W, in0)] + [(W, W)] * (D - 1) + [(3, W)]
+    for l, (o, i) in enumerate(rdims):
+        flat.add(f"r{l}", (o, i)); flat.add(f"rb{l}", (o,))
+    ar = np.arange
+    chunks = []
+    chunks += _layer_chunks(flat.mat_index("w8", 1 + ar(256), ar(256)), 16, 0)
+    cols0 = np.concatenate([n_extra + ar(256), _pad(ar(n_extra), 16 * view_tiles)])
+    chunks += _layer_chunks(flat.mat_index("r0", ar(256), cols0), 16, view_tiles)
+    for l in range(1, D):
+        chunks += _layer_chunks(flat.mat_index(f"r{l}", ar(256), ar(256)), 16, 0)
+    aux = [flat.vec_index("b8", 1 + ar(256))]
+    for l in range(D):
+        aux.append(flat.vec_index(f"rb{l}", ar(256)))
+    aux.append(flat.mat_index(f"r{D}", ar(3), ar(256)).reshape(-1))
+    aux.append(flat.vec_index(f"rb{D}", _pad(ar(3), 4)))
+    aux = np.concatenate(aux)
+    assert len(aux) == RAD_AUX_FLOATS
+    return PackPlan(PROG_RADIANCE, flat, chunks, aux)
+
+
+def fold_weight_norm(weight_g: torch.Tensor, weight_v: torch.Tensor) -> torch.Tensor:
+    """w[o,:] = g[o] * v[o,:] / ||v[o,:]||  (torch.nn.utils.weight_norm default dim=0; the
+    reference re-does this on every forward, base.py:226-227 - here once per weight update)."""
+    return torch._weight_norm(weight_v, weight_g, 0)
+
+
+def surface_tensors(sd: dict, stem: str = "implicit_surface.surface_fc_layers", D: int = 8) -> dict:
+    out = {}
+    for l in range(D + 1):
+        out[f"w{l}"] = fold_weight_norm(sd[f"{stem}.{l}.weight_g"], sd[f"{stem}.{l}.weight_v"])
+        out[f"b{l}"] = sd[f"{stem}.{l}.bias"]
+    return out
+
+
+def radiance_tensors(sd: dict, surf_stem: str = "implicit_surface.surface_fc_layers",
+                     rad_stem: str = "radiance_net.layers", D_surf: int = 8, D: int = 4) -> dict:
+    out = {
+        "w8": fold_weight_norm(sd[f"{surf_stem}.{D_surf}.weight_g"], sd[f"{surf_stem}.{D_surf}.weight_v"]),
+        "b8": sd[f"{surf_stem}.{D_surf}.bias"],
+    }
+    for l in range(D + 1):
+        out[f"r{l}"] = fold_weight_norm(sd[f"{rad_stem}.{l}.weight_g"], sd[f"{rad_stem}.{l}.weight_v"])
+        out[f"rb{l}"] = sd[f"{rad_stem}.{l}.bias"]
+    return out

@@ -1,0 +1,126 @@
+"""VolSDF renderer with the reference's boundary (models/frameworks/volsdf.py).
+
+``volume_render(rays_o, rays_d, model, **kw) -> (rgb, depth, extras)`` takes the reference's keyword
+set (:389-424) and returns the reference's ``extras`` keys (:566-594); ``SingleRenderer`` (:618-624) and
+``get_model`` (:943-994) keep their shapes.  The whole chunk body (:448-596: sampling, network queries,
+integration) is one call into the HIP library; Python only slices rays into chunks and reshapes.
+
+Differences that cannot change results: chunks default to 65,536 rays instead of
+2,048-4,000 (rays are independent and ``perturb=False`` is deterministic; the reference sizes were 24 GB
+fits); the 256-d feature map the reference materialises and drops in ``fine_sample`` never exists;
+weight_norm is folded once per weight update.
+"""
+from __future__ import annotations
+
+import copy
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import hip
+from .nets import VolSDF
+
+DEFAULT_RAYSCHUNK = 65536
+
+
+def volume_render(rays_o, rays_d, model: VolSDF, near=0.0, far=6.0, obj_bounding_radius=3.0, batched=False,
+                  batched_info=None, require_nablas=False, calc_normal=True, use_view_dirs=True, rayschunk=None,
+                  netchunk=1048576, white_bkgd=False, use_nerfplusplus=False, detailed_output=True,
+                  show_progress=False, perturb=False, N_samples=128, N_importance=64, N_outside=32,
+                  max_upsample_steps=5, max_bisection_steps=10, epsilon=0.1, k3_rays_chunk=8192, **dummy_kwargs):
+    """rays_o / rays_d: [(B,) N_rays, 3], rays_d un-normalised.  See module docstring."""
+    if use_nerfplusplus:
+        raise NotImplementedError("outside_scene: nerf++ is outside the hot-path scope (SURVEY.md 2, row 19)")
+    if perturb:
+        raise NotImplementedError("perturb=True (stratified jitter of the 64 final samples, rend_util.py:307) is the "
+                                  "reconstruction-training sampler: a 'next' row of SURVEY.md 8f; the render / "
+                                  "fine-tune-evaluation path uses perturb=False")
+    if not use_view_dirs:
+        raise NotImplementedError("use_view_dirs=False is not used by any reference config")
+    if torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters()) and rays_o.requires_grad:
+        raise NotImplementedError("differentiable rays are not supported")
+    lead = rays_o.shape[:-1]
+    ro = rays_o.reshape(-1, 3).float().contiguous()
+    rd = rays_d.reshape(-1, 3).float().contiguous()
+    N = ro.shape[0]
+    surf_blob, rad_blob = model.packed()
+    alpha, beta = model.forward_ab()
+    alpha, beta = float(alpha), float(beta)
+    chunk = int(rayschunk) if rayschunk else DEFAULT_RAYSCHUNK
+    want_normal = bool(calc_normal and require_nablas)
+    parts = []
+    for i in range(0, N, chunk):
+        parts.append(hip.volsdf_render(
+            surf_blob, rad_blob, model.view_tiles, ro[i:i + chunk], rd[i:i + chunk], near=near, far=far,
+            R_bg=obj_bounding_radius, alpha=alpha, beta=beta, eps=epsilon, n_samples=N_samples,
+            n_importance=N_importance, max_upsample_steps=max_upsample_steps,
+            max_bisection_steps=max_bisection_steps, white_bkgd=white_bkgd, calc_normal=want_normal,
+            detailed=detailed_output, k3_rays_chunk=k3_rays_chunk))
+    ret = OrderedDict()
+    order = ["rgb", "depth_volume", "mask_volume", "normals_volume", "implicit_surface", "implicit_nablas", "radiance",
+             "alpha", "p_i", "visibility_weights", "d_vals", "sigma", "beta_map", "iter_usage"]
+    for k in order:
+        if k == "alpha":
+            if detailed_output:
+                ret["alpha"] = None
+            continue
+        if k in parts[0]:
+            if k == "implicit_nablas" and not require_nablas:
+                continue
+            v = torch.cat([p[k] for p in parts], 0) if len(parts) > 1 else parts[0][k]
+            ret[k] = v.reshape(*lead, *v.shape[1:])
+    if detailed_output:
+        ret["alpha"] = 1.0 - ret["p_i"]
+        ret["beta_map"] = ret["beta_map"].unsqueeze(-1)          # reference shape [(B), N_rays, 1] (volsdf.py:590)
+    return ret["rgb"], ret["depth_volume"], ret
+
+
+class SingleRenderer(nn.Module):
+    def __init__(self, model: VolSDF):
+        super().__init__()
+        self.model = model
+
+    def forward(self, rays_o, rays_d, **kwargs):
+        return volume_render(rays_o, rays_d, self.model, **kwargs)
+
+
+def get_model(args, render_target=None):
+    """(volsdf.py:943-994) args: the YAML config as an attribute dict (nerf-art_amd/config.py).
+    Returns (model, trainer=None, render_kwargs_train, render_kwargs_test, render_fn).  The Trainer
+    (two-pass CLIP fine-tune step) is SURVEY.md row a19 and lives in nerf-art_amd/trainer.py when built."""
+    m, t = args.model, args.training
+    model_config = {
+        "use_nerfplusplus": m.setdefault("outside_scene", "builtin") == "nerf++",
+        "obj_bounding_radius": m.obj_bounding_radius,
+        "W_geo_feat": m.setdefault("W_geometry_feature", 256),
+        "speed_factor": t.setdefault("speed_factor", 1.0),
+        "beta_init": t.setdefault("beta_init", 0.1),
+    }
+    s, r = m.surface, m.radiance
+    model_config["surface_cfg"] = {
+        "use_siren": s.setdefault("use_siren", m.setdefault("use_siren", False)),
+        "embed_multires": s.setdefault("embed_multires", 6),
+        "radius_init": s.setdefault("radius_init", 1.0),
+        "geometric_init": s.setdefault("geometric_init", True),
+        "D": s.setdefault("D", 8), "W": s.setdefault("W", 256), "skips": s.setdefault("skips", [4]),
+    }
+    model_config["radiance_cfg"] = {
+        "use_siren": r.setdefault("use_siren", m.setdefault("use_siren", False)),
+        "embed_multires": r.setdefault("embed_multires", -1),
+        "embed_multires_view": r.setdefault("embed_multires_view", -1),
+        "use_view_dirs": r.setdefault("use_view_dirs", True),
+        "D": r.setdefault("D", 4), "W": r.setdefault("W", 256), "skips": r.setdefault("skips", []),
+    }
+    model = VolSDF(**model_config)
+    render_kwargs_train = {
+        "near": args.data.near, "far": args.data.far, "batched": True,
+        "perturb": m.setdefault("perturb", True), "white_bkgd": m.setdefault("white_bkgd", False),
+        "max_upsample_steps": m.setdefault("max_upsample_iter", 5),
+        "use_nerfplusplus": model_config["use_nerfplusplus"], "obj_bounding_radius": m.obj_bounding_radius,
+    }
+    render_kwargs_test = copy.deepcopy(render_kwargs_train)
+    render_kwargs_test["rayschunk"] = args.data.val_rayschunk
+    render_kwargs_test["perturb"] = False
+    renderer = SingleRenderer(model)
+    return model, None, render_kwargs_train, render_kwargs_test, renderer

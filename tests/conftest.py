@@ -1,0 +1,63 @@
+import hashlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden", "renderer_golden.npz")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def state_checksum(sd):
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(sd[k].detach().cpu().numpy().tobytes())
+    return h.hexdigest()
+
+
+@pytest.fixture(scope="session")
+def golden():
+    z = np.load(GOLDEN, allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+_states = {}
+
+
+def scene_state(framework="VolSDF", beta=0.01):
+    """Reference-format state dict of the synthetic scene (regenerated from seeds, CPU tensors)."""
+    key = (framework, beta)
+    if key not in _states:
+        from nerfart_amd import scene, frameworks
+        torch.manual_seed(0)
+        model, _, _, rk_test, _ = frameworks.get_model(scene.synthetic_config(framework))
+        _states[key] = (scene.perturb_state(model.state_dict(), beta=beta, seed=1), dict(rk_test))
+    return _states[key]
+
+
+@pytest.fixture(scope="session")
+def volsdf_state(golden):
+    sd, rk = scene_state("VolSDF", 0.01)
+    assert state_checksum(sd) == str(golden["G3_state_sha256"]), \
+        "regenerated synthetic weights differ from the ones the golden vectors were captured with (RNG drift)"
+    return sd, rk
+
+
+@pytest.fixture(scope="session")
+def neus_state(golden):
+    sd, rk = scene_state("NeuS", None)
+    assert state_checksum(sd) == str(golden["G10_state_sha256"])
+    return sd, rk
+
+
+def tt(a):
+    return torch.from_numpy(np.asarray(a))

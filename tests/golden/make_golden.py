@@ -1,0 +1,245 @@
+"""Generate the golden vectors under tests/golden/ by running the REAL reference
+(/root/reference, cassiePython/NeRF-Art) on CPU in the build container.
+
+    python tests/golden/make_golden.py
+
+The reference's Python never travels: only inputs/outputs (small .npz files) are committed.  Missing
+non-arithmetic dependencies of the reference (cv2, addict, imageio, skimage, plyfile, torchvision,
+clip, tensorboard) are stubbed - none of them carries renderer arithmetic.
+
+Full-width network weights are not stored: they are regenerated from seeds by the package's own
+initialiser (nerf-art_amd/nets.py + scene.py), which this script first proves identical to the
+reference's initialiser (same RNG calls -> bit-identical state dict); a checksum of every state is
+stored so a drifting RNG would be detected rather than silently compared.
+"""
+import hashlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, REPO)
+
+
+def install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+    for n in ("cv2", "imageio", "plyfile", "clip", "tensorboard"):
+        mod(n)
+    sk = mod("skimage"); sk.transform = mod("skimage.transform", rescale=None); sk.measure = mod("skimage.measure")
+
+    class _IM:
+        BICUBIC = 3
+        BILINEAR = 2
+    tv = mod("torchvision")
+    tv.transforms = mod("torchvision.transforms", InterpolationMode=_IM)
+    tv.transforms.functional = mod("torchvision.transforms.functional")
+    tv.models = mod("torchvision.models", vgg16=None)
+    tv.utils = mod("torchvision.utils")
+    from nerfart_amd.config import ConfigDict
+
+    class Dict(ConfigDict):            # addict.Dict: missing keys create children
+        def __missing__(self, k):
+            v = type(self)()
+            dict.__setitem__(self, k, v)
+            return v
+
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            try:
+                return self[k]
+            except KeyError:
+                return self.__missing__(k)
+    mod("addict", Dict=Dict)
+
+
+def state_checksum(sd):
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(sd[k].detach().cpu().numpy().tobytes())
+    return h.hexdigest()
+
+
+def t2n(d):
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
+
+
+def main():
+    install_stubs()
+    sys.path.insert(0, REF)
+    os.chdir(REF)
+    from utils import io_util, rend_util
+    from models import base as ref_base
+    from models.frameworks import get_model as ref_get_model
+    from models.frameworks import volsdf as ref_volsdf, neus as ref_neus
+    import nerfart_amd  # noqa: F401
+    from nerfart_amd import scene, frameworks
+
+    out = {}
+    torch.set_num_threads(8)
+
+    # ---- G12: init equivalence + state manifest ------------------------------------------
+    states = {}
+    for fw, yaml_name in (("VolSDF", "volsdf_fangzhou_nature.yaml"), ("NeuS", "neus_fangzhou_vangogh.yaml")):
+        cfg = io_util.load_yaml(os.path.join(REF, "configs", yaml_name))
+        cfg.device_ids = [0]
+        cfg.training.is_finetune = False
+        torch.manual_seed(0)
+        ref_model, _, rk_train, rk_test, ref_render = ref_get_model(cfg, [480, 270])
+        torch.manual_seed(0)
+        mine, _, _, my_rk_test, _ = frameworks.get_model(scene.synthetic_config(fw))
+        sd_ref, sd_mine = ref_model.state_dict(), mine.state_dict()
+        assert list(sd_ref.keys()) == list(sd_mine.keys()), (list(sd_ref.keys()), list(sd_mine.keys()))
+        for k in sd_ref:
+            assert sd_ref[k].shape == sd_mine[k].shape, k
+            assert torch.equal(sd_ref[k], sd_mine[k]), f"init mismatch at {k}"
+        assert dict(rk_test) == dict(my_rk_test), (dict(rk_test), dict(my_rk_test))
+        states[fw] = (cfg, ref_model, ref_render, rk_test)
+        out[f"G12_{fw}_keys"] = np.array(list(sd_ref.keys()))
+        out[f"G12_{fw}_shapes"] = np.array([str(tuple(v.shape)) for v in sd_ref.values()])
+        out[f"G12_{fw}_init_sha256"] = np.array(state_checksum(sd_ref))
+        # weight_norm fold check on one layer
+        lay = ref_model.implicit_surface.surface_fc_layers[4]
+        out[f"G12_{fw}_fold_l4_row0"] = lay.weight.detach()[0].numpy().copy()
+    print("G12 ok: package init == reference init (bit-identical)")
+
+    # scenes at three betas (VolSDF) and one (NeuS); weights loaded INTO the reference models
+    def load_scene(fw, beta):
+        cfg, ref_model, ref_render, rk_test = states[fw]
+        torch.manual_seed(0)
+        mine, _, _, _, _ = frameworks.get_model(scene.synthetic_config(fw))
+        sd = scene.perturb_state(mine.state_dict(), beta=beta, seed=1)
+        ref_model.load_state_dict(sd)
+        return sd, ref_model, ref_render, rk_test
+
+    g = torch.Generator().manual_seed(1234)
+
+    # ---- G1 get_rays ------------------------------------------------------------------------
+    c2w = torch.from_numpy(rend_util.look_at(np.array([0.3, -0.2, -2.5]), np.array([0.0, 0.1, 0.0]))).float()
+    K = torch.eye(4); K[0, 0] = 7.0; K[1, 1] = 6.5; K[0, 2] = 2.4; K[1, 2] = 3.1; K[0, 1] = 0.15
+    ro, rd, inds = rend_util.get_rays(c2w[None], K[None], 6, 5)
+    # (the quaternion-pose branch of the reference, rend_util.py:114-119 -> quat_to_rot :77, cannot run:
+    #  `prefix, _ = q.shape[:-1]` unpacks an int and then splats it; nothing in the repo calls it)
+    out.update(G1_c2w=c2w, G1_K=K, G1_rays_o=ro[0], G1_rays_d=rd[0], G1_inds=inds[0])
+
+    # ---- G2 embedder ------------------------------------------------------------------------
+    x = (torch.rand(64, 3, generator=g) * 6 - 3)
+    e6, d6 = ref_base.get_embedder(6); e4, d4 = ref_base.get_embedder(4)
+    out.update(G2_x=x, G2_e6=e6(x), G2_e4=e4(x))
+
+    # ---- G3/G4/G5 networks (VolSDF scene, beta 0.01) -----------------------------------------
+    sd, ref_model, ref_render, rk_test = load_scene("VolSDF", 0.01)
+    out["G3_state_sha256"] = np.array(state_checksum(sd))
+    pts = torch.rand(256, 3, generator=g) * 6 - 3          # includes points outside R = 3
+    pts[:32] *= 0.3
+    v = torch.nn.functional.normalize(torch.randn(256, 3, generator=g), dim=-1)
+    with torch.no_grad():
+        sdf, h = ref_model.implicit_surface.forward(pts, return_h=True)
+    sdf_n, nab, h_n = ref_model.implicit_surface.forward_with_nablas(pts.clone())
+    with torch.no_grad():
+        fs_sdf, _ = ref_model.forward_surface(pts)
+    rad, sdf_c, nab_c = ref_model.forward(pts.clone(), v)
+    with torch.no_grad():
+        rad_direct = ref_model.radiance_net.forward(pts, v, nab.detach(), h.detach())
+    out.update(G3_pts=pts, G3_view=v, G3_sdf=sdf, G3_feat=h, G3_nabla=nab.detach(), G5_forward_surface=fs_sdf,
+               G5_radiance=rad.detach(), G5_sdf=sdf_c.detach(), G5_nabla=nab_c.detach(), G4_radiance=rad_direct)
+
+    # ---- G6 sigma / error bound ----------------------------------------------------------------
+    d = torch.sort(torch.rand(8, 40, generator=g) * 6, dim=-1).values
+    s = torch.randn(8, 40, generator=g) * 0.5
+    a_s, b_s = torch.tensor([100.0]), torch.tensor([0.01])
+    b_r = torch.rand(8, 1, generator=g) * 0.4 + 0.005
+    out.update(G6_d=d, G6_s=s, G6_sigma=ref_volsdf.sdf_to_sigma(s, a_s, b_s),
+               G6_bound_scalar=ref_volsdf.error_bound(d, s, a_s, b_s), G6_beta_ray=b_r,
+               G6_bound_ray=ref_volsdf.error_bound(d, s, 1.0 / b_r, b_r))
+    s_big = s.clone(); s_big[0] = 0.0; d_big = d.clone(); d_big[0] = torch.linspace(0, 6000, 40)
+    out.update(G6_nan_d=d_big, G6_nan_s=s_big, G6_nan_bound=ref_volsdf.error_bound(d_big, s_big, torch.tensor([1e4]), torch.tensor([1e-4])))
+
+    # ---- G7 samplers ---------------------------------------------------------------------------
+    w = torch.rand(8, 39, generator=g); w[1, 5:20] = 0.0; w[2] = 0.0
+    cdf = torch.cumsum(w / (w.sum(-1, keepdim=True) + 1e-3), -1) * 0.9
+    out.update(G7_bins=d, G7_w=w, G7_pdf16=rend_util.sample_pdf(d, w, 16, det=True), G7_pdf66=rend_util.sample_pdf(d, w, 66, det=True),
+               G7_cdf=cdf, G7_cdf16=rend_util.sample_cdf(d, cdf, 16, det=True))
+
+    # ---- G8 fine_sample + G9 volume_render at three betas ------------------------------------------
+    H = W = 8
+    c2w_s, K_s = scene.camera(H, W)
+    for beta in (0.1, 0.01, 0.002):
+        sd, ref_model, ref_render, rk_test = load_scene("VolSDF", beta)
+        ro, rd, _ = rend_util.get_rays(c2w_s[None], K_s[None], H, W)
+        rdn = torch.nn.functional.normalize(rd, dim=-1)
+        alpha, bnet = ref_model.forward_ab()
+        t = torch.linspace(0, 1, 512).float()
+        d_init = 0.0 * (1 - t) + 6.0 * torch.ones(1, H * W, 1) * t
+        with torch.no_grad():
+            d_fine, beta_map, usage = ref_volsdf.fine_sample(ref_model.forward_surface, d_init, ro, rdn, alpha_net=alpha, beta_net=bnet,
+                                                              far=6.0 * torch.ones(1, H * W, 1), eps=0.1, max_iter=6, max_bisection=10,
+                                                              final_N_importance=64, perturb=False, N_up=512)
+        tag = f"b{beta}"
+        out.update({f"G8_{tag}_d_fine": d_fine[0], f"G8_{tag}_beta_map": beta_map[0], f"G8_{tag}_iter_usage": usage[0]})
+        for ns in ((32, 128) if beta == 0.01 else (128,)):
+            with torch.no_grad():
+                rgb, depth, ex = ref_render(ro, rd, require_nablas=True, calc_normal=True, detailed_output=True, N_samples=ns, **rk_test)
+            for k, vv in ex.items():
+                out[f"G9_{tag}_n{ns}_{k}"] = vv[0]
+        print("G8/G9", tag, "iter_usage", usage.unique(return_counts=True))
+    out.update(G9_c2w=c2w_s, G9_K=K_s, G9_H=np.array(H), G9_W=np.array(W))
+
+    # ---- G10 NeuS ------------------------------------------------------------------------------------
+    sd, neus_model, neus_render, nrk = load_scene("NeuS", None)
+    out["G10_state_sha256"] = np.array(state_checksum(sd))
+    ro, rd, _ = rend_util.get_rays(c2w_s[None], K_s[None], H, W)
+    rdn = torch.nn.functional.normalize(rd, dim=-1)
+    near, far = rend_util.near_far_from_sphere(ro, rdn, r=1.0)
+    sdfp = torch.randn(8, 20, generator=g) * 0.2
+    cdf_n, alpha_n = ref_neus.sdf_to_alpha(sdfp, torch.tensor([20.0]))
+    out.update(G10_near=near[0], G10_far=far[0], G10_sdfp=sdfp, G10_cdf=cdf_n, G10_alpha=alpha_n, G10_w=ref_neus.alpha_to_w(alpha_n))
+    with torch.no_grad():
+        rgb, depth, ex = neus_render(ro, rd, calc_normal=True, detailed_output=True, **nrk)
+    for k, vv in ex.items():
+        out[f"G10_render_{k}"] = vv[0]
+    pts_n = torch.rand(64, 3, generator=g) * 2 - 1
+    v_n = torch.nn.functional.normalize(torch.randn(64, 3, generator=g), dim=-1)
+    rad_n, sdf_nn, nab_n = neus_model.forward(pts_n.clone(), v_n)
+    out.update(G10_pts=pts_n, G10_view=v_n, G10_radiance=rad_n.detach(), G10_sdf=sdf_nn.detach(), G10_nabla=nab_n.detach())
+
+    # ---- G11 backward (for the training rows; stored now so the oracle's autograd is pinned) -------------
+    sd, ref_model, ref_render, rk_test = load_scene("VolSDF", 0.01)
+    ro4, rd4 = ro[:, :4], rd[:, :4]
+    ref_model.zero_grad()
+    rgb, depth, ex = ref_render(ro4, rd4, require_nablas=True, calc_normal=True, detailed_output=True, **rk_test)
+    gvec = torch.rand(rgb.shape, generator=g)
+    rgb.backward(gvec, retain_graph=True)
+    nn_ = ex["implicit_nablas"].flatten(-3, -2).norm(dim=-1)
+    eik = 0.1 * torch.nn.functional.mse_loss(nn_, torch.ones_like(nn_))
+    eik.backward()
+    out["G11_gvec"] = gvec[0]
+    for name, p in ref_model.named_parameters():          # norms + leading slices keep the fixture small
+        gr = p.grad.detach()
+        out[f"G11_gradnorm_{name}"] = gr.norm()
+        out[f"G11_gradhead_{name}"] = gr.reshape(-1)[:64].clone()
+
+    # ---- G13 negative prompt list ---------------------------------------------------------------------
+    tr = ref_volsdf.Trainer.__new__(ref_volsdf.Trainer)
+    class A: pass
+    a = A(); a.finetune = A(); a.finetune.target_text = "painting, oil on canvas, Vincent van gogh self-portrait style"
+    out["G13_neg_texts"] = np.array(ref_volsdf.Trainer.create_fine_neg_texts(tr, a))
+
+    path = os.path.join(HERE, "renderer_golden.npz")
+    np.savez_compressed(path, **t2n(out))
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,78 @@
+"""CPU validation of the weight-packing plan and of the HIP kernels' index arithmetic: a numpy model of
+csrc/mlp_chain.hip (tests/emul_chain.py: MFMA lane layouts, chunk order, slot order, tangent quads)
+walks the REAL packed blob and must reproduce the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import scene_state
+from oracle import nets
+import emul_chain as em
+from nerfart_amd import packing
+
+
+def _blobs(fw):
+    sd, _ = scene_state(fw, 0.01 if fw == "VolSDF" else None)
+    surf = packing.surface_plan().pack(packing.surface_tensors(sd)).numpy()
+    vt = 1 if fw == "VolSDF" else 3
+    rad = packing.radiance_plan(vt).pack(packing.radiance_tensors(sd)).numpy()
+    return sd, surf, rad, vt
+
+
+def test_enc_slot_map_is_a_bijection_onto_39_features():
+    feats = [packing.enc_slot_feature(s) for s in range(48)]
+    real = [f for f in feats if f >= 0]
+    assert sorted(real) == list(range(39)) and feats.count(-1) == 9
+
+
+def test_blob_header_and_chunk_table():
+    _, surf, rad, _ = _blobs("VolSDF")
+    for blob, nc in ((surf, 59), (rad, 41)):
+        hdr = blob[:512].view(np.int32)
+        assert hdr[0] == packing.MAGIC and hdr[2] == nc and hdr[3] == blob.size
+        offs = hdr[16:16 + nc + 1]
+        sizes = np.diff(offs)
+        assert set(sizes.tolist()) <= {4096, 8192} and offs[0] == 512 and offs[-1] == hdr[4]
+    assert _blobs("NeuS")[2][:512].view(np.int32)[2] == 42
+
+
+def test_emulated_sdf_only_matches_oracle():
+    sd, surf, _, _ = _blobs("VolSDF")
+    g = torch.Generator().manual_seed(7)
+    pts = (torch.rand(16, 3, generator=g) * 6 - 3)
+    pts[:4] *= 0.3
+    ref = nets.volsdf_forward_surface(sd, pts)[0].numpy()
+    out = em.emul_sdf_only(surf, pts.numpy(), 3.0)
+    np.testing.assert_allclose(out, ref, atol=3e-6, rtol=1e-5)
+    ref_nc = nets.surface_forward(sd, pts)[0].numpy()
+    np.testing.assert_allclose(em.emul_sdf_only(surf, pts.numpy(), 0.0), ref_nc, atol=3e-6, rtol=1e-5)
+
+
+def test_emulated_sdf_nabla_matches_oracle():
+    sd, surf, _, _ = _blobs("VolSDF")
+    g = torch.Generator().manual_seed(8)
+    pts = (torch.rand(4, 3, generator=g) * 4 - 2)
+    sdf, nab, h7 = em.emul_sdf_nabla(surf, pts.numpy(), 3.0)
+    s_ref, n_ref, feat_ref = nets.surface_forward_with_nablas(sd, pts)
+    d_bg = 3.0 - pts.norm(dim=-1)
+    s_ref = torch.where(d_bg < s_ref, d_bg, s_ref)
+    np.testing.assert_allclose(sdf, s_ref.numpy(), atol=3e-6, rtol=1e-5)
+    np.testing.assert_allclose(nab, n_ref.numpy(), atol=2e-5, rtol=1e-4)
+    # h7 -> feature via the last layer's rows 1..256 must give the oracle's geometry feature
+    w8 = nets.folded_weight(sd, "implicit_surface.surface_fc_layers.8").numpy()
+    b8 = sd["implicit_surface.surface_fc_layers.8.bias"].numpy()
+    np.testing.assert_allclose(h7 @ w8[1:].T + b8[1:], feat_ref.numpy(), atol=1e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("fw", ["VolSDF", "NeuS"])
+def test_emulated_radiance_matches_oracle(fw):
+    sd, surf, rad, vt = _blobs(fw)
+    g = torch.Generator().manual_seed(9)
+    pts = (torch.rand(16, 3, generator=g) * 2 - 1)
+    view = torch.nn.functional.normalize(torch.randn(16, 3, generator=g), dim=-1)
+    _, nab, feat = nets.surface_forward_with_nablas(sd, pts)
+    # recover h7 from the oracle by running the hidden layers
+    h7 = np.stack([em.emul_sdf_nabla(surf, pts[i:i + 4].numpy(), 0.0)[2] for i in range(0, 16, 4)]).reshape(16, 256)
+    out = em.emul_radiance(rad, vt, pts.numpy(), view.numpy(), nab.numpy(), h7)
+    ref = nets.radiance_forward(sd, pts, view, nab, feat, -1, -1 if fw == "VolSDF" else 4).numpy()
+    np.testing.assert_allclose(out, ref, atol=3e-6, rtol=1e-5)
