@@ -29,6 +29,12 @@ extern "C" {
 int nerfart_abi_version(void);
 const char* nerfart_last_error(void);
 
+/* Optional launch profiling (bench.py): between begin and end every chained-MLP launch is bracketed by HIP
+ * events on its own stream; end() returns per kernel class c = 0 k_sdf_only, 1 k_sdf_nabla, 2 k_radiance the
+ * summed elapsed ms, launch count and points processed (host arrays of 3). */
+int nerfart_profile_begin(void);
+int nerfart_profile_end(double* ms, long long* launches, long long* units);
+
 /* host helper: torch.linspace(start, end, n) in fp32, bit for bit (out is a HOST array). */
 void nerfart_linspace(float start, float end, int n, float* out);
 
@@ -88,8 +94,11 @@ long long nerfart_volsdf_sampler_workspace_bytes(int n_rays, int n_init, int n_u
 int nerfart_volsdf_fine_sample(const float* surf_blob, const float* rays_o, const float* rays_dn, int n_rays,
                                const float* near, const float* far, float near_s, float far_s, float R_bg,
                                float alpha_net, float beta_net, float eps, int n_init, int n_up, int n_final,
-                               int max_iter, int max_bisect, float* d_fine, float* beta_map, float* iter_usage,
+                               int max_iter, int max_bisect, const float* t_init_dev, const float* u_up_dev,
+                               const float* u_final_dev, float* d_fine, float* beta_map, float* iter_usage,
                                void* workspace, long long workspace_bytes, void* stream);
+/* t_init_dev / u_up_dev / u_final_dev: device copies of torch.linspace(0,1,n) for n = n_init, n_up+2, n_final
+ * (the reference's tables, volsdf.py:483, rend_util.py:269,304); all three NULL -> nerfart_linspace is used. */
 
 /* out[r] = sort(cat(a[r, :na], b[r, :nb]))  (volsdf.py:501-502) */
 int nerfart_sort_concat(int n_rays, const float* a, int na, int a_stride, const float* b, int nb, int b_stride,
@@ -106,8 +115,9 @@ long long nerfart_volsdf_render_workspace_bytes(int n_rays, int n_samples, int n
 int nerfart_volsdf_render_fwd(const float* surf_blob, const float* rad_blob, int view_tiles, const float* rays_o,
                               const float* rays_d, int n_rays, float near_s, float far_s, float R_bg, float alpha,
                               float beta, float eps, int n_samples, int n_importance, int max_upsample_steps,
-                              int max_bisection_steps, int white_bkgd, int k3_rays_chunk, float* rgb, float* depth,
-                              float* acc, float* normals, float* d_all_out, float* sdf_out, float* nabla_out,
+                              int max_bisection_steps, int white_bkgd, int k3_rays_chunk, const float* t_coarse_dev,
+                              const float* t_init_dev, const float* u_up_dev, const float* u_final_dev, float* rgb,
+                              float* depth, float* acc, float* normals, float* d_all_out, float* sdf_out, float* nabla_out,
                               float* radiance_out, float* sigma_out, float* p_out, float* tau_out, float* beta_map_out,
                               float* iter_usage_out, void* workspace, long long workspace_bytes, void* stream);
 
@@ -126,7 +136,8 @@ int nerfart_neus_composite(int n_rays, int P, const float* d_all, const float* s
 long long nerfart_neus_render_workspace_bytes(int n_rays, int n_samples, int n_importance, int k3_rays_chunk);
 int nerfart_neus_render_fwd(const float* surf_blob, const float* rad_blob, int view_tiles, const float* rays_o,
                             const float* rays_d, int n_rays, float obj_bounding_radius, float s, int n_samples,
-                            int n_importance, int n_upsample_iters, int white_bkgd, int k3_rays_chunk, float* rgb,
+                            int n_importance, int n_upsample_iters, int white_bkgd, int k3_rays_chunk,
+                            const float* t_coarse_dev, const float* u_new_dev, float* rgb,
                             float* depth, float* acc, float* normals, float* d_all_out, float* sdf_out,
                             float* nabla_out, float* radiance_out, float* cdf_out, float* alpha_out, float* w_out,
                             float* d_mid_out, void* workspace, long long workspace_bytes, void* stream);

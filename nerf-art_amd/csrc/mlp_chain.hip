@@ -524,11 +524,14 @@ static int validate_src(const PointSrc& s) {
 }
 
 template <typename K, typename... Args>
-static int launch_chain(K kernel, unsigned ntiles, hipStream_t stream, Args... args) {
+static int launch_chain(int prof_cls, long long units, K kernel, unsigned ntiles, hipStream_t stream, Args... args) {
     const size_t lds = LDS_FLOATS * sizeof(float);
     NERFART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned grid = ntiles < (unsigned)num_cus() ? ntiles : (unsigned)num_cus();
+    void* ph = nullptr;
+    if (profile_enabled()) profile_open(prof_cls, units, stream, &ph);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(WG_THREADS), lds, stream, args...);
+    profile_close(ph, stream);
     NERFART_HIP(hipGetLastError());
     return 0;
 }
@@ -557,7 +560,7 @@ int nerfart_sdf_fwd(const float* blob, const float* pts, long long M, float R_bg
     if (M == 0) return 0;
     PointSrc s = make_src(pts, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, M);
     if (int rc = validate_src(s)) return rc;
-    return launch_chain(k_sdf_only, (unsigned)((M + 127) / 128), (hipStream_t)stream, blob, s, R_bg, sdf_out, 0);
+    return launch_chain(0, M, k_sdf_only, (unsigned)((M + 127) / 128), (hipStream_t)stream, blob, s, R_bg, sdf_out, 0);
 }
 
 int nerfart_sdf_fwd_rays(const float* blob, const float* rays_o, const float* rays_d, const int* ray_idx,
@@ -568,7 +571,7 @@ int nerfart_sdf_fwd_rays(const float* blob, const float* rays_o, const float* ra
     if (M == 0) return 0;
     PointSrc s = make_src(nullptr, nullptr, rays_o, rays_d, ray_idx, depth, n_per_ray, depth_stride, M);
     if (int rc = validate_src(s)) return rc;
-    return launch_chain(k_sdf_only, (unsigned)((M + 127) / 128), (hipStream_t)stream, blob, s, R_bg, sdf_out, out_stride);
+    return launch_chain(0, M, k_sdf_only, (unsigned)((M + 127) / 128), (hipStream_t)stream, blob, s, R_bg, sdf_out, out_stride);
 }
 
 int nerfart_sdf_nabla_fwd(const float* blob, const float* pts, long long M, float R_bg, float* sdf_out,
@@ -577,7 +580,7 @@ int nerfart_sdf_nabla_fwd(const float* blob, const float* pts, long long M, floa
     if (M == 0) return 0;
     PointSrc s = make_src(pts, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, M);
     if (int rc = validate_src(s)) return rc;
-    return launch_chain(k_sdf_nabla, (unsigned)((M + 31) / 32), (hipStream_t)stream, blob, s, R_bg, sdf_out, nabla_out, h7_out);
+    return launch_chain(1, M, k_sdf_nabla, (unsigned)((M + 31) / 32), (hipStream_t)stream, blob, s, R_bg, sdf_out, nabla_out, h7_out);
 }
 
 int nerfart_sdf_nabla_fwd_rays(const float* blob, const float* rays_o, const float* rays_d, const int* ray_idx,
@@ -588,7 +591,7 @@ int nerfart_sdf_nabla_fwd_rays(const float* blob, const float* rays_o, const flo
     if (M == 0) return 0;
     PointSrc s = make_src(nullptr, nullptr, rays_o, rays_d, ray_idx, depth, n_per_ray, depth_stride, M);
     if (int rc = validate_src(s)) return rc;
-    return launch_chain(k_sdf_nabla, (unsigned)((M + 31) / 32), (hipStream_t)stream, blob, s, R_bg, sdf_out, nabla_out, h7_out);
+    return launch_chain(1, M, k_sdf_nabla, (unsigned)((M + 31) / 32), (hipStream_t)stream, blob, s, R_bg, sdf_out, nabla_out, h7_out);
 }
 
 int nerfart_radiance_fwd(const float* blob, int view_tiles, const float* pts, const float* view, long long M,
@@ -599,8 +602,8 @@ int nerfart_radiance_fwd(const float* blob, int view_tiles, const float* pts, co
     PointSrc s = make_src(pts, view, nullptr, nullptr, nullptr, nullptr, 1, 0, M);
     if (int rc = validate_src(s)) return rc;
     const unsigned nt = (unsigned)((M + 127) / 128);
-    if (view_tiles == 1) return launch_chain(k_radiance<1>, nt, (hipStream_t)stream, blob, s, nabla, h7, rgb_out);
-    if (view_tiles == 3) return launch_chain(k_radiance<3>, nt, (hipStream_t)stream, blob, s, nabla, h7, rgb_out);
+    if (view_tiles == 1) return launch_chain(2, M, k_radiance<1>, nt, (hipStream_t)stream, blob, s, nabla, h7, rgb_out);
+    if (view_tiles == 3) return launch_chain(2, M, k_radiance<3>, nt, (hipStream_t)stream, blob, s, nabla, h7, rgb_out);
     set_last_error("radiance_fwd: view_tiles must be 1 (raw view dirs) or 3 (multires_view = 4)");
     return 2;
 }
@@ -614,8 +617,8 @@ int nerfart_radiance_fwd_rays(const float* blob, int view_tiles, const float* ra
     PointSrc s = make_src(nullptr, nullptr, rays_o, rays_d, ray_idx, depth, n_per_ray, depth_stride, M);
     if (int rc = validate_src(s)) return rc;
     const unsigned nt = (unsigned)((M + 127) / 128);
-    if (view_tiles == 1) return launch_chain(k_radiance<1>, nt, (hipStream_t)stream, blob, s, nabla, h7, rgb_out);
-    if (view_tiles == 3) return launch_chain(k_radiance<3>, nt, (hipStream_t)stream, blob, s, nabla, h7, rgb_out);
+    if (view_tiles == 1) return launch_chain(2, M, k_radiance<1>, nt, (hipStream_t)stream, blob, s, nabla, h7, rgb_out);
+    if (view_tiles == 3) return launch_chain(2, M, k_radiance<3>, nt, (hipStream_t)stream, blob, s, nabla, h7, rgb_out);
     set_last_error("radiance_fwd: view_tiles must be 1 (raw view dirs) or 3 (multires_view = 4)");
     return 2;
 }

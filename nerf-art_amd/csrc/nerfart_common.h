@@ -90,6 +90,9 @@ __device__ __forceinline__ float ray_point(float o, float d, float t) { return _
 namespace nerfart {
 void set_last_error(const char* s);
 int check_hip(hipError_t e, const char* what);
+bool profile_enabled();
+void profile_open(int cls, long long units, hipStream_t s, void** handle);
+void profile_close(void* handle, hipStream_t s);
 }
 #define NERFART_HIP(expr)                                                   \
     do {                                                                    \

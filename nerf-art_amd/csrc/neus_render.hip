@@ -260,7 +260,8 @@ long long nerfart_neus_render_workspace_bytes(int n_rays, int n_samples, int n_i
 // nabla [R,P,3], radiance/alpha/w/d_mid on the P-1 mid-points.
 int nerfart_neus_render_fwd(const float* surf_blob, const float* rad_blob, int view_tiles, const float* rays_o,
                             const float* rays_d, int n_rays, float obj_bounding_radius, float s, int n_samples,
-                            int n_importance, int n_upsample_iters, int white_bkgd, int k3_rays_chunk, float* rgb,
+                            int n_importance, int n_upsample_iters, int white_bkgd, int k3_rays_chunk,
+                            const float* t_coarse_dev, const float* u_new_dev, float* rgb,
                             float* depth, float* acc, float* normals, float* d_all_out, float* sdf_out,
                             float* nabla_out, float* radiance_out, float* cdf_out, float* alpha_out, float* w_out,
                             float* d_mid_out, void* workspace, long long workspace_bytes, void* stream_) {
@@ -276,7 +277,9 @@ int nerfart_neus_render_fwd(const float* surf_blob, const float* rad_blob, int v
     float* sdf = sdf_out ? sdf_out : w.sdf;
     float* nabla = nabla_out ? nabla_out : w.nabla;
     float* rad = radiance_out ? radiance_out : w.rad;
-    {
+    if (t_coarse_dev && u_new_dev) {
+        w.t_coarse = const_cast<float*>(t_coarse_dev); w.u_new = const_cast<float*>(u_new_dev);
+    } else {
         float* h = (float*)malloc(sizeof(float) * (size_t)(n_samples + n_new));
         if (!h) { set_last_error("out of host memory"); return 3; }
         nerfart_linspace(0.f, 1.f, n_samples, h);

@@ -430,7 +430,8 @@ long long nerfart_volsdf_sampler_workspace_bytes(int n_rays, int n_init, int n_u
 int nerfart_volsdf_fine_sample(const float* surf_blob, const float* rays_o, const float* rays_dn, int n_rays,
                                const float* near, const float* far, float near_s, float far_s, float R_bg,
                                float alpha_net, float beta_net, float eps, int n_init, int n_up, int n_final,
-                               int max_iter, int max_bisect, float* d_fine, float* beta_map, float* iter_usage,
+                               int max_iter, int max_bisect, const float* t_init_dev, const float* u_up_dev,
+                               const float* u_final_dev, float* d_fine, float* beta_map, float* iter_usage,
                                void* workspace, long long workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_rays <= 0) return 0;
@@ -438,8 +439,12 @@ int nerfart_volsdf_fine_sample(const float* surf_blob, const float* rays_o, cons
     sampler_ws_t w;
     const size_t need = carve_sampler((char*)workspace, n_rays, cap, n_up, n_init, n_final, &w);
     if (!workspace || (size_t)workspace_bytes < need) { set_last_error("fine_sample: workspace too small"); return 2; }
-    // linspace tables (exactly torch.linspace)
-    {
+    // linspace tables: torch.linspace(0, 1, n) for n = n_init, n_up + 2, n_final.  Callers that hold the
+    // host framework's own tables pass them (torch's CPU kernel is vectorised and differs from the scalar
+    // formula by an ulp on some entries); otherwise the library's nerfart_linspace is used.
+    if (t_init_dev && u_up_dev && u_final_dev) {
+        w.t_init = const_cast<float*>(t_init_dev); w.u_up = const_cast<float*>(u_up_dev); w.u_final = const_cast<float*>(u_final_dev);
+    } else {
         float* h = (float*)malloc(sizeof(float) * (size_t)(n_init + n_up + 2 + n_final));
         if (!h) { set_last_error("out of host memory"); return 3; }
         nerfart_linspace(0.f, 1.f, n_init, h);
@@ -528,8 +533,9 @@ long long nerfart_volsdf_render_workspace_bytes(int n_rays, int n_samples, int n
 int nerfart_volsdf_render_fwd(const float* surf_blob, const float* rad_blob, int view_tiles, const float* rays_o,
                               const float* rays_d, int n_rays, float near_s, float far_s, float R_bg, float alpha,
                               float beta, float eps, int n_samples, int n_importance, int max_upsample_steps,
-                              int max_bisection_steps, int white_bkgd, int k3_rays_chunk, float* rgb, float* depth,
-                              float* acc, float* normals, float* d_all_out, float* sdf_out, float* nabla_out,
+                              int max_bisection_steps, int white_bkgd, int k3_rays_chunk, const float* t_coarse_dev,
+                              const float* t_init_dev, const float* u_up_dev, const float* u_final_dev, float* rgb,
+                              float* depth, float* acc, float* normals, float* d_all_out, float* sdf_out, float* nabla_out,
                               float* radiance_out, float* sigma_out, float* p_out, float* tau_out, float* beta_map_out,
                               float* iter_usage_out, void* workspace, long long workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -549,9 +555,11 @@ int nerfart_volsdf_render_fwd(const float* surf_blob, const float* rad_blob, int
     if (int rc = nerfart_normalize_dirs(rays_d, w.rays_dn, n_rays, stream)) return rc;
     if (int rc = nerfart_volsdf_fine_sample(surf_blob, rays_o, w.rays_dn, n_rays, nullptr, nullptr, near_s, far_s, R_bg,
                                             alpha, beta, eps, 4 * n_samples, 4 * n_samples, n_importance,
-                                            max_upsample_steps, max_bisection_steps, w.d_fine, beta_map, iter_usage,
-                                            w.sampler, (long long)w.sampler_bytes, stream)) return rc;
-    {
+                                            max_upsample_steps, max_bisection_steps, t_init_dev, u_up_dev, u_final_dev,
+                                            w.d_fine, beta_map, iter_usage, w.sampler, (long long)w.sampler_bytes, stream)) return rc;
+    if (t_coarse_dev) {
+        w.t_coarse = const_cast<float*>(t_coarse_dev);
+    } else {
         float* h = (float*)malloc(sizeof(float) * (size_t)n_samples);
         if (!h) { set_last_error("out of host memory"); return 3; }
         nerfart_linspace(0.f, 1.f, n_samples, h);

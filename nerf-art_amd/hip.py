@@ -27,6 +27,8 @@ _SIGS = {
     "nerfart_abi_version": (_i, []),
     "nerfart_last_error": (C.c_char_p, []),
     "nerfart_linspace": (None, [_f, _f, _i, _p]),
+    "nerfart_profile_begin": (_i, []),
+    "nerfart_profile_end": (_i, [_p, _p, _p]),
     "nerfart_sdf_fwd": (_i, [_p, _p, _ll, _f, _p, _p]),
     "nerfart_sdf_fwd_rays": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _i, _p]),
     "nerfart_sdf_nabla_fwd": (_i, [_p, _p, _ll, _f, _p, _p, _p, _p]),
@@ -41,17 +43,17 @@ _SIGS = {
     "nerfart_volsdf_merge_check": (_i, [_i, _i, _i, _i, _i, _i, _i, _f, _f, _f] + [_p] * 15),
     "nerfart_volsdf_finalize": (_i, [_i, _i, _i, _i] + [_p] * 9),
     "nerfart_volsdf_sampler_workspace_bytes": (_ll, [_i, _i, _i, _i, _i]),
-    "nerfart_volsdf_fine_sample": (_i, [_p, _p, _p, _i, _p, _p, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _p, _p, _p, _p, _ll, _p]),
+    "nerfart_volsdf_fine_sample": (_i, [_p, _p, _p, _i, _p, _p, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _ll, _p]),
     "nerfart_sort_concat": (_i, [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p]),
     "nerfart_volsdf_composite": (_i, [_i, _i, _p, _p, _p, _p, _f, _f, _i] + [_p] * 8),
     "nerfart_volsdf_render_workspace_bytes": (_ll, [_i, _i, _i, _i, _i]),
-    "nerfart_volsdf_render_fwd": (_i, [_p, _p, _i, _p, _p, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i] + [_p] * 13 + [_p, _ll, _p]),
+    "nerfart_volsdf_render_fwd": (_i, [_p, _p, _i, _p, _p, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i] + [_p] * 4 + [_p] * 13 + [_p, _ll, _p]),
     "nerfart_near_far_from_sphere": (_i, [_p, _p, _i, _f, _p, _p, _p]),
     "nerfart_neus_upsample_step": (_i, [_i, _i, _i, _i, _f, _p, _p, _p, _p, _p]),
     "nerfart_merge_sorted_pairs": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "nerfart_neus_composite": (_i, [_i, _i, _p, _p, _p, _p, _f, _i] + [_p] * 9),
     "nerfart_neus_render_workspace_bytes": (_ll, [_i, _i, _i, _i]),
-    "nerfart_neus_render_fwd": (_i, [_p, _p, _i, _p, _p, _i, _f, _f, _i, _i, _i, _i, _i] + [_p] * 12 + [_p, _ll, _p]),
+    "nerfart_neus_render_fwd": (_i, [_p, _p, _i, _p, _p, _i, _f, _f, _i, _i, _i, _i, _i] + [_p] * 2 + [_p] * 12 + [_p, _ll, _p]),
 }
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)          # AttributeError here = header / library mismatch
@@ -90,6 +92,17 @@ def linspace(start: float, end: float, n: int) -> torch.Tensor:
     out = torch.empty(n, dtype=torch.float32)
     lib.nerfart_linspace(start, end, n, out.data_ptr())
     return out
+
+
+def profile_begin():
+    lib.nerfart_profile_begin()
+
+
+def profile_end():
+    """-> {kernel: (ms, launches, points)} for the chained-MLP kernels launched since profile_begin()."""
+    ms = (C.c_double * 3)(); ln = (C.c_longlong * 3)(); un = (C.c_longlong * 3)()
+    lib.nerfart_profile_end(ms, ln, un)
+    return {k: (ms[i], ln[i], un[i]) for i, k in enumerate(("k_sdf_only", "k_sdf_nabla", "k_radiance"))}
 
 
 # ---- point queries -----------------------------------------------------------------------
@@ -147,6 +160,17 @@ def normalize_dirs(d):
     return out
 
 
+_lin_cache = {}
+
+
+def lin_table(n: int, device) -> torch.Tensor:
+    """torch.linspace(0, 1, n) as the reference builds it (CPU kernel, then moved; volsdf.py:472,483), cached."""
+    key = (n, str(device))
+    if key not in _lin_cache:
+        _lin_cache[key] = torch.linspace(0, 1, n).float().to(device)
+    return _lin_cache[key]
+
+
 _ws_cache = {}
 
 
@@ -172,7 +196,8 @@ def volsdf_fine_sample(surf_blob, rays_o, rays_dn, near: float, far: float, R_bg
     ws = _workspace(nb, dev)
     _check(lib.nerfart_volsdf_fine_sample(_dev(surf_blob), _dev(rays_o), _dev(rays_dn), R, None, None, float(near), float(far),
                                           float(R_bg), float(alpha), float(beta), float(eps), n_init, n_up, n_final, max_iter,
-                                          max_bisect, _dev(d_fine), _dev(beta_map), _dev(usage), ws.data_ptr(), ws.numel(),
+                                          max_bisect, _dev(lin_table(n_init, dev)), _dev(lin_table(n_up + 2, dev)),
+                                          _dev(lin_table(n_final, dev)), _dev(d_fine), _dev(beta_map), _dev(usage), ws.data_ptr(), ws.numel(),
                                           _stream()), "nerfart_volsdf_fine_sample")
     return d_fine, beta_map, usage
 
@@ -199,6 +224,8 @@ def volsdf_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, near, far,
         _dev(surf_blob), _dev(rad_blob), int(view_tiles), _dev(rays_o, name="rays_o"), _dev(rays_d, name="rays_d"), R,
         float(near), float(far), float(R_bg), float(alpha), float(beta), float(eps), n_samples, n_importance,
         max_upsample_steps, max_bisection_steps, int(bool(white_bkgd)), k3_rays_chunk,
+        _dev(lin_table(n_samples, dev)), _dev(lin_table(4 * n_samples, dev)), _dev(lin_table(4 * n_samples + 2, dev)),
+        _dev(lin_table(n_importance, dev)),
         _dev(out["rgb"]), _dev(out["depth_volume"]), _dev(out["mask_volume"]), _dev(out.get("normals_volume")),
         g("d_vals"), g("implicit_surface"), g("implicit_nablas"), g("radiance"), g("sigma"), g("p_i"),
         g("visibility_weights"), g("beta_map"), g("iter_usage"), ws.data_ptr(), ws.numel(), _stream()),
@@ -226,6 +253,7 @@ def neus_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, obj_bounding
     _check(lib.nerfart_neus_render_fwd(
         _dev(surf_blob), _dev(rad_blob), int(view_tiles), _dev(rays_o, name="rays_o"), _dev(rays_d, name="rays_d"), R,
         float(obj_bounding_radius), float(s), n_samples, n_importance, n_upsample_iters, int(bool(white_bkgd)), k3_rays_chunk,
+        _dev(lin_table(n_samples, dev)), _dev(lin_table(n_importance // n_upsample_iters, dev)),
         _dev(out["rgb"]), _dev(out["depth_volume"]), _dev(out["mask_volume"]), _dev(out.get("normals_volume")),
         g("d_all"), g("implicit_surface"), g("implicit_nablas"), g("radiance"), g("cdf"), g("alpha"),
         g("visibility_weights"), g("d_final"), ws.data_ptr(), ws.numel(), _stream()), "nerfart_neus_render_fwd")

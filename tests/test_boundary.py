@@ -1,0 +1,35 @@
+"""The product never routes through the oracle or any CPU fallback (task rule 3)."""
+import os
+import re
+
+from conftest import REPO
+
+
+def _py_files(root):
+    for d, _, fs in os.walk(root):
+        if "_build" in d or "__pycache__" in d:
+            continue
+        for f in fs:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                yield os.path.join(d, f)
+
+
+def test_package_does_not_import_oracle_or_reference():
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|/root/reference", re.M)
+    for root in (os.path.join(REPO, "nerf-art_amd"), os.path.join(REPO, "nerfart_amd")):
+        for p in _py_files(root):
+            assert not pat.search(open(p).read()), f"{p} references the oracle / the reference tree"
+
+
+def test_runtime_files_do_not_read_reference_tree():
+    for name in ("bench.py", "__graft_entry__.py"):
+        p = os.path.join(REPO, name)
+        if os.path.exists(p):
+            assert "/root/reference" not in open(p).read()
+
+
+def test_hip_module_has_no_fallback_branch():
+    src = open(os.path.join(REPO, "nerf-art_amd", "hip.py")).read()
+    assert "raise ImportError" in src and "fallback" in src
+    nets = open(os.path.join(REPO, "nerf-art_amd", "nets.py")).read()
+    assert "F.linear" not in nets and "softplus" not in nets, "nets.py must not carry an eager compute path"

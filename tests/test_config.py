@@ -1,0 +1,43 @@
+"""Config loader keeps the reference's schema / CLI override semantics (utils/io_util.py:194-340) and the
+reference's four YAMLs load unchanged when the reference tree is available."""
+import os
+
+import pytest
+
+from nerfart_amd import config, scene, frameworks
+
+REF_CFG = "/root/reference/configs"
+
+
+def test_attribute_dict_semantics():
+    c = config.ConfigDict({"a": {"b": 1, "c": [1, {"d": 2}]}, "x": None})
+    assert c.a.b == 1 and c.a.c[1].d == 2
+    with pytest.raises(KeyError):
+        _ = c.a.zzz
+    assert c.a.setdefault("e", 5) == 5 and c.a.e == 5
+    assert c.to_dict() == {"a": {"b": 1, "c": [1, {"d": 2}], "e": 5}, "x": None}
+
+
+def test_cli_overrides_are_typed_by_existing_value():
+    c = config.ConfigDict({"data": {"downscale": 1, "pin_memory": True, "cam_file": None}, "expname": "x"})
+    config.update_config(c, ["--data:downscale", "2", "--data:pin_memory", "false", "--data:cam_file", "cams.npz", "--expname", "y"])
+    assert c.data.downscale == 2 and c.data.pin_memory is False and c.data.cam_file == "cams.npz" and c.expname == "y"
+
+
+def test_synthetic_configs_build_both_frameworks():
+    for fw, n in (("VolSDF", 796347), ("NeuS", 802491)):
+        m, _, rk_train, rk_test, fn = frameworks.get_model(scene.synthetic_config(fw))
+        assert sum(p.numel() for p in m.parameters()) == n
+        assert rk_test["perturb"] is False and callable(fn)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CFG), reason="reference tree not present (GPU box)")
+def test_reference_yamls_load_unchanged():
+    for name, fw in (("volsdf_fangzhou_nature.yaml", "VolSDF"), ("volsdf_fangzhou_vangogh.yaml", "VolSDF"),
+                     ("neus_fangzhou.yaml", "NeuS"), ("neus_fangzhou_vangogh.yaml", "NeuS")):
+        c = config.load_yaml(os.path.join(REF_CFG, name))
+        assert c.model.framework == fw
+        m, _, _, rk_test, _ = frameworks.get_model(c)
+        assert type(m).__name__ == fw
+        if c.get("finetune"):
+            assert c.finetune.target_text.startswith("painting")
