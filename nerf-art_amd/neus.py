@@ -35,7 +35,7 @@ def volume_render(rays_o, rays_d, model: NeuS, obj_bounding_radius=1.0, batched=
     rd = rays_d.reshape(-1, 3).float().contiguous()
     N = ro.shape[0]
     surf_blob, rad_blob = model.packed()
-    s = float(model.forward_s())
+    s = float(model.forward_s().detach())
     chunk = int(rayschunk) if rayschunk else DEFAULT_RAYSCHUNK
     parts = []
     for i in range(0, N, chunk):

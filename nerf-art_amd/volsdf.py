@@ -46,7 +46,7 @@ def volume_render(rays_o, rays_d, model: VolSDF, near=0.0, far=6.0, obj_bounding
     N = ro.shape[0]
     surf_blob, rad_blob = model.packed()
     alpha, beta = model.forward_ab()
-    alpha, beta = float(alpha), float(beta)
+    alpha, beta = float(alpha.detach()), float(beta.detach())
     chunk = int(rayschunk) if rayschunk else DEFAULT_RAYSCHUNK
     want_normal = bool(calc_normal and require_nablas)
     parts = []
