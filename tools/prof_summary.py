@@ -9,9 +9,9 @@ def main():
     db, out = sys.argv[1], sys.argv[2]
     title = sys.argv[3] if len(sys.argv) > 3 else db
     c = sqlite3.connect(db)
-    lines = [f"# {title}", "# source: rocprofv3 --kernel-trace --stats (view top_kernels); durations in microseconds", ""]
+    lines = [f"# {title}", "# source: rocprofv3 --kernel-trace --stats (view top_kernels); durations in milliseconds", ""]
     rows = c.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
-    lines.append(f"{'calls':>6} {'total_us':>14} {'avg_us':>12} {'pct':>7}  kernel")
+    lines.append(f"{'calls':>6} {'total_ms':>14} {'avg_ms':>12} {'pct':>7}  kernel")
     for name, calls, tot, avg, pct in rows[:24]:
         short = name.split("(")[0].replace("void ", "")
         lines.append(f"{calls:>6} {tot/1e3:>14.1f} {avg/1e3:>12.2f} {pct:>7.3f}  {short}")
