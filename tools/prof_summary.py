@@ -16,23 +16,23 @@ def main():
         short = name.split("(")[0].replace("void ", "")
         lines.append(f"{calls:>6} {tot/1e3:>14.1f} {avg/1e3:>12.2f} {pct:>7.3f}  {short}")
     tabs = [r[0] for r in c.execute("select name from sqlite_master where type in ('table','view')")]
-    if "pmc_events" in tabs or any(t.startswith("rocpd_pmc_event") for t in tabs):
-        try:
-            q = ("select k.kernel_name, p.counter_name, count(*), sum(p.value), avg(p.value) from counters_collection p "
-                 "join kernels k on 1=0")
-        except Exception:
-            pass
-        for view in ("counters_collection",):
-            if view in tabs:
-                cur = c.execute(f"select * from {view} limit 1")
-                cols = [d[0] for d in cur.description]
-                lines += ["", f"# PMC counters (view {view}; columns {cols})"]
-                namecol = "kernel_name" if "kernel_name" in cols else cols[0]
-                agg = c.execute(f"select {namecol}, counter_name, count(*), sum(value), avg(value) from {view} "
-                                f"group by {namecol}, counter_name order by sum(value) desc").fetchall()
-                lines.append(f"{'n':>6} {'sum':>20} {'avg_per_dispatch':>20}  counter  kernel")
-                for kn, cn, n, s, a in agg[:60]:
-                    lines.append(f"{n:>6} {s:>20.4g} {a:>20.6g}  {cn}  {str(kn).split('(')[0]}")
+    pmc_views = [t for t in tabs if t in ("counters_collection", "pmc_events", "pmc_info") or "pmc" in t.lower() or "counter" in t.lower()]
+    lines += ["", f"# pmc-related tables/views: {pmc_views}"]
+    for view in ("counters_collection",):
+        if view in tabs:
+            cur = c.execute(f"select * from {view} limit 1")
+            cols = [d[0] for d in cur.description]
+            lines += [f"# view {view} columns: {cols}"]
+            namecol = next((x for x in ("kernel_name", "name", "kernel") if x in cols), None)
+            cntcol = next((x for x in ("counter_name", "pmc_name", "counter") if x in cols), None)
+            valcol = next((x for x in ("value", "counter_value") if x in cols), None)
+            if namecol and cntcol and valcol:
+                agg = c.execute(f"select {namecol}, {cntcol}, count(*), sum({valcol}), avg({valcol}) from {view} "
+                                f"group by {namecol}, {cntcol} order by {cntcol}, sum({valcol}) desc").fetchall()
+                lines.append(f"{'dispatches':>10} {'sum':>20} {'avg_per_dispatch':>20}  counter  kernel")
+                for kn, cn, n, sm, av in agg:
+                    if "nerfart" in str(kn):
+                        lines.append(f"{n:>10} {sm:>20.6g} {av:>20.6g}  {cn}  {str(kn).split('(')[0].replace('void ', '')}")
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines[:14]))
 
