@@ -126,6 +126,19 @@ def main():
                     "launches": int(launches), "avg_launch_ms": round(ms / launches, 4),
                     "points_per_launch": int(points / launches),
                     "flops_per_point": F_SDF}
+        # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+        # separate runs; (2*FETCH + WRITE) KiB with the gfx950 FETCH_SIZE correction) - bench.py itself cannot
+        # read hardware counters.
+        import glob
+        pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+        if pm:
+            try:
+                kk = json.load(open(pm[-1]))["kernels"]["k_sdf_only"]
+                roofline["traffic"] = int(kk["hbm_bytes_corrected_per_launch"])
+                roofline["traffic_source"] = os.path.basename(pm[-1])
+                roofline["mfma_util_pmc"] = round(kk.get("mfma_util", 0.0), 4)
+            except Exception:
+                pass
     kernels_ms = {k: round(v[0] / args.steps, 3) for k, v in prof.items()}
 
     cpu = None
