@@ -34,6 +34,7 @@ if ROOT not in sys.path:
 F_SDF, F_NABLA, F_RAD = 1049088, 918016, 530432          # algorithmic flops / point
 H, W, N_SAMPLES, N_IMPORTANCE = 480, 270, 128, 64
 PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_BF16_MFMA_TFLOPS = 2500.0
 
 
 def main():
@@ -42,6 +43,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--beta", type=float, default=0.01)
+    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
+                    help="fp32: exact v_mfma_f32_16x16x4_f32; bf16x3: split-bf16 operands on v_mfma_f32_32x32x16_bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=768)
     args = ap.parse_args()
@@ -62,7 +65,7 @@ def main():
 
     from nerfart_amd import scene, rend_util, hip, dist as nd
 
-    model, rk, render_fn = scene.build_model("VolSDF", seed=0, beta=args.beta, device=dev)
+    model, rk, render_fn = scene.build_model("VolSDF", seed=0, beta=args.beta, device=dev, precision=args.precision)
     kw = {k: v for k, v in rk.items() if k != "rayschunk"}
     n_views = args.warmup + args.steps
     angles = scene.spiral(max(90, n_views * world))
@@ -121,8 +124,11 @@ def main():
         flops_per_launch = points / launches * F_SDF
         avg_s = ms / launches * 1e-3
         achieved = flops_per_launch / avg_s / 1e12
-        roofline = {"bound": "mfma", "kernel": "k_sdf_only", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+        # bf16x3 issues 3 bf16 MFMAs per algorithmic product: priced against the dense bf16 MFMA peak
+        peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+        kname = "k_sdf_only" if args.precision == "fp32" else "k_sdf_only_bf16"
+        roofline = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
                     "launches": int(launches), "avg_launch_ms": round(ms / launches, 4),
                     "points_per_launch": int(points / launches),
                     "flops_per_point": F_SDF}
@@ -133,7 +139,7 @@ def main():
         pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
         if pm:
             try:
-                kk = json.load(open(pm[-1]))["kernels"]["k_sdf_only"]
+                kk = json.load(open(pm[-1]))["kernels"][kname]
                 roofline["traffic"] = int(kk["hbm_bytes_corrected_per_launch"])
                 roofline["traffic_source"] = os.path.basename(pm[-1])
                 roofline["mfma_util_pmc"] = round(kk.get("mfma_util", 0.0), 4)
@@ -164,7 +170,7 @@ def main():
             "metric": "rays/sec at 480x270x128spp VolSDF render",
             "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16x3 (f32 split into 2 bf16 terms, f32 accumulate)", "data": "synthetic",
             "config": {"workload": "configs[1]: volsdf_fangzhou_nature.yaml dims, 480x270 rays/frame, 128 coarse + 64 fine "
                                    "spp, pure renderer (no CLIP), synthetic random-weight scene beta=%g" % args.beta,
                        "rays_per_step_per_gpu": H * W, "samples_per_ray": N_SAMPLES + N_IMPORTANCE,

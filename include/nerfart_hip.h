@@ -12,8 +12,11 @@
  *     with a data-dependent loop (fine_sample, render) synchronise that stream internally.
  *   - return value 0 = success; non-zero = failure, message via nerfart_last_error() (thread local).
  *   - `blob` arguments are weight blobs produced by nerf-art_amd/packing.py (layout documented
- *     there and in DESIGN.md): `surf_blob` = program 1 (SDF net), `rad_blob` = program 2
- *     (geometry-feature rows + radiance net).
+ *     there and in DESIGN.md): `surf_blob` = SDF net, `rad_blob` = geometry-feature rows + radiance net.
+ *   - `precision` selects the matrix-core path AND the blob format it expects:
+ *       0 = fp32-exact (v_mfma_f32_16x16x4_f32; blobs from surface_plan()/radiance_plan()),
+ *       1 = split bf16 "bf16x3" (3 x v_mfma_f32_32x32x16_bf16 per k-step on hi/lo operand splits, ~2^-16
+ *           relative per product; blobs from surface_plan_bf16()/radiance_plan_bf16()).
  *   - point sources: either an explicit array pts[M,3], or ("_rays" variants) rays + per-ray depths:
  *     point m = slot m / n_per_ray, sample m % n_per_ray, ray = ray_idx ? ray_idx[slot] : slot,
  *     x = rays_o[ray] + rays_d[ray] * depth[slot * depth_stride + sample]  (two roundings, as the
@@ -41,25 +44,25 @@ void nerfart_linspace(float start, float end, int n, float* out);
 /* ---- B3: SDF query.  ImplicitSurface.forward (models/base.py:243-263) + VolSDF.forward_surface
  * sphere clamp sdf = min(sdf, R_bg - |x|) (models/frameworks/volsdf.py:341-347); R_bg <= 0: no clamp
  * (NeuS, neus.py:277,299). */
-int nerfart_sdf_fwd(const float* surf_blob, const float* pts, long long M, float R_bg, float* sdf_out, void* stream);
-int nerfart_sdf_fwd_rays(const float* surf_blob, const float* rays_o, const float* rays_d, const int* ray_idx,
+int nerfart_sdf_fwd(const float* surf_blob, int precision, const float* pts, long long M, float R_bg, float* sdf_out, void* stream);
+int nerfart_sdf_fwd_rays(const float* surf_blob, int precision, const float* rays_o, const float* rays_d, const int* ray_idx,
                          const float* depth, int n_slots, int n_per_ray, int depth_stride, float R_bg,
                          float* sdf_out, int out_stride, void* stream);
 
 /* ---- B2 (first half): ImplicitSurface.forward_with_nablas (models/base.py:265-282) + the clamp of
  * VolSDF.forward_surface_with_nablas (volsdf.py:349-357; nabla is NOT replaced).  Outputs sdf[M],
  * nabla[M,3] and, if h7_out != NULL, the layer-7 activation h7[M,256] consumed by nerfart_radiance_fwd. */
-int nerfart_sdf_nabla_fwd(const float* surf_blob, const float* pts, long long M, float R_bg, float* sdf_out,
+int nerfart_sdf_nabla_fwd(const float* surf_blob, int precision, const float* pts, long long M, float R_bg, float* sdf_out,
                           float* nabla_out, float* h7_out, void* stream);
-int nerfart_sdf_nabla_fwd_rays(const float* surf_blob, const float* rays_o, const float* rays_d, const int* ray_idx,
+int nerfart_sdf_nabla_fwd_rays(const float* surf_blob, int precision, const float* rays_o, const float* rays_d, const int* ray_idx,
                                const float* depth, int n_slots, int n_per_ray, int depth_stride, float R_bg,
                                float* sdf_out, float* nabla_out, float* h7_out, void* stream);
 
 /* ---- B2 (second half): geometry feature (last SDF layer rows 1..256, base.py:253-256) + RadianceNet.forward
  * (models/base.py:372-391) on [x, view (raw: view_tiles=1 | embed 4: view_tiles=3), nabla, feat]. */
-int nerfart_radiance_fwd(const float* rad_blob, int view_tiles, const float* pts, const float* view, long long M,
+int nerfart_radiance_fwd(const float* rad_blob, int precision, int view_tiles, const float* pts, const float* view, long long M,
                          const float* nabla, const float* h7, float* rgb_out, void* stream);
-int nerfart_radiance_fwd_rays(const float* rad_blob, int view_tiles, const float* rays_o, const float* rays_d,
+int nerfart_radiance_fwd_rays(const float* rad_blob, int precision, int view_tiles, const float* rays_o, const float* rays_d,
                               const int* ray_idx, const float* depth, int n_slots, int n_per_ray, int depth_stride,
                               const float* nabla, const float* h7, float* rgb_out, void* stream);
 
@@ -91,7 +94,7 @@ int nerfart_volsdf_finalize(int n_active, int n, int cap, int n_final, const flo
                             const float* u_final, const float* beta_plus, float* d_fine, float* beta_map,
                             float* iter_usage, void* stream);
 long long nerfart_volsdf_sampler_workspace_bytes(int n_rays, int n_init, int n_up, int n_final, int max_iter);
-int nerfart_volsdf_fine_sample(const float* surf_blob, const float* rays_o, const float* rays_dn, int n_rays,
+int nerfart_volsdf_fine_sample(const float* surf_blob, int precision, const float* rays_o, const float* rays_dn, int n_rays,
                                const float* near, const float* far, float near_s, float far_s, float R_bg,
                                float alpha_net, float beta_net, float eps, int n_init, int n_up, int n_final,
                                int max_iter, int max_bisect, const float* t_init_dev, const float* u_up_dev,
@@ -112,7 +115,7 @@ int nerfart_volsdf_composite(int n_rays, int P, const float* d_all, const float*
 /* ---- B1: VolSDF volume_render (volsdf.py:389-615) for one chunk of rays (rays_d un-normalised). */
 long long nerfart_volsdf_render_workspace_bytes(int n_rays, int n_samples, int n_importance, int max_upsample_steps,
                                                 int k3_rays_chunk);
-int nerfart_volsdf_render_fwd(const float* surf_blob, const float* rad_blob, int view_tiles, const float* rays_o,
+int nerfart_volsdf_render_fwd(const float* surf_blob, const float* rad_blob, int precision, int view_tiles, const float* rays_o,
                               const float* rays_d, int n_rays, float near_s, float far_s, float R_bg, float alpha,
                               float beta, float eps, int n_samples, int n_importance, int max_upsample_steps,
                               int max_bisection_steps, int white_bkgd, int k3_rays_chunk, const float* t_coarse_dev,
@@ -134,7 +137,7 @@ int nerfart_neus_composite(int n_rays, int P, const float* d_all, const float* s
                            float* normals, float* cdf_out, float* alpha_out, float* w_out, float* d_mid_out,
                            void* stream);
 long long nerfart_neus_render_workspace_bytes(int n_rays, int n_samples, int n_importance, int k3_rays_chunk);
-int nerfart_neus_render_fwd(const float* surf_blob, const float* rad_blob, int view_tiles, const float* rays_o,
+int nerfart_neus_render_fwd(const float* surf_blob, const float* rad_blob, int precision, int view_tiles, const float* rays_o,
                             const float* rays_d, int n_rays, float obj_bounding_radius, float s, int n_samples,
                             int n_importance, int n_upsample_iters, int white_bkgd, int k3_rays_chunk,
                             const float* t_coarse_dev, const float* u_new_dev, float* rgb,

@@ -19,7 +19,7 @@
 //   * K3a evaluates d sdf / d x in forward mode: a column quad = (value, d/dx, d/dy, d/dz) of one
 //     point, the activation derivative is broadcast inside the quad with one DPP op.
 //   * persistent grid (one workgroup per CU), tiles grid-strided.
-#include "nerfart_common.h"
+#include "mlp_common.h"
 
 namespace nerfart {
 
@@ -29,99 +29,9 @@ constexpr int XT_MAX = 19;                          // most input tiles of any l
 constexpr int KT_FLOATS = 16 * 256;                 // one k tile of a chunk: 16 out tiles x (64 lanes x 4)
 constexpr int CHUNK_FLOATS_MAX = 2 * KT_FLOATS;     // a chunk holds 1 or 2 k tiles (32 KiB)
 constexpr int AUX_FLOATS_MAX = 2560;
-constexpr int TAB_INTS = 128;                       // chunk offset table (nc + 1 <= 128 entries)
 constexpr int LDS_FLOATS = 2 * CHUNK_FLOATS_MAX + AUX_FLOATS_MAX + TAB_INTS;   // 76,288 B
 
-// Where the points of a launch come from: an explicit [M,3] array, or rays + per-ray depths
-// (point m = slot m / n_per_ray, sample m % n_per_ray; ray = ray_idx ? ray_idx[slot] : slot).
-struct PointSrc {
-    const float* pts;
-    const float* rays_o;
-    const float* rays_d;
-    const int* ray_idx;
-    const float* depth;
-    const float* view;      // explicit per-point view dirs [M,3] (pts mode, radiance only)
-    int n_per_ray;
-    int depth_stride;
-    unsigned M;
-};
-
-struct Pt { float x, y, z, vx, vy, vz; };
-
-__device__ __forceinline__ Pt fetch_point(const PointSrc& s, unsigned m, bool want_view) {
-    Pt p = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (m >= s.M) return p;
-    if (s.pts) {
-        p.x = s.pts[3 * (size_t)m + 0]; p.y = s.pts[3 * (size_t)m + 1]; p.z = s.pts[3 * (size_t)m + 2];
-        if (want_view) { p.vx = s.view[3 * (size_t)m + 0]; p.vy = s.view[3 * (size_t)m + 1]; p.vz = s.view[3 * (size_t)m + 2]; }
-    } else {
-        const unsigned slot = m / (unsigned)s.n_per_ray;
-        const unsigned k = m - slot * (unsigned)s.n_per_ray;
-        const unsigned ray = s.ray_idx ? (unsigned)s.ray_idx[slot] : slot;
-        const float t = s.depth[(size_t)slot * s.depth_stride + k];
-        const float ox = s.rays_o[3 * (size_t)ray + 0], oy = s.rays_o[3 * (size_t)ray + 1], oz = s.rays_o[3 * (size_t)ray + 2];
-        p.vx = s.rays_d[3 * (size_t)ray + 0]; p.vy = s.rays_d[3 * (size_t)ray + 1]; p.vz = s.rays_d[3 * (size_t)ray + 2];
-        p.x = ray_point(ox, p.vx, t); p.y = ray_point(oy, p.vy, t); p.z = ray_point(oz, p.vz, t);
-    }
-    return p;
-}
-
-// ---------------------------------------------------------------------------------------
-// Weight-chunk pipeline: chunk c of the blob is consumed from LDS buffer pb while chunk c+1
-// streams into buffer pb^1.  The chunk offset table lives in LDS (copied once at kernel start);
-// the offsets of the chunk to prefetch are looked up one acquire ahead so the lookup latency never
-// sits between the barrier and the LDS-DMA issue.  (Reading the table from global memory here
-// would be a VMEM load - the LDS-DMA asm makes hipcc treat global memory as clobbered, so it
-// cannot use scalar loads - and its vmcnt(0) wait would serialise behind the DMA.)
-// ---------------------------------------------------------------------------------------
-struct Pipe {
-    const float* blob;
-    const int* tab;   // LDS copy of header[NERFART_HDR_OFFS ...]: nc + 1 float offsets
-    float* lds;
-    int nc;           // chunks per pass
-    int nxt;          // chunk the next acquire() will prefetch (-1: none)
-    int nxt_o0, nxt_o1;
-    int pb;           // LDS buffer the next acquire() returns
-    bool wrap;        // another tile follows: prefetch chunk 0 after the last chunk
-};
-
-__device__ __forceinline__ void pipe_issue_range(const Pipe& p, int o0, int o1, int buf) {
-    const int npieces = (o1 - o0) >> 8;                       // 1 KiB (256 floats) per wave-instruction
-    const float* src = p.blob + o0 + lane_id() * 4;
-    const unsigned dst = lds_addr(p.lds + buf * CHUNK_FLOATS_MAX);
-    for (int q = wave_id(); q < npieces; q += WAVES)
-        glds16(src + q * 256, __builtin_amdgcn_readfirstlane(dst + q * 1024));
-}
-
-__device__ __forceinline__ void pipe_lookup(Pipe& p, int chunk) {
-    p.nxt = chunk;
-    if (chunk >= 0) {
-        p.nxt_o0 = __builtin_amdgcn_readfirstlane(p.tab[chunk]);
-        p.nxt_o1 = __builtin_amdgcn_readfirstlane(p.tab[chunk + 1]);
-    }
-}
-
-// Called once per workgroup after the table is in LDS: start streaming chunk 0 into buffer 0.
-__device__ __forceinline__ void pipe_start(Pipe& p) {
-    pipe_lookup(p, 0);
-    pipe_issue_range(p, p.nxt_o0, p.nxt_o1, 0);
-    p.pb = 0;
-    pipe_lookup(p, 1 < p.nc ? 1 : -1);
-}
-
-__device__ __forceinline__ const float* pipe_acquire(Pipe& p) {
-    wait_glds();          // my pieces of the current chunk have landed
-    __syncthreads();      // everyone's pieces landed; everyone is done with buffer pb^1
-    const int cur = p.nxt;
-    if (cur >= 0) pipe_issue_range(p, p.nxt_o0, p.nxt_o1, p.pb ^ 1);
-    int f = cur + 1;
-    if (cur < 0) f = -1;
-    else if (f == p.nc) f = p.wrap ? 0 : -1;
-    pipe_lookup(p, f);
-    const float* w = p.lds + p.pb * CHUNK_FLOATS_MAX;
-    p.pb ^= 1;
-    return w;
-}
+using Pipe = PipeT<WAVES, CHUNK_FLOATS_MAX>;
 
 // ---------------------------------------------------------------------------------------
 // One dense layer on register-resident activations, in place.
@@ -504,25 +414,6 @@ k_radiance(const float* __restrict__ blob, PointSrc src, const float* __restrict
     }
 }
 
-static int g_num_cus = 0;
-static int num_cus() {
-    if (!g_num_cus) {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    return g_num_cus;
-}
-
-static int validate_src(const PointSrc& s) {
-    if (s.M == 0) return 0;
-    if (!s.pts && !(s.rays_o && s.rays_d && s.depth && s.n_per_ray > 0)) {
-        set_last_error("point source: need pts, or rays_o + rays_d + depth + n_per_ray");
-        return 2;
-    }
-    return 0;
-}
-
 template <typename K, typename... Args>
 static int launch_chain(int prof_cls, long long units, K kernel, unsigned ntiles, hipStream_t stream, Args... args) {
     const size_t lds = LDS_FLOATS * sizeof(float);
@@ -540,30 +431,30 @@ static int launch_chain(int prof_cls, long long units, K kernel, unsigned ntiles
 
 using namespace nerfart;
 
-static PointSrc make_src(const float* pts, const float* view, const float* rays_o, const float* rays_d,
-                         const int* ray_idx, const float* depth, int n_per_ray, int depth_stride, long long M) {
-    PointSrc s;
-    s.pts = pts; s.view = view; s.rays_o = rays_o; s.rays_d = rays_d; s.ray_idx = ray_idx; s.depth = depth;
-    s.n_per_ray = n_per_ray; s.depth_stride = depth_stride; s.M = (unsigned)M;
-    return s;
+namespace nerfart {
+int sdf_bf16(const float* blob, const PointSrc& s, float R_bg, float* out, int out_stride, hipStream_t st);
+int sdf_nabla_bf16(const float* blob, const PointSrc& s, float R_bg, float* sdf, float* nabla, float* h7, hipStream_t st);
+int radiance_bf16(const float* blob, int view_tiles, const PointSrc& s, const float* nabla, const float* h7, float* rgb, hipStream_t st);
+static int check_precision(int precision) {
+    if (precision == 0 || precision == 1) return 0;
+    set_last_error("precision must be 0 (fp32-exact MFMA) or 1 (split-bf16 'bf16x3' MFMA)");
+    return 2;
 }
-
-static int check_M(long long M) {
-    if (M < 0 || M >= (1ll << 31)) { set_last_error("M out of range (0 <= M < 2^31 points per launch)"); return 2; }
-    return 0;
-}
+}  // namespace nerfart
 
 extern "C" {
 
-int nerfart_sdf_fwd(const float* blob, const float* pts, long long M, float R_bg, float* sdf_out, void* stream) {
+int nerfart_sdf_fwd(const float* blob, int precision, const float* pts, long long M, float R_bg, float* sdf_out, void* stream) {
+    if (int rc = check_precision(precision)) return rc;
     if (int rc = check_M(M)) return rc;
     if (M == 0) return 0;
     PointSrc s = make_src(pts, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, M);
     if (int rc = validate_src(s)) return rc;
+    if (precision == 1) return sdf_bf16(blob, s, R_bg, sdf_out, 0, (hipStream_t)stream);
     return launch_chain(0, M, k_sdf_only, (unsigned)((M + 127) / 128), (hipStream_t)stream, blob, s, R_bg, sdf_out, 0);
 }
 
-int nerfart_sdf_fwd_rays(const float* blob, const float* rays_o, const float* rays_d, const int* ray_idx,
+int nerfart_sdf_fwd_rays(const float* blob, int precision, const float* rays_o, const float* rays_d, const int* ray_idx,
                          const float* depth, int n_slots, int n_per_ray, int depth_stride, float R_bg,
                          float* sdf_out, int out_stride, void* stream) {
     const long long M = (long long)n_slots * n_per_ray;
@@ -571,19 +462,23 @@ int nerfart_sdf_fwd_rays(const float* blob, const float* rays_o, const float* ra
     if (M == 0) return 0;
     PointSrc s = make_src(nullptr, nullptr, rays_o, rays_d, ray_idx, depth, n_per_ray, depth_stride, M);
     if (int rc = validate_src(s)) return rc;
+    if (int rc = check_precision(precision)) return rc;
+    if (precision == 1) return sdf_bf16(blob, s, R_bg, sdf_out, out_stride, (hipStream_t)stream);
     return launch_chain(0, M, k_sdf_only, (unsigned)((M + 127) / 128), (hipStream_t)stream, blob, s, R_bg, sdf_out, out_stride);
 }
 
-int nerfart_sdf_nabla_fwd(const float* blob, const float* pts, long long M, float R_bg, float* sdf_out,
+int nerfart_sdf_nabla_fwd(const float* blob, int precision, const float* pts, long long M, float R_bg, float* sdf_out,
                           float* nabla_out, float* h7_out, void* stream) {
     if (int rc = check_M(M)) return rc;
     if (M == 0) return 0;
     PointSrc s = make_src(pts, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, M);
     if (int rc = validate_src(s)) return rc;
+    if (int rc = check_precision(precision)) return rc;
+    if (precision == 1) return sdf_nabla_bf16(blob, s, R_bg, sdf_out, nabla_out, h7_out, (hipStream_t)stream);
     return launch_chain(1, M, k_sdf_nabla, (unsigned)((M + 31) / 32), (hipStream_t)stream, blob, s, R_bg, sdf_out, nabla_out, h7_out);
 }
 
-int nerfart_sdf_nabla_fwd_rays(const float* blob, const float* rays_o, const float* rays_d, const int* ray_idx,
+int nerfart_sdf_nabla_fwd_rays(const float* blob, int precision, const float* rays_o, const float* rays_d, const int* ray_idx,
                                const float* depth, int n_slots, int n_per_ray, int depth_stride, float R_bg,
                                float* sdf_out, float* nabla_out, float* h7_out, void* stream) {
     const long long M = (long long)n_slots * n_per_ray;
@@ -591,16 +486,20 @@ int nerfart_sdf_nabla_fwd_rays(const float* blob, const float* rays_o, const flo
     if (M == 0) return 0;
     PointSrc s = make_src(nullptr, nullptr, rays_o, rays_d, ray_idx, depth, n_per_ray, depth_stride, M);
     if (int rc = validate_src(s)) return rc;
+    if (int rc = check_precision(precision)) return rc;
+    if (precision == 1) return sdf_nabla_bf16(blob, s, R_bg, sdf_out, nabla_out, h7_out, (hipStream_t)stream);
     return launch_chain(1, M, k_sdf_nabla, (unsigned)((M + 31) / 32), (hipStream_t)stream, blob, s, R_bg, sdf_out, nabla_out, h7_out);
 }
 
-int nerfart_radiance_fwd(const float* blob, int view_tiles, const float* pts, const float* view, long long M,
+int nerfart_radiance_fwd(const float* blob, int precision, int view_tiles, const float* pts, const float* view, long long M,
                          const float* nabla, const float* h7, float* rgb_out, void* stream) {
     if (int rc = check_M(M)) return rc;
     if (M == 0) return 0;
     if (!view) { set_last_error("radiance_fwd: view dirs required in pts mode"); return 2; }
     PointSrc s = make_src(pts, view, nullptr, nullptr, nullptr, nullptr, 1, 0, M);
     if (int rc = validate_src(s)) return rc;
+    if (int rc = check_precision(precision)) return rc;
+    if (precision == 1) return radiance_bf16(blob, view_tiles, s, nabla, h7, rgb_out, (hipStream_t)stream);
     const unsigned nt = (unsigned)((M + 127) / 128);
     if (view_tiles == 1) return launch_chain(2, M, k_radiance<1>, nt, (hipStream_t)stream, blob, s, nabla, h7, rgb_out);
     if (view_tiles == 3) return launch_chain(2, M, k_radiance<3>, nt, (hipStream_t)stream, blob, s, nabla, h7, rgb_out);
@@ -608,7 +507,7 @@ int nerfart_radiance_fwd(const float* blob, int view_tiles, const float* pts, co
     return 2;
 }
 
-int nerfart_radiance_fwd_rays(const float* blob, int view_tiles, const float* rays_o, const float* rays_d,
+int nerfart_radiance_fwd_rays(const float* blob, int precision, int view_tiles, const float* rays_o, const float* rays_d,
                               const int* ray_idx, const float* depth, int n_slots, int n_per_ray, int depth_stride,
                               const float* nabla, const float* h7, float* rgb_out, void* stream) {
     const long long M = (long long)n_slots * n_per_ray;
@@ -616,6 +515,8 @@ int nerfart_radiance_fwd_rays(const float* blob, int view_tiles, const float* ra
     if (M == 0) return 0;
     PointSrc s = make_src(nullptr, nullptr, rays_o, rays_d, ray_idx, depth, n_per_ray, depth_stride, M);
     if (int rc = validate_src(s)) return rc;
+    if (int rc = check_precision(precision)) return rc;
+    if (precision == 1) return radiance_bf16(blob, view_tiles, s, nabla, h7, rgb_out, (hipStream_t)stream);
     const unsigned nt = (unsigned)((M + 127) / 128);
     if (view_tiles == 1) return launch_chain(2, M, k_radiance<1>, nt, (hipStream_t)stream, blob, s, nabla, h7, rgb_out);
     if (view_tiles == 3) return launch_chain(2, M, k_radiance<3>, nt, (hipStream_t)stream, blob, s, nabla, h7, rgb_out);

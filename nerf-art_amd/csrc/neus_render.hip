@@ -166,9 +166,9 @@ using namespace nerfart;
 
 extern "C" {
 
-int nerfart_sdf_fwd_rays(const float*, const float*, const float*, const int*, const float*, int, int, int, float, float*, int, void*);
-int nerfart_sdf_nabla_fwd_rays(const float*, const float*, const float*, const int*, const float*, int, int, int, float, float*, float*, float*, void*);
-int nerfart_radiance_fwd_rays(const float*, int, const float*, const float*, const int*, const float*, int, int, int, const float*, const float*, float*, void*);
+int nerfart_sdf_fwd_rays(const float*, int, const float*, const float*, const int*, const float*, int, int, int, float, float*, int, void*);
+int nerfart_sdf_nabla_fwd_rays(const float*, int, const float*, const float*, const int*, const float*, int, int, int, float, float*, float*, float*, void*);
+int nerfart_radiance_fwd_rays(const float*, int, int, const float*, const float*, const int*, const float*, int, int, int, const float*, const float*, float*, void*);
 int nerfart_normalize_dirs(const float*, float*, int, void*);
 int nerfart_linspace_depths(const float*, int, const float*, const float*, float, float, int, float*, int, void*);
 void nerfart_linspace(float, float, int, float*);
@@ -258,7 +258,7 @@ long long nerfart_neus_render_workspace_bytes(int n_rays, int n_samples, int n_i
 // NeuS volume_render for one chunk of rays (upsample_algo = 'official_solution', N_outside = 0).
 // s = exp(ln_s * speed_factor).  Outputs as nerfart_volsdf_render_fwd; detailed outputs: d_all/sdf/cdf [R,P],
 // nabla [R,P,3], radiance/alpha/w/d_mid on the P-1 mid-points.
-int nerfart_neus_render_fwd(const float* surf_blob, const float* rad_blob, int view_tiles, const float* rays_o,
+int nerfart_neus_render_fwd(const float* surf_blob, const float* rad_blob, int precision, int view_tiles, const float* rays_o,
                             const float* rays_d, int n_rays, float obj_bounding_radius, float s, int n_samples,
                             int n_importance, int n_upsample_iters, int white_bkgd, int k3_rays_chunk,
                             const float* t_coarse_dev, const float* u_new_dev, float* rgb,
@@ -293,11 +293,11 @@ int nerfart_neus_render_fwd(const float* surf_blob, const float* rad_blob, int v
     if (int rc = nerfart_normalize_dirs(rays_d, w.rays_dn, n_rays, stream)) return rc;
     if (int rc = nerfart_near_far_from_sphere(rays_o, w.rays_dn, n_rays, obj_bounding_radius, w.near, w.far, stream)) return rc;
     if (int rc = nerfart_linspace_depths(w.t_coarse, n_samples, w.near, w.far, 0.f, 0.f, n_rays, w.d, P, stream)) return rc;
-    if (int rc = nerfart_sdf_fwd_rays(surf_blob, rays_o, w.rays_dn, nullptr, w.d, n_rays, n_samples, P, 0.f, w.s, P, stream)) return rc;
+    if (int rc = nerfart_sdf_fwd_rays(surf_blob, precision, rays_o, w.rays_dn, nullptr, w.d, n_rays, n_samples, P, 0.f, w.s, P, stream)) return rc;
     int n = n_samples;
     for (int i = 0; i < n_upsample_iters; ++i) {
         if (int rc = nerfart_neus_upsample_step(n_rays, n, P, n_new, 64.f * (float)(1 << i), w.d, w.s, w.u_new, w.d_new, stream)) return rc;
-        if (int rc = nerfart_sdf_fwd_rays(surf_blob, rays_o, w.rays_dn, nullptr, w.d_new, n_rays, n_new, n_new, 0.f, w.s_new, n_new, stream)) return rc;
+        if (int rc = nerfart_sdf_fwd_rays(surf_blob, precision, rays_o, w.rays_dn, nullptr, w.d_new, n_rays, n_new, n_new, 0.f, w.s_new, n_new, stream)) return rc;
         if (int rc = nerfart_merge_sorted_pairs(n_rays, n, P, n_new, w.d, w.s, w.d_new, w.s_new, stream)) return rc;
         n += n_new;
     }
@@ -308,14 +308,14 @@ int nerfart_neus_render_fwd(const float* surf_blob, const float* rad_blob, int v
     }
     if (d_all_out) NERFART_HIP(hipMemcpyAsync(d_all_out, w.d, sizeof(float) * (size_t)n_rays * P, hipMemcpyDeviceToDevice, stream));
     // sdf + nablas at the P sample points (neus.py:320)
-    if (int rc = nerfart_sdf_nabla_fwd_rays(surf_blob, rays_o, w.rays_dn, nullptr, w.d, n_rays, P, P, 0.f, sdf, nabla, nullptr, stream)) return rc;
+    if (int rc = nerfart_sdf_nabla_fwd_rays(surf_blob, precision, rays_o, w.rays_dn, nullptr, w.d, n_rays, P, P, 0.f, sdf, nabla, nullptr, stream)) return rc;
     // radiance at the P-1 mid-points, with their own nablas (neus.py:324 -> forward_radiance :111-114)
     for (int c0 = 0; c0 < n_rays; c0 += k3_rays_chunk) {
         const int rk = (n_rays - c0 < k3_rays_chunk) ? n_rays - c0 : k3_rays_chunk;
         const size_t po = (size_t)c0 * (P - 1);
-        if (int rc = nerfart_sdf_nabla_fwd_rays(surf_blob, rays_o + 3 * (size_t)c0, w.rays_dn + 3 * (size_t)c0, nullptr,
+        if (int rc = nerfart_sdf_nabla_fwd_rays(surf_blob, precision, rays_o + 3 * (size_t)c0, w.rays_dn + 3 * (size_t)c0, nullptr,
                                                 w.d_mid + po, rk, P - 1, P - 1, 0.f, w.sdf_mid, w.nabla_mid, w.h7, stream)) return rc;
-        if (int rc = nerfart_radiance_fwd_rays(rad_blob, view_tiles, rays_o + 3 * (size_t)c0, w.rays_dn + 3 * (size_t)c0, nullptr,
+        if (int rc = nerfart_radiance_fwd_rays(rad_blob, precision, view_tiles, rays_o + 3 * (size_t)c0, w.rays_dn + 3 * (size_t)c0, nullptr,
                                                w.d_mid + po, rk, P - 1, P - 1, w.nabla_mid, w.h7, rad + 3 * po, stream)) return rc;
     }
     return nerfart_neus_composite(n_rays, P, w.d, sdf, rad, nabla, s, white_bkgd, rgb, depth, acc, normals, cdf_out,

@@ -275,9 +275,9 @@ using namespace nerfart;
 extern "C" {
 
 // ---- forward declarations of the MLP entry points (mlp_chain.hip) ---------------------
-int nerfart_sdf_fwd_rays(const float*, const float*, const float*, const int*, const float*, int, int, int, float, float*, int, void*);
-int nerfart_sdf_nabla_fwd_rays(const float*, const float*, const float*, const int*, const float*, int, int, int, float, float*, float*, float*, void*);
-int nerfart_radiance_fwd_rays(const float*, int, const float*, const float*, const int*, const float*, int, int, int, const float*, const float*, float*, void*);
+int nerfart_sdf_fwd_rays(const float*, int, const float*, const float*, const int*, const float*, int, int, int, float, float*, int, void*);
+int nerfart_sdf_nabla_fwd_rays(const float*, int, const float*, const float*, const int*, const float*, int, int, int, float, float*, float*, float*, void*);
+int nerfart_radiance_fwd_rays(const float*, int, int, const float*, const float*, const int*, const float*, int, int, int, const float*, const float*, float*, void*);
 
 // torch.linspace(start, end, n) in fp32: step = (end-start)/(n-1); the first half counts up from
 // start, the second half down from end (ATen RangeFactories linspace kernel).  Host helper.
@@ -427,7 +427,7 @@ long long nerfart_volsdf_sampler_workspace_bytes(int n_rays, int n_init, int n_u
 // fine_sample (volsdf.py:97-302) for n_rays rays with already normalised directions.
 //   near/far: per-ray device arrays or nullptr + scalars.  Outputs: d_fine [R, n_final],
 //   beta_map [R], iter_usage [R] (float: 0..max_iter, -1 = never converged).
-int nerfart_volsdf_fine_sample(const float* surf_blob, const float* rays_o, const float* rays_dn, int n_rays,
+int nerfart_volsdf_fine_sample(const float* surf_blob, int precision, const float* rays_o, const float* rays_dn, int n_rays,
                                const float* near, const float* far, float near_s, float far_s, float R_bg,
                                float alpha_net, float beta_net, float eps, int n_init, int n_up, int n_final,
                                int max_iter, int max_bisect, const float* t_init_dev, const float* u_up_dev,
@@ -458,7 +458,7 @@ int nerfart_volsdf_fine_sample(const float* surf_blob, const float* rays_o, cons
         NERFART_HIP(e1); NERFART_HIP(e2); NERFART_HIP(e3); NERFART_HIP(e4);
     }
     if (int rc = nerfart_linspace_depths(w.t_init, n_init, near, far, near_s, far_s, n_rays, w.dA, cap, stream)) return rc;
-    if (int rc = nerfart_sdf_fwd_rays(surf_blob, rays_o, rays_dn, nullptr, w.dA, n_rays, n_init, cap, R_bg, w.sA, cap, stream)) return rc;
+    if (int rc = nerfart_sdf_fwd_rays(surf_blob, precision, rays_o, rays_dn, nullptr, w.dA, n_rays, n_init, cap, R_bg, w.sA, cap, stream)) return rc;
     NERFART_HIP(hipMemsetAsync(w.count, 0, 256, stream));
     const float denom = (float)(4.0 * (double)(n_init - 1) * log(1.0 + (double)eps));     // volsdf.py:149
     if (int rc = nerfart_volsdf_first_check(n_rays, n_init, cap, n_final, eps, alpha_net, beta_net, w.dA, w.sA, w.u_final,
@@ -472,7 +472,7 @@ int nerfart_volsdf_fine_sample(const float* surf_blob, const float* rays_o, cons
     int n = n_init;
     for (int it = 1; it <= max_iter && n_act > 0; ++it) {
         if (int rc = nerfart_volsdf_upsample(n_act, n, cap, n_up, dA, sA, act, w.beta_plus, w.u_up, it > 1, w.d_new, stream)) return rc;
-        if (int rc = nerfart_sdf_fwd_rays(surf_blob, rays_o, rays_dn, act, w.d_new, n_act, n_up, n_up, R_bg, w.s_new, n_up, stream)) return rc;
+        if (int rc = nerfart_sdf_fwd_rays(surf_blob, precision, rays_o, rays_dn, act, w.d_new, n_act, n_up, n_up, R_bg, w.s_new, n_up, stream)) return rc;
         NERFART_HIP(hipMemsetAsync(w.count + it, 0, sizeof(int), stream));
         if (int rc = nerfart_volsdf_merge_check(n_act, n, cap, n_up, n_final, max_bisect, it, eps, alpha_net, beta_net, dA, sA,
                                                 dB, sB, act, w.d_new, w.s_new, w.u_final, d_fine, w.beta_plus, beta_map,
@@ -530,7 +530,7 @@ long long nerfart_volsdf_render_workspace_bytes(int n_rays, int n_samples, int n
 // Renders n_rays rays (rays_d un-normalised, as get_rays returns them).  Outputs rgb [R,3], depth [R],
 // acc [R] always; every other output pointer may be null:  normals [R,3]; detailed per-sample
 // arrays d_all/sdf/sigma [R,P], nabla/radiance [R,P,3], p_i/tau [R,P-1]; beta_map/iter_usage [R].
-int nerfart_volsdf_render_fwd(const float* surf_blob, const float* rad_blob, int view_tiles, const float* rays_o,
+int nerfart_volsdf_render_fwd(const float* surf_blob, const float* rad_blob, int precision, int view_tiles, const float* rays_o,
                               const float* rays_d, int n_rays, float near_s, float far_s, float R_bg, float alpha,
                               float beta, float eps, int n_samples, int n_importance, int max_upsample_steps,
                               int max_bisection_steps, int white_bkgd, int k3_rays_chunk, const float* t_coarse_dev,
@@ -553,7 +553,7 @@ int nerfart_volsdf_render_fwd(const float* surf_blob, const float* rad_blob, int
     float* iter_usage = iter_usage_out ? iter_usage_out : w.iter_usage;
 
     if (int rc = nerfart_normalize_dirs(rays_d, w.rays_dn, n_rays, stream)) return rc;
-    if (int rc = nerfart_volsdf_fine_sample(surf_blob, rays_o, w.rays_dn, n_rays, nullptr, nullptr, near_s, far_s, R_bg,
+    if (int rc = nerfart_volsdf_fine_sample(surf_blob, precision, rays_o, w.rays_dn, n_rays, nullptr, nullptr, near_s, far_s, R_bg,
                                             alpha, beta, eps, 4 * n_samples, 4 * n_samples, n_importance,
                                             max_upsample_steps, max_bisection_steps, t_init_dev, u_up_dev, u_final_dev,
                                             w.d_fine, beta_map, iter_usage, w.sampler, (long long)w.sampler_bytes, stream)) return rc;
@@ -573,9 +573,9 @@ int nerfart_volsdf_render_fwd(const float* surf_blob, const float* rad_blob, int
     for (int c0 = 0; c0 < n_rays; c0 += k3_rays_chunk) {
         const int rk = (n_rays - c0 < k3_rays_chunk) ? n_rays - c0 : k3_rays_chunk;
         const size_t po = (size_t)c0 * P;
-        if (int rc = nerfart_sdf_nabla_fwd_rays(surf_blob, rays_o + 3 * (size_t)c0, w.rays_dn + 3 * (size_t)c0, nullptr,
+        if (int rc = nerfart_sdf_nabla_fwd_rays(surf_blob, precision, rays_o + 3 * (size_t)c0, w.rays_dn + 3 * (size_t)c0, nullptr,
                                                 d_all + po, rk, P, P, R_bg, sdf + po, nabla + 3 * po, w.h7, stream)) return rc;
-        if (int rc = nerfart_radiance_fwd_rays(rad_blob, view_tiles, rays_o + 3 * (size_t)c0, w.rays_dn + 3 * (size_t)c0,
+        if (int rc = nerfart_radiance_fwd_rays(rad_blob, precision, view_tiles, rays_o + 3 * (size_t)c0, w.rays_dn + 3 * (size_t)c0,
                                                nullptr, d_all + po, rk, P, P, nabla + 3 * po, w.h7, rad + 3 * po, stream)) return rc;
     }
     return nerfart_volsdf_composite(n_rays, P, d_all, sdf, rad, nabla, alpha, beta, white_bkgd, rgb, depth, acc, normals,

@@ -29,12 +29,12 @@ _SIGS = {
     "nerfart_linspace": (None, [_f, _f, _i, _p]),
     "nerfart_profile_begin": (_i, []),
     "nerfart_profile_end": (_i, [_p, _p, _p]),
-    "nerfart_sdf_fwd": (_i, [_p, _p, _ll, _f, _p, _p]),
-    "nerfart_sdf_fwd_rays": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _i, _p]),
-    "nerfart_sdf_nabla_fwd": (_i, [_p, _p, _ll, _f, _p, _p, _p, _p]),
-    "nerfart_sdf_nabla_fwd_rays": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p]),
-    "nerfart_radiance_fwd": (_i, [_p, _i, _p, _p, _ll, _p, _p, _p, _p]),
-    "nerfart_radiance_fwd_rays": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
+    "nerfart_sdf_fwd": (_i, [_p, _i, _p, _ll, _f, _p, _p]),
+    "nerfart_sdf_fwd_rays": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _f, _p, _i, _p]),
+    "nerfart_sdf_nabla_fwd": (_i, [_p, _i, _p, _ll, _f, _p, _p, _p, _p]),
+    "nerfart_sdf_nabla_fwd_rays": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p]),
+    "nerfart_radiance_fwd": (_i, [_p, _i, _i, _p, _p, _ll, _p, _p, _p, _p]),
+    "nerfart_radiance_fwd_rays": (_i, [_p, _i, _i, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "nerfart_get_rays": (_i, [_p, _p, _i, _i, _p, _i, _p, _p, _p]),
     "nerfart_normalize_dirs": (_i, [_p, _p, _i, _p]),
     "nerfart_linspace_depths": (_i, [_p, _i, _p, _p, _f, _f, _i, _p, _i, _p]),
@@ -43,17 +43,17 @@ _SIGS = {
     "nerfart_volsdf_merge_check": (_i, [_i, _i, _i, _i, _i, _i, _i, _f, _f, _f] + [_p] * 15),
     "nerfart_volsdf_finalize": (_i, [_i, _i, _i, _i] + [_p] * 9),
     "nerfart_volsdf_sampler_workspace_bytes": (_ll, [_i, _i, _i, _i, _i]),
-    "nerfart_volsdf_fine_sample": (_i, [_p, _p, _p, _i, _p, _p, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _ll, _p]),
+    "nerfart_volsdf_fine_sample": (_i, [_p, _i, _p, _p, _i, _p, _p, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _ll, _p]),
     "nerfart_sort_concat": (_i, [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p]),
     "nerfart_volsdf_composite": (_i, [_i, _i, _p, _p, _p, _p, _f, _f, _i] + [_p] * 8),
     "nerfart_volsdf_render_workspace_bytes": (_ll, [_i, _i, _i, _i, _i]),
-    "nerfart_volsdf_render_fwd": (_i, [_p, _p, _i, _p, _p, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i] + [_p] * 4 + [_p] * 13 + [_p, _ll, _p]),
+    "nerfart_volsdf_render_fwd": (_i, [_p, _p, _i, _i, _p, _p, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i] + [_p] * 4 + [_p] * 13 + [_p, _ll, _p]),
     "nerfart_near_far_from_sphere": (_i, [_p, _p, _i, _f, _p, _p, _p]),
     "nerfart_neus_upsample_step": (_i, [_i, _i, _i, _i, _f, _p, _p, _p, _p, _p]),
     "nerfart_merge_sorted_pairs": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "nerfart_neus_composite": (_i, [_i, _i, _p, _p, _p, _p, _f, _i] + [_p] * 9),
     "nerfart_neus_render_workspace_bytes": (_ll, [_i, _i, _i, _i]),
-    "nerfart_neus_render_fwd": (_i, [_p, _p, _i, _p, _p, _i, _f, _f, _i, _i, _i, _i, _i] + [_p] * 2 + [_p] * 12 + [_p, _ll, _p]),
+    "nerfart_neus_render_fwd": (_i, [_p, _p, _i, _i, _p, _p, _i, _f, _f, _i, _i, _i, _i, _i] + [_p] * 2 + [_p] * 12 + [_p, _ll, _p]),
 }
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)          # AttributeError here = header / library mismatch
@@ -106,39 +106,42 @@ def profile_end():
 
 
 # ---- point queries -----------------------------------------------------------------------
-def sdf_fwd(surf_blob, pts, R_bg: float):
+PRECISIONS = {"fp32": 0, "bf16x3": 1}
+
+
+def sdf_fwd(surf_blob, pts, R_bg: float, precision: int = 0):
     M = pts.shape[0]
     out = torch.empty(M, dtype=torch.float32, device=pts.device)
-    _check(lib.nerfart_sdf_fwd(_dev(surf_blob, name="surf_blob"), _dev(pts, name="pts"), M, float(R_bg), _dev(out), _stream()),
+    _check(lib.nerfart_sdf_fwd(_dev(surf_blob, name="surf_blob"), int(precision), _dev(pts, name="pts"), M, float(R_bg), _dev(out), _stream()),
            "nerfart_sdf_fwd")
     return out
 
 
-def sdf_nabla_fwd(surf_blob, pts, R_bg: float, want_h7: bool = True):
+def sdf_nabla_fwd(surf_blob, pts, R_bg: float, want_h7: bool = True, precision: int = 0):
     M = pts.shape[0]
     sdf = torch.empty(M, dtype=torch.float32, device=pts.device)
     nab = torch.empty(M, 3, dtype=torch.float32, device=pts.device)
     h7 = torch.empty(M, 256, dtype=torch.float32, device=pts.device) if want_h7 else None
-    _check(lib.nerfart_sdf_nabla_fwd(_dev(surf_blob), _dev(pts, name="pts"), M, float(R_bg), _dev(sdf), _dev(nab),
+    _check(lib.nerfart_sdf_nabla_fwd(_dev(surf_blob), int(precision), _dev(pts, name="pts"), M, float(R_bg), _dev(sdf), _dev(nab),
                                      _dev(h7), _stream()), "nerfart_sdf_nabla_fwd")
     return sdf, nab, h7
 
 
-def radiance_fwd(rad_blob, view_tiles: int, pts, view, nabla, h7):
+def radiance_fwd(rad_blob, view_tiles: int, pts, view, nabla, h7, precision: int = 0):
     M = pts.shape[0]
     rgb = torch.empty(M, 3, dtype=torch.float32, device=pts.device)
-    _check(lib.nerfart_radiance_fwd(_dev(rad_blob), int(view_tiles), _dev(pts, name="pts"), _dev(view, name="view"), M,
+    _check(lib.nerfart_radiance_fwd(_dev(rad_blob), int(precision), int(view_tiles), _dev(pts, name="pts"), _dev(view, name="view"), M,
                                     _dev(nabla, name="nabla"), _dev(h7, name="h7"), _dev(rgb), _stream()),
            "nerfart_radiance_fwd")
     return rgb
 
 
-def sdf_fwd_rays(surf_blob, rays_o, rays_dn, depth, R_bg: float, ray_idx=None, n_per_ray=None):
+def sdf_fwd_rays(surf_blob, rays_o, rays_dn, depth, R_bg: float, ray_idx=None, n_per_ray=None, precision: int = 0):
     """depth [n_slots, stride >= n_per_ray] -> sdf [n_slots, n_per_ray]"""
     n_slots, stride = depth.shape
     n_per_ray = stride if n_per_ray is None else n_per_ray
     out = torch.empty(n_slots, n_per_ray, dtype=torch.float32, device=depth.device)
-    _check(lib.nerfart_sdf_fwd_rays(_dev(surf_blob), _dev(rays_o), _dev(rays_dn), _dev(ray_idx, torch.int32),
+    _check(lib.nerfart_sdf_fwd_rays(_dev(surf_blob), int(precision), _dev(rays_o), _dev(rays_dn), _dev(ray_idx, torch.int32),
                                     _dev(depth), n_slots, n_per_ray, stride, float(R_bg), _dev(out), n_per_ray, _stream()),
            "nerfart_sdf_fwd_rays")
     return out
@@ -186,7 +189,7 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 
 def volsdf_fine_sample(surf_blob, rays_o, rays_dn, near: float, far: float, R_bg: float, alpha: float, beta: float,
-                       eps: float, n_init: int, n_up: int, n_final: int, max_iter: int, max_bisect: int):
+                       eps: float, n_init: int, n_up: int, n_final: int, max_iter: int, max_bisect: int, precision: int = 0):
     R = rays_o.shape[0]
     dev = rays_o.device
     d_fine = torch.empty(R, n_final, dtype=torch.float32, device=dev)
@@ -194,7 +197,7 @@ def volsdf_fine_sample(surf_blob, rays_o, rays_dn, near: float, far: float, R_bg
     usage = torch.empty(R, dtype=torch.float32, device=dev)
     nb = lib.nerfart_volsdf_sampler_workspace_bytes(R, n_init, n_up, n_final, max_iter)
     ws = _workspace(nb, dev)
-    _check(lib.nerfart_volsdf_fine_sample(_dev(surf_blob), _dev(rays_o), _dev(rays_dn), R, None, None, float(near), float(far),
+    _check(lib.nerfart_volsdf_fine_sample(_dev(surf_blob), int(precision), _dev(rays_o), _dev(rays_dn), R, None, None, float(near), float(far),
                                           float(R_bg), float(alpha), float(beta), float(eps), n_init, n_up, n_final, max_iter,
                                           max_bisect, _dev(lin_table(n_init, dev)), _dev(lin_table(n_up + 2, dev)),
                                           _dev(lin_table(n_final, dev)), _dev(d_fine), _dev(beta_map), _dev(usage), ws.data_ptr(), ws.numel(),
@@ -204,7 +207,7 @@ def volsdf_fine_sample(surf_blob, rays_o, rays_dn, near: float, far: float, R_bg
 
 def volsdf_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, near, far, R_bg, alpha, beta, eps=0.1,
                   n_samples=128, n_importance=64, max_upsample_steps=5, max_bisection_steps=10, white_bkgd=False,
-                  calc_normal=True, detailed=False, k3_rays_chunk=8192):
+                  calc_normal=True, detailed=False, k3_rays_chunk=8192, precision=0):
     """One chunk of rays through nerfart_volsdf_render_fwd.  Returns a dict of flat [R, ...] tensors."""
     R = rays_o.shape[0]
     dev = rays_o.device
@@ -221,7 +224,7 @@ def volsdf_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, near, far,
     ws = _workspace(nb, dev)
     g = lambda k: _dev(det.get(k))
     _check(lib.nerfart_volsdf_render_fwd(
-        _dev(surf_blob), _dev(rad_blob), int(view_tiles), _dev(rays_o, name="rays_o"), _dev(rays_d, name="rays_d"), R,
+        _dev(surf_blob), _dev(rad_blob), int(precision), int(view_tiles), _dev(rays_o, name="rays_o"), _dev(rays_d, name="rays_d"), R,
         float(near), float(far), float(R_bg), float(alpha), float(beta), float(eps), n_samples, n_importance,
         max_upsample_steps, max_bisection_steps, int(bool(white_bkgd)), k3_rays_chunk,
         _dev(lin_table(n_samples, dev)), _dev(lin_table(4 * n_samples, dev)), _dev(lin_table(4 * n_samples + 2, dev)),
@@ -235,7 +238,7 @@ def volsdf_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, near, far,
 
 
 def neus_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, obj_bounding_radius, s, n_samples=64, n_importance=64,
-                n_upsample_iters=4, white_bkgd=False, calc_normal=True, detailed=False, k3_rays_chunk=8192):
+                n_upsample_iters=4, white_bkgd=False, calc_normal=True, detailed=False, k3_rays_chunk=8192, precision=0):
     R = rays_o.shape[0]
     dev = rays_o.device
     P = n_samples + n_importance
@@ -251,7 +254,7 @@ def neus_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, obj_bounding
     ws = _workspace(nb, dev)
     g = lambda k: _dev(det.get(k))
     _check(lib.nerfart_neus_render_fwd(
-        _dev(surf_blob), _dev(rad_blob), int(view_tiles), _dev(rays_o, name="rays_o"), _dev(rays_d, name="rays_d"), R,
+        _dev(surf_blob), _dev(rad_blob), int(precision), int(view_tiles), _dev(rays_o, name="rays_o"), _dev(rays_d, name="rays_d"), R,
         float(obj_bounding_radius), float(s), n_samples, n_importance, n_upsample_iters, int(bool(white_bkgd)), k3_rays_chunk,
         _dev(lin_table(n_samples, dev)), _dev(lin_table(n_importance // n_upsample_iters, dev)),
         _dev(out["rgb"]), _dev(out["depth_volume"]), _dev(out["mask_volume"]), _dev(out.get("normals_volume")),

@@ -112,16 +112,41 @@ class _PackedModel(nn.Module):
 
     def _init_packing(self):
         s, r = self.implicit_surface, self.radiance_net
-        self._surf_plan = packing.surface_plan(s.W, s.D, tuple(s.skips), s.embed_multires, s.W_geo_feat)
         if r.embed_multires != -1 or r.embed_multires_view not in (-1, 4):
             raise NotImplementedError("radiance embed_multires must be -1 and embed_multires_view in (-1, 4)")
         self.view_tiles = 1 if r.embed_multires_view == -1 else 3
-        self._rad_plan = packing.radiance_plan(self.view_tiles, r.W, r.D, s.W_geo_feat)
+        self._plans = {}
         self._blobs = None
         self._blob_key = None
+        self.precision = "fp32"
+
+    def set_precision(self, precision: str):
+        """'fp32'  : v_mfma_f32_16x16x4_f32, exact fp32 FMA chains (157 TFLOP/s peak);
+        'bf16x3': operands split hi+lo in bf16, 3 x v_mfma_f32_32x32x16_bf16 per k-step, fp32 accumulate
+                  (~2^-16 relative per product, 5.3x the fp32 MFMA rate)."""
+        if precision not in hip.PRECISIONS:
+            raise ValueError(f"precision must be one of {list(hip.PRECISIONS)}")
+        self.precision = precision
+        self._blobs = None
+        return self
+
+    @property
+    def precision_id(self) -> int:
+        return hip.PRECISIONS[self.precision]
+
+    def _get_plans(self):
+        if self.precision not in self._plans:
+            s, r = self.implicit_surface, self.radiance_net
+            if self.precision == "fp32":
+                self._plans[self.precision] = (packing.surface_plan(s.W, s.D, tuple(s.skips), s.embed_multires, s.W_geo_feat),
+                                               packing.radiance_plan(self.view_tiles, r.W, r.D, s.W_geo_feat))
+            else:
+                self._plans[self.precision] = (packing.surface_plan_bf16(s.W, s.D, tuple(s.skips), s.embed_multires, s.W_geo_feat),
+                                               packing.radiance_plan_bf16(self.view_tiles, r.W, r.D, s.W_geo_feat))
+        return self._plans[self.precision]
 
     def _param_key(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (self.precision,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def packed(self):
         """(surface_blob, radiance_blob) for the current parameters; re-packed only after an
@@ -130,10 +155,10 @@ class _PackedModel(nn.Module):
         key = self._param_key()
         if self._blobs is None or key != self._blob_key:
             sd = {k: v.detach() for k, v in self.state_dict().items()}
+            sp, rp = self._get_plans()
             with torch.no_grad():
-                self._blobs = (self._surf_plan.pack(packing.surface_tensors(sd, D=self.implicit_surface.D)),
-                               self._rad_plan.pack(packing.radiance_tensors(sd, D_surf=self.implicit_surface.D,
-                                                                            D=self.radiance_net.D)))
+                self._blobs = (sp.pack(packing.surface_tensors(sd, D=self.implicit_surface.D)),
+                               rp.pack(packing.radiance_tensors(sd, D_surf=self.implicit_surface.D, D=self.radiance_net.D)))
             self._blob_key = key
         return self._blobs
 
@@ -145,15 +170,15 @@ class _PackedModel(nn.Module):
         blob, _ = self.packed()
         xf = self._flat(x)
         if with_nablas:
-            sdf, nab, h7 = hip.sdf_nabla_fwd(blob, xf, R_bg, want_h7=want_h7)
+            sdf, nab, h7 = hip.sdf_nabla_fwd(blob, xf, R_bg, want_h7=want_h7, precision=self.precision_id)
             return sdf.reshape(x.shape[:-1]), nab.reshape(x.shape), h7
-        sdf = hip.sdf_fwd(blob, xf, R_bg)
+        sdf = hip.sdf_fwd(blob, xf, R_bg, precision=self.precision_id)
         return sdf.reshape(x.shape[:-1])
 
     def _radiance_query(self, x, view_dirs, nablas, h7):
         _, rblob = self.packed()
         rgb = hip.radiance_fwd(rblob, self.view_tiles, self._flat(x), self._flat(view_dirs),
-                               self._flat(nablas), h7)
+                               self._flat(nablas), h7, precision=self.precision_id)
         return rgb.reshape(x.shape)
 
 

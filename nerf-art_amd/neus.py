@@ -43,7 +43,7 @@ def volume_render(rays_o, rays_d, model: NeuS, obj_bounding_radius=1.0, batched=
             surf_blob, rad_blob, model.view_tiles, ro[i:i + chunk], rd[i:i + chunk],
             obj_bounding_radius=obj_bounding_radius, s=s, n_samples=N_samples, n_importance=N_importance,
             n_upsample_iters=N_upsample_iters, white_bkgd=white_bkgd, calc_normal=calc_normal,
-            detailed=detailed_output, k3_rays_chunk=k3_rays_chunk))
+            detailed=detailed_output, k3_rays_chunk=k3_rays_chunk, precision=model.precision_id))
     ret = OrderedDict()
     for k in ["rgb", "depth_volume", "mask_volume", "normals_volume", "implicit_nablas", "implicit_surface", "radiance",
               "alpha", "cdf", "visibility_weights", "d_final"]:

@@ -233,6 +233,173 @@ def radiance_plan(view_tiles: int, W: int = 256, D: int = 4, W_geo_feat: int = 2
     return PackPlan(PROG_RADIANCE, flat, chunks, aux)
 
 
+# ----------------------------------------------------------------------------------------------------
+# split-bf16 ("bf16x3") programs for csrc/mlp_chain_bf16.hip
+# ----------------------------------------------------------------------------------------------------
+PROG_SURFACE_BF16 = 3
+PROG_RADIANCE_BF16 = 4
+KS_FLOATS = 512           # one k-step of a chunk: (hi, lo) x 64 lanes x 8 bf16 = 2 KiB
+
+
+def unit_feature_hidden(ks: int, h: int, e: int) -> int:
+    """Slot (k-step ks, lane half h, element e) of a hidden-layer input -> feature index.  The C layout of
+    v_mfma_f32_32x32x16_bf16 puts row (r&3) + 8(r>>2) + 4h in register r; registers 8u..8u+7 of output tile T
+    are unit 2T+u of the next layer."""
+    T, u = ks >> 1, ks & 1
+    r = 8 * u + e
+    return 32 * T + (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+def unit_feature_enc(q: int, h: int, e: int) -> int:
+    """Slot of the 3 positional-encoding units -> reference feature (0..38) or -1: half 0 holds features 0..20
+    (x, y, z, bands 0..2), half 1 features 21..38 (bands 3..5), both in the reference's own order."""
+    m = 8 * q + e
+    if h == 0:
+        return m if m < 21 else -1
+    return 21 + m if m < 18 else -1
+
+
+def unit_feature_extra(q: int, h: int, e: int, n_extra: int) -> int:
+    m = 16 * q + 8 * h + e
+    return m if m < n_extra else -1
+
+
+def _tile_chunk_index(flat, name, out_dim, To, cols_fn, nk):
+    """Index array [nk][lane=64][e=8] for output tile To: W[32 To + i][cols_fn(ks, h, e)]."""
+    R, C = flat.shape[name]
+    idx = np.full((nk, 64, 8), flat.zero, dtype=np.int64)
+    for ks in range(nk):
+        for h in range(2):
+            for e in range(8):
+                c = cols_fn(ks, h, e)
+                if c < 0:
+                    continue
+                rows = 32 * To + np.arange(32)
+                ok = rows < out_dim
+                lanes = 32 * h + np.arange(32)
+                idx[ks, lanes[ok], e] = flat.base[name] + rows[ok] * C + c
+    return idx.reshape(-1)
+
+
+class PackPlanBF16(PackPlan):
+    """Chunks hold bf16 hi/lo fragments: float[ks][term=2][lane=64][4] (= 8 bf16 per lane)."""
+
+    def __init__(self, prog, flat, chunk_indices, aux):
+        self.prog, self.flat = prog, flat
+        offs = [HDR_INTS]
+        for c in chunk_indices:
+            offs.append(offs[-1] + (len(c) // 512) * KS_FLOATS)
+        self.nc = len(chunk_indices)
+        assert self.nc + 1 <= 128
+        self.aux_off = offs[-1]
+        self.cindex = np.concatenate(chunk_indices)
+        self.aindex = aux
+        self.total = self.aux_off + len(aux)
+        hdr = np.zeros(HDR_INTS, dtype=np.int32)
+        hdr[0], hdr[1], hdr[2], hdr[3], hdr[4], hdr[5] = MAGIC, prog, self.nc, self.total, self.aux_off, len(aux)
+        hdr[HDR_OFFS: HDR_OFFS + self.nc + 1] = offs
+        self.header = hdr
+        self._index_t = {}
+
+    def pack(self, tensors: dict) -> torch.Tensor:
+        dev = tensors[self.flat.names[0]].device
+        parts = [tensors[n].detach().reshape(-1).to(torch.float32) for n in self.flat.names]
+        for n in self.flat.names:
+            assert tuple(tensors[n].shape) == self.flat.shape[n], n
+        parts.append(torch.zeros(1, dtype=torch.float32, device=dev))
+        src = torch.cat(parts)
+        key = str(dev)
+        if key not in self._index_t:
+            self._index_t[key] = (torch.from_numpy(self.cindex).to(dev), torch.from_numpy(self.aindex).to(dev))
+        ci, ai = self._index_t[key]
+        w = src[ci].reshape(-1, 64, 8)                        # [k-steps of all chunks, lane, e]
+        hi = w.to(torch.bfloat16)                             # round-to-nearest-even
+        lo = (w - hi.to(torch.float32)).to(torch.bfloat16)
+        body = torch.stack([hi, lo], dim=1).contiguous().view(torch.float32).reshape(-1)   # [ks][term][lane][4]
+        hdr = torch.from_numpy(self.header.copy()).view(torch.float32).to(dev)
+        return torch.cat([hdr, body, src[ai]]).contiguous()
+
+
+def surface_plan_bf16(W: int = 256, D: int = 8, skips=(4,), multires: int = 6, W_geo_feat: int = 256) -> PackPlanBF16:
+    if not (W == 256 and D == 8 and tuple(skips) == (4,) and multires == 6 and W_geo_feat == 256):
+        raise NotImplementedError("gfx950 surface kernels are built for W=256, D=8, skips=[4], embed_multires=6, W_geo_feat=256")
+    enc = 39
+    flat = _Flat()
+    dims = []
+    for l in range(D + 1):
+        out_dim = (1 + W_geo_feat) if l == D else (W - enc if (l + 1) in skips else W)
+        in_dim = enc if l == 0 else W
+        dims.append((out_dim, in_dim))
+        flat.add(f"w{l}", (out_dim, in_dim)); flat.add(f"b{l}", (out_dim,))
+    hw = W - enc
+    chunks = []
+    for l in range(D):
+        out_dim, in_dim = dims[l]
+        if l == 0:
+            nk, fn = 3, (lambda ks, h, e: unit_feature_enc(ks, h, e))
+        elif l in skips:
+            def fn(ks, h, e, hw=hw):
+                if ks < 14:
+                    f = unit_feature_hidden(ks, h, e)
+                    return f if f < hw else -1
+                f = unit_feature_enc(ks - 14, h, e)
+                return hw + f if f >= 0 else -1
+            nk = 17
+        else:
+            def fn(ks, h, e, in_dim=in_dim):
+                f = unit_feature_hidden(ks, h, e)
+                return f if f < in_dim else -1
+            nk = 16
+        ntiles = (out_dim + 31) // 32
+        for To in range(ntiles):
+            chunks.append(_tile_chunk_index(flat, f"w{l}", out_dim, To, fn, nk))
+    ar = np.arange
+    aux = [flat.vec_index(f"b{l}", _pad(ar(dims[l][0]), 256)) for l in range(D)]
+    aux.append(flat.mat_index(f"w{D}", np.array([0]), ar(256)).reshape(-1))
+    aux.append(flat.vec_index(f"b{D}", _pad(np.array([0]), 4)))
+    aux = np.concatenate(aux)
+    assert len(aux) == SURF_AUX_FLOATS
+    return PackPlanBF16(PROG_SURFACE_BF16, flat, chunks, aux)
+
+
+def radiance_plan_bf16(view_tiles: int, W: int = 256, D: int = 4, W_geo_feat: int = 256) -> PackPlanBF16:
+    if not (W == 256 and D == 4 and W_geo_feat == 256 and view_tiles in (1, 3)):
+        raise NotImplementedError("gfx950 radiance kernel is built for W=256, D=4, W_geo_feat=256")
+    n_extra = 9 if view_tiles == 1 else 33
+    flat = _Flat()
+    flat.add("w8", (1 + W_geo_feat, 256)); flat.add("b8", (1 + W_geo_feat,))
+    in0 = n_extra + W_geo_feat
+    rdims = [(W, in0)] + [(W, W)] * (D - 1) + [(3, W)]
+    for l, (o, i) in enumerate(rdims):
+        flat.add(f"r{l}", (o, i)); flat.add(f"rb{l}", (o,))
+    chunks = []
+    # layer A: feat = W8[1:257] h7: rows 1.. of w8 (index the 256 rows, then shift by one row = 256 entries)
+    for To in range(8):
+        idx = _tile_chunk_index(flat, "w8", 1 + W_geo_feat - 1, To, unit_feature_hidden, 16)
+        # shift rows by one (row 32To+i of the layer = row 1+32To+i of w8)
+        idx = np.where(idx == flat.zero, idx, idx + 256)
+        chunks.append(idx)
+
+    def fn0(ks, h, e):
+        if ks < 16:
+            return n_extra + unit_feature_hidden(ks, h, e)
+        return unit_feature_extra(ks - 16, h, e, n_extra)
+    for To in range(8):
+        chunks.append(_tile_chunk_index(flat, "r0", W, To, fn0, 16 + view_tiles))
+    for l in range(1, D):
+        for To in range(8):
+            chunks.append(_tile_chunk_index(flat, f"r{l}", W, To, unit_feature_hidden, 16))
+    ar = np.arange
+    aux = [flat.vec_index("b8", 1 + ar(256))]
+    for l in range(D):
+        aux.append(flat.vec_index(f"rb{l}", ar(256)))
+    aux.append(flat.mat_index(f"r{D}", ar(3), ar(256)).reshape(-1))
+    aux.append(flat.vec_index(f"rb{D}", _pad(ar(3), 4)))
+    aux = np.concatenate(aux)
+    assert len(aux) == RAD_AUX_FLOATS
+    return PackPlanBF16(PROG_RADIANCE_BF16, flat, chunks, aux)
+
+
 def fold_weight_norm(weight_g: torch.Tensor, weight_v: torch.Tensor) -> torch.Tensor:
     """w[o,:] = g[o] * v[o,:] / ||v[o,:]||  (torch.nn.utils.weight_norm default dim=0; the
     reference re-does this on every forward, base.py:226-227 - here once per weight update)."""

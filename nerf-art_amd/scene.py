@@ -57,7 +57,7 @@ def perturb_state(sd: dict, beta: float | None = 0.01, speed_factor: float = 10.
     return out
 
 
-def build_model(framework: str = "VolSDF", seed: int = 0, beta: float | None = 0.01, device=None):
+def build_model(framework: str = "VolSDF", seed: int = 0, beta: float | None = 0.01, device=None, precision: str = "fp32"):
     """(model, render_kwargs_test, render_fn) with the synthetic scene's weights."""
     from .frameworks import get_model
     cfg = synthetic_config(framework)
@@ -66,6 +66,7 @@ def build_model(framework: str = "VolSDF", seed: int = 0, beta: float | None = 0
     model.load_state_dict(perturb_state(model.state_dict(), beta=beta, seed=seed + 1))
     if device is not None:
         model.to(device)
+    model.set_precision(precision)
     return model, rk_test, render_fn
 
 

@@ -207,3 +207,194 @@ def emul_radiance(blob_np, view_tiles, pts16, view16, nabla16, h7_16):
         z = dot_row16(X, blob.aux[1280 + 256 * c: 1280 + 256 * (c + 1)]) + blob.aux[2048 + c]
         rgb[:, c] = (1.0 / (1.0 + np.exp(-z)))[:16]
     return rgb
+
+
+# ======================================================================================================
+# Software model of csrc/mlp_chain_bf16.hip (split-bf16 "bf16x3", v_mfma_f32_32x32x16_bf16 layouts)
+# ======================================================================================================
+import torch as _torch
+
+H2, J2 = LANE // 32, LANE % 32
+KS_FLOATS = 512
+
+
+def _bf16(x):
+    return _torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(_torch.bfloat16).to(_torch.float32).numpy()
+
+
+def split2(x):
+    hi = _bf16(x)
+    lo = _bf16(x.astype(np.float32) - hi)
+    return hi, lo
+
+
+def mfma_32x32x16(a, b, c):
+    """a, b: [64 lanes, 8] (bf16 values as float32); c: [64, 16].  Slot (h, e) of A pairs with slot (h, e) of B;
+    C register r of lane (h, j) is row (r&3) + 8(r>>2) + 4h, column j."""
+    A = np.zeros((32, 16), np.float64); B = np.zeros((16, 32), np.float64)
+    for e in range(8):
+        A[J2, 8 * H2 + e] = a[:, e]
+        B[8 * H2 + e, J2] = b[:, e]
+    Cm = A @ B
+    d = c.copy()
+    for r in range(16):
+        d[:, r] = (d[:, r].astype(np.float64) + Cm[(r & 3) + 8 * (r >> 2) + 4 * H2, J2]).astype(np.float32)
+    return d
+
+
+def _frag(w, ks):
+    """chunk float array -> (A_hi, A_lo) [64, 8] bf16 values for k-step ks"""
+    raw = np.ascontiguousarray(w[ks * KS_FLOATS:(ks + 1) * KS_FLOATS]).view(np.uint16).reshape(2, 64, 8)
+    f = (raw.astype(np.uint32) << 16).view(np.float32)
+    return f[0], f[1]
+
+
+def run_layer_bf16(Xh, Xl, blob, bias, rows, nk, ntiles, act, tangent, scale, last, dots, h7=None):
+    """Xh/Xl: lists of [64, 8] units.  Returns (Yh, Yl) lists of 16 units (None when last)."""
+    Yh, Yl = [None] * 19, [None] * 19
+    is_val = (LANE & 3) == 0 if tangent else np.ones(64, bool)
+    for T in range(ntiles):
+        w = blob.acquire()
+        acc = np.zeros((64, 16), np.float32)
+        for ks in range(nk):
+            ah, al = _frag(w, ks)
+            acc = mfma_32x32x16(ah, Xh[ks], acc)
+            acc = mfma_32x32x16(ah, Xl[ks], acc)
+            acc = mfma_32x32x16(al, Xh[ks], acc)
+        feat = 32 * T + (np.arange(16)[None, :] & 3) + 8 * (np.arange(16)[None, :] >> 2) + 4 * H2[:, None]    # [64,16]
+        b = bias[feat]
+        z = acc + np.where(is_val[:, None], b, 0).astype(np.float32)
+        if act == "softplus":
+            if tangent:
+                d = softplus100_grad(z)[LANE & ~3]
+                y = np.where(is_val[:, None], softplus100(z), d * acc).astype(np.float32)
+            else:
+                y = softplus100(z)
+        elif act == "relu":
+            y = np.maximum(z, 0).astype(np.float32)
+        else:
+            y = z.astype(np.float32)
+        if scale:
+            y = (y / np.float32(1.41421356237309504880)).astype(np.float32)
+        if last:
+            for n in range(len(dots)):
+                dots[n] += (y * rows[n * 256 + feat]).sum(1).astype(np.float32)
+            if h7 is not None:
+                for lane in range(64):
+                    if is_val[lane]:
+                        h7[J2[lane] >> 2 if tangent else J2[lane], feat[lane]] = y[lane]
+        else:
+            for u in range(2):
+                hi, lo = split2(y[:, 8 * u: 8 * u + 8])
+                Yh[2 * T + u], Yl[2 * T + u] = hi, lo
+    return Yh, Yl
+
+
+def encode_units_bf16(p, dq, scale):
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+    co = [x, y, z]
+    m0 = np.zeros((64, 24), np.float32); m1 = np.zeros((64, 24), np.float32)
+    val = dq < 0
+    fb = np.where(H2 == 1, 8.0, 1.0).astype(np.float32)
+    for c in range(3):
+        m0[:, c] = np.where(val, co[c], (dq == c).astype(np.float32))
+    for k in range(3):
+        f = fb * np.float32(1 << k)
+        for c in range(3):
+            s = np.sin(co[c] * f, dtype=np.float32); cs = np.cos(co[c] * f, dtype=np.float32)
+            vs = np.where(val, s, np.where(dq == c, cs * f, 0.0)).astype(np.float32)
+            vc = np.where(val, cs, np.where(dq == c, -(s * f), 0.0)).astype(np.float32)
+            m0[:, 3 + 6 * k + c] = vs; m0[:, 6 + 6 * k + c] = vc
+            m1[:, 6 * k + c] = vs; m1[:, 3 + 6 * k + c] = vc
+    m = np.where((H2 == 1)[:, None], m1, m0).astype(np.float32)
+    if scale:
+        m = (m / np.float32(1.41421356237309504880)).astype(np.float32)
+    out = []
+    for q in range(3):
+        out.append(split2(m[:, 8 * q: 8 * q + 8]))
+    return out
+
+
+def surface_chain_bf16(blob, p, dq, tangent, h7=None):
+    Xh, Xl = [None] * 19, [None] * 19
+    for q, (hi, lo) in enumerate(encode_units_bf16(p, dq, False)):
+        Xh[q], Xl[q] = hi, lo
+    dots = [np.zeros(64, np.float32)]
+    rows = blob.aux[2048:2304]
+    Yh, Yl = run_layer_bf16(Xh, Xl, blob, blob.aux[0:256], rows, 3, 8, "softplus", tangent, False, False, dots)
+    for L in range(1, 8):
+        Xh[:16], Xl[:16] = Yh[:16], Yl[:16]
+        nk = 16
+        if L == 4:
+            for q, (hi, lo) in enumerate(encode_units_bf16(p, dq, True)):
+                Xh[14 + q], Xl[14 + q] = hi, lo
+            nk = 17
+        Yh, Yl = run_layer_bf16(Xh, Xl, blob, blob.aux[L * 256:(L + 1) * 256], rows, nk, 7 if L == 3 else 8, "softplus",
+                                tangent, L == 3, L == 7, dots, h7 if L == 7 else None)
+    d = dots[0]
+    return d + d[LANE ^ 32]
+
+
+def emul_sdf_only_bf16(blob_np, pts32, R_bg):
+    blob = Blob(blob_np)
+    p = pts32[J2].astype(np.float32)
+    sdf = surface_chain_bf16(blob, p, np.full(64, -1), False) + blob.aux[2304]
+    if R_bg > 0:
+        sdf = np.minimum(sdf, R_bg - np.sqrt((p ** 2).sum(1)))
+    return sdf[:32]
+
+
+def emul_sdf_nabla_bf16(blob_np, pts8, R_bg):
+    blob = Blob(blob_np)
+    p = pts8[J2 >> 2].astype(np.float32)
+    cq = J2 & 3
+    h7 = np.zeros((8, 256), np.float32)
+    v = surface_chain_bf16(blob, p, cq - 1, True, h7)
+    sdf = np.zeros(8, np.float32); nab = np.zeros((8, 3), np.float32)
+    for lane in range(32):
+        pi = lane >> 2
+        if cq[lane] == 0:
+            sv = v[lane] + blob.aux[2304]
+            if R_bg > 0:
+                d_bg = R_bg - np.sqrt((p[lane] ** 2).sum())
+                sv = d_bg if d_bg < sv else sv
+            sdf[pi] = sv
+        else:
+            nab[pi, cq[lane] - 1] = v[lane]
+    return sdf, nab, h7
+
+
+def emul_radiance_bf16(blob_np, view_tiles, pts32, view32, nabla32, h7_32):
+    blob = Blob(blob_np)
+    p, v, n = pts32[J2].astype(np.float32), view32[J2].astype(np.float32), nabla32[J2].astype(np.float32)
+    Xh, Xl = [None] * 19, [None] * 19
+    e8 = np.arange(8)
+    for u in range(16):
+        T, uu = u >> 1, u & 1
+        r = 8 * uu + e8
+        feat = 32 * T + (r[None, :] & 3) + 8 * (r[None, :] >> 2) + 4 * H2[:, None]
+        Xh[u], Xl[u] = split2(h7_32[J2[:, None], feat].astype(np.float32))
+    ne = 9 if view_tiles == 1 else 33
+    ex = np.zeros((64, 16 * view_tiles), np.float32)
+    ex[:, 0:3] = p; ex[:, 3:6] = v
+    if view_tiles == 3:
+        for k in range(4):
+            f = np.float32(1 << k)
+            ex[:, 6 + 6 * k: 9 + 6 * k] = np.sin(v * f, dtype=np.float32)
+            ex[:, 9 + 6 * k: 12 + 6 * k] = np.cos(v * f, dtype=np.float32)
+    ex[:, ne - 3: ne] = n
+    for q in range(view_tiles):
+        idx = 16 * q + 8 * H2[:, None] + e8[None, :]
+        Xh[16 + q], Xl[16 + q] = split2(ex[np.arange(64)[:, None], idx])
+    dots = [np.zeros(64, np.float32) for _ in range(3)]
+    rows = blob.aux[1280:1280 + 768]
+    for L in range(5):
+        Yh, Yl = run_layer_bf16(Xh, Xl, blob, blob.aux[L * 256:(L + 1) * 256], rows, 16 + (view_tiles if L == 1 else 0), 8,
+                                "none" if L == 0 else "relu", False, False, L == 4, dots)
+        if L < 4:
+            Xh[:16], Xl[:16] = Yh[:16], Yl[:16]
+    rgb = np.zeros((32, 3), np.float32)
+    for c in range(3):
+        z = dots[c] + dots[c][LANE ^ 32] + blob.aux[2048 + c]
+        rgb[:, c] = (1.0 / (1.0 + np.exp(-z)))[:32]
+    return rgb

@@ -76,3 +76,59 @@ def test_emulated_radiance_matches_oracle(fw):
     out = em.emul_radiance(rad, vt, pts.numpy(), view.numpy(), nab.numpy(), h7)
     ref = nets.radiance_forward(sd, pts, view, nab, feat, -1, -1 if fw == "VolSDF" else 4).numpy()
     np.testing.assert_allclose(out, ref, atol=3e-6, rtol=1e-5)
+
+
+# ---- split-bf16 ("bf16x3") programs ---------------------------------------------------------------------
+def _blobs_bf16(fw):
+    sd, _ = scene_state(fw, 0.01 if fw == "VolSDF" else None)
+    surf = packing.surface_plan_bf16().pack(packing.surface_tensors(sd)).numpy()
+    vt = 1 if fw == "VolSDF" else 3
+    rad = packing.radiance_plan_bf16(vt).pack(packing.radiance_tensors(sd)).numpy()
+    return sd, surf, rad, vt
+
+
+def test_bf16_blob_header():
+    _, surf, rad, _ = _blobs_bf16("VolSDF")
+    for blob, nc in ((surf, 63), (rad, 40)):
+        hdr = blob[:512].view(np.int32)
+        assert hdr[0] == packing.MAGIC and hdr[2] == nc and hdr[3] == blob.size
+        offs = hdr[16:16 + nc + 1]
+        assert set(np.diff(offs).tolist()) <= {3 * 512, 16 * 512, 17 * 512} and offs[-1] == hdr[4]
+
+
+def test_emulated_bf16_sdf_only_matches_oracle():
+    sd, surf, _, _ = _blobs_bf16("VolSDF")
+    g = torch.Generator().manual_seed(17)
+    pts = (torch.rand(32, 3, generator=g) * 6 - 3)
+    pts[:8] *= 0.3
+    ref = nets.volsdf_forward_surface(sd, pts)[0].numpy()
+    out = em.emul_sdf_only_bf16(surf, pts.numpy(), 3.0)
+    np.testing.assert_allclose(out, ref, atol=1e-4, rtol=1e-4)
+
+
+def test_emulated_bf16_sdf_nabla_matches_oracle():
+    sd, surf, _, _ = _blobs_bf16("VolSDF")
+    g = torch.Generator().manual_seed(18)
+    pts = (torch.rand(8, 3, generator=g) * 4 - 2)
+    sdf, nab, h7 = em.emul_sdf_nabla_bf16(surf, pts.numpy(), 3.0)
+    s_ref, n_ref, feat_ref = nets.surface_forward_with_nablas(sd, pts)
+    d_bg = 3.0 - pts.norm(dim=-1)
+    s_ref = torch.where(d_bg < s_ref, d_bg, s_ref)
+    np.testing.assert_allclose(sdf, s_ref.numpy(), atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(nab, n_ref.numpy(), atol=5e-4, rtol=1e-3)
+    w8 = nets.folded_weight(sd, "implicit_surface.surface_fc_layers.8").numpy()
+    b8 = sd["implicit_surface.surface_fc_layers.8.bias"].numpy()
+    np.testing.assert_allclose(h7 @ w8[1:].T + b8[1:], feat_ref.numpy(), atol=5e-4, rtol=1e-3)
+
+
+@pytest.mark.parametrize("fw", ["VolSDF", "NeuS"])
+def test_emulated_bf16_radiance_matches_oracle(fw):
+    sd, surf, rad, vt = _blobs_bf16(fw)
+    g = torch.Generator().manual_seed(19)
+    pts = (torch.rand(32, 3, generator=g) * 2 - 1)
+    view = torch.nn.functional.normalize(torch.randn(32, 3, generator=g), dim=-1)
+    _, nab, feat = nets.surface_forward_with_nablas(sd, pts)
+    h7 = np.concatenate([em.emul_sdf_nabla_bf16(surf, pts[i:i + 8].numpy(), 0.0)[2] for i in range(0, 32, 8)])
+    out = em.emul_radiance_bf16(rad, vt, pts.numpy(), view.numpy(), nab.numpy(), h7)
+    ref = nets.radiance_forward(sd, pts, view, nab, feat, -1, -1 if fw == "VolSDF" else 4).numpy()
+    np.testing.assert_allclose(out, ref, atol=2e-4, rtol=1e-3)
