@@ -14,10 +14,12 @@
 //     pairs slot (h,e) of A with slot (h,e) of B), so regs 8u..8u+7 of output tile T become, after the
 //     activation + split + v_cvt_pk_bf16_f32, "unit" 2T+u of the next layer's B operand directly in
 //     registers; the weight packing (packing.py: bf16 plans) applies the matching permutation.
-//   * t-outer order: one 32-row output tile per weight chunk (all k, hi and lo fragments: <= 38 KiB),
-//     LDS-DMA double buffered; the epilogue of tile T-1 is issued between the MFMAs of tile T (one wave
-//     per SIMD: matrix and vector pipes overlap only inside the wave).
-//   * 4 waves x 32 columns = 128 columns per workgroup, persistent grid.
+//   * k-outer order: the 8 accumulator tiles of a layer (128 registers, AGPRs) stay live; a weight chunk is
+//     up to 4 k-steps x 8 output tiles x (hi, lo) fragments = 64 KiB, LDS-DMA double buffered; input units
+//     die as they are consumed and the epilogue writes the next layer's units in place (X + acc = 264
+//     registers; a t-outer variant with a deferred epilogue needs X + Y + 2 acc = 300 and spills because
+//     vector results must land in the 256 arch VGPRs).
+//   * 4 waves x 32 columns = 128 columns per workgroup (one wave per SIMD), persistent grid.
 #include "mlp_common.h"
 
 namespace nerfart {
@@ -31,10 +33,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int WG_THREADS = 256;
 constexpr int WAVES = 4;
 constexpr int XU_MAX = 19;                          // input units (16 feature slots each)
-constexpr int KS_FLOATS = 512;                      // one k-step of a chunk: (hi, lo) x 64 lanes x 16 B
-constexpr int CHUNK_FLOATS_MAX = XU_MAX * KS_FLOATS;
+constexpr int TS_FLOATS = 512;                      // one (k-step, output tile): (hi, lo) x 64 lanes x 16 B = 2 KiB
+constexpr int KS_FLOATS = 8 * TS_FLOATS;            // one k-step of a chunk: 8 output tiles = 16 KiB
+constexpr int CHUNK_KS = 4;                         // k-steps per chunk
+constexpr int CHUNK_FLOATS_MAX = CHUNK_KS * KS_FLOATS;   // 64 KiB
 constexpr int AUX_FLOATS_MAX = 2560;
-constexpr int LDS_FLOATS = 2 * CHUNK_FLOATS_MAX + AUX_FLOATS_MAX + TAB_INTS;   // 88,576 B
+constexpr int LDS_FLOATS = 2 * CHUNK_FLOATS_MAX + AUX_FLOATS_MAX + TAB_INTS;   // 141,824 B
 using Pipe = PipeT<WAVES, CHUNK_FLOATS_MAX>;
 
 struct Act { u32x4 h[XU_MAX]; u32x4 l[XU_MAX]; };   // packed bf16 pairs: hi and lo terms of 8 slots per unit
@@ -56,142 +60,135 @@ __device__ __forceinline__ f32x16 mfma3(const u32x4 ah, const u32x4 al, const u3
     return acc;
 }
 
-// Run-time (wave-uniform) description of what a layer's epilogue does.
+// Run-time (wave-uniform) description of what a layer's epilogue does (branch free).
 struct Epi {
     const float* bias;     // LDS, natural feature order
-    bool relu;             // ReLU family only
-    bool scale;            // divide the output by sqrt(2) (the layer feeding the skip connection)
-    bool last;             // last hidden layer: accumulate the output rows instead of producing the next input
-    const float* rows;     // LDS: NROWS x 256 weights of the final linear layer
-    float* h7;             // per-lane destination of the fp32 activations (tangent kernel, last layer) or null
+    float floor;           // ReLU family: 0 (ReLU) or -inf (no activation)
+    float post_mul;        // 1, or 1/sqrt(2) for the layer feeding the skip connection
+    const float* rows;     // LDS: NROWS x 256 weights of the final linear layer (LAST bodies)
+    float* h7;             // per-lane destination of the fp32 activations (tangent kernel, LAST body) or null
 };
 
-// Epilogue of one 32-row output tile (its 16 accumulator registers) - pair p = registers 2p, 2p+1.
-template <int T, int P, bool SOFTPLUS, bool TANGENT, int NROWS>
-__device__ __forceinline__ void epi_pair(const f32x16& acc, const Epi& e, Act& Y, float (&dot)[NROWS], int h, bool is_val) {
+struct Acc { f32x16 t[8]; };
+
+// one k-step: 8 output tiles x 3 MFMAs; tile 7 is skipped for the 217-wide layer (ntiles == 7)
+__device__ __forceinline__ void mma_kstep(Acc& A, const u32x4 xh, const u32x4 xl, const float* w, bool full8) {
+#pragma unroll
+    for (int T = 0; T < 8; ++T) {
+        if (T < 7 || full8) {
+            const u32x4 ah = *reinterpret_cast<const u32x4*>(w + T * TS_FLOATS);
+            const u32x4 al = *reinterpret_cast<const u32x4*>(w + T * TS_FLOATS + 256);
+            A.t[T] = mfma3(ah, al, xh, xl, A.t[T]);
+        }
+    }
+}
+
+// Epilogue of output tile T, pair P (registers 2P, 2P+1): activation, then either the next layer's
+// unit 2T + (P>>2) (hi/lo split, packed) or the final rows' dot products.
+template <int T, int P, bool SOFTPLUS, bool TANGENT, bool LAST, int NROWS>
+__device__ __forceinline__ void epi_pair(const f32x16& acc, const Epi& e, Act& X, float (&dot)[NROWS], int h, bool is_val) {
     constexpr int g = P >> 1, c = 2 * (P & 1);                 // feature = 32T + 8g + 4h + c + {0,1}
     const int fo = 32 * T + 8 * g + 4 * h;
-    const f32x4 b = *reinterpret_cast<const f32x4*>(e.bias + fo);
     float y[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const float a = acc[2 * P + k];
-        const float z = a + (is_val ? b[c + k] : 0.f);
         if (SOFTPLUS) {
             if (TANGENT) {
                 float v, d;
-                softplus100_vd(z, v, d);
+                softplus100_vd(a, v, d);        // value lanes carry the bias from the accumulator init
                 d = quad_bcast0(d);
                 y[k] = is_val ? v : d * a;
             } else {
-                y[k] = softplus100(z);
+                y[k] = softplus100(a);
             }
         } else {
-            y[k] = e.relu ? fmaxf(z, 0.f) : z;
+            y[k] = fmaxf(a, e.floor);
         }
-        if (e.scale) y[k] = y[k] / 1.41421356237309504880f;
+        y[k] *= e.post_mul;
     }
-    if (e.last) {
+    if (LAST) {
 #pragma unroll
         for (int n = 0; n < NROWS; ++n) {
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(e.rows + n * 256 + fo);
-            dot[n] = fmaf(y[0], wv[c], dot[n]);
-            dot[n] = fmaf(y[1], wv[c + 1], dot[n]);
+            const f32x2 wv = *reinterpret_cast<const f32x2*>(e.rows + n * 256 + fo + c);
+            dot[n] = fmaf(y[0], wv[0], dot[n]);
+            dot[n] = fmaf(y[1], wv[1], dot[n]);
         }
-        if (TANGENT && e.h7 != nullptr && is_val) {
-            e.h7[fo + c] = y[0];
-            e.h7[fo + c + 1] = y[1];
+        if (TANGENT) {
+            if (e.h7 != nullptr && is_val) *reinterpret_cast<f32x2*>(e.h7 + fo + c) = f32x2{y[0], y[1]};
         }
     } else {
         unsigned hi, lo;
         split2(y[0], y[1], hi, lo);
-        Y.h[2 * T + (P >> 2)][P & 3] = hi;
-        Y.l[2 * T + (P >> 2)][P & 3] = lo;
+        X.h[2 * T + (P >> 2)][P & 3] = hi;
+        X.l[2 * T + (P >> 2)][P & 3] = lo;
     }
 }
 
-template <int T, bool SOFTPLUS, bool TANGENT, int NROWS>
-__device__ __forceinline__ void epi_tile(const f32x16& acc, const Epi& e, Act& Y, float (&dot)[NROWS], int h, bool is_val) {
-    epi_pair<T, 0, SOFTPLUS, TANGENT, NROWS>(acc, e, Y, dot, h, is_val);
-    epi_pair<T, 1, SOFTPLUS, TANGENT, NROWS>(acc, e, Y, dot, h, is_val);
-    epi_pair<T, 2, SOFTPLUS, TANGENT, NROWS>(acc, e, Y, dot, h, is_val);
-    epi_pair<T, 3, SOFTPLUS, TANGENT, NROWS>(acc, e, Y, dot, h, is_val);
-    epi_pair<T, 4, SOFTPLUS, TANGENT, NROWS>(acc, e, Y, dot, h, is_val);
-    epi_pair<T, 5, SOFTPLUS, TANGENT, NROWS>(acc, e, Y, dot, h, is_val);
-    epi_pair<T, 6, SOFTPLUS, TANGENT, NROWS>(acc, e, Y, dot, h, is_val);
-    epi_pair<T, 7, SOFTPLUS, TANGENT, NROWS>(acc, e, Y, dot, h, is_val);
+template <int T, bool SOFTPLUS, bool TANGENT, bool LAST, int NROWS>
+__device__ __forceinline__ void epi_tile(const f32x16& acc, const Epi& e, Act& X, float (&dot)[NROWS], int h, bool is_val) {
+    epi_pair<T, 0, SOFTPLUS, TANGENT, LAST, NROWS>(acc, e, X, dot, h, is_val);
+    epi_pair<T, 1, SOFTPLUS, TANGENT, LAST, NROWS>(acc, e, X, dot, h, is_val);
+    epi_pair<T, 2, SOFTPLUS, TANGENT, LAST, NROWS>(acc, e, X, dot, h, is_val);
+    epi_pair<T, 3, SOFTPLUS, TANGENT, LAST, NROWS>(acc, e, X, dot, h, is_val);
+    epi_pair<T, 4, SOFTPLUS, TANGENT, LAST, NROWS>(acc, e, X, dot, h, is_val);
+    epi_pair<T, 5, SOFTPLUS, TANGENT, LAST, NROWS>(acc, e, X, dot, h, is_val);
+    epi_pair<T, 6, SOFTPLUS, TANGENT, LAST, NROWS>(acc, e, X, dot, h, is_val);
+    epi_pair<T, 7, SOFTPLUS, TANGENT, LAST, NROWS>(acc, e, X, dot, h, is_val);
 }
 
-// One output tile: NU_BASE (+ nextra) k-steps of 3 MFMAs, with the previous tile's epilogue pairs
-// slotted between the k-steps.
-template <int T, int NU_BASE, int NU_EXTRA_MAX, bool SOFTPLUS, bool TANGENT, int NROWS>
-__device__ __forceinline__ f32x16 tile_mma(const Act& X, Act& Y, Pipe& p, const Epi& e, float (&dot)[NROWS], int nextra,
-                                           const f32x16& acc_prev, int h, bool is_val, int lane) {
-    const float* w = pipe_acquire(p) + lane * 4;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < NU_BASE; ++ks) {
-        const u32x4 ah = *reinterpret_cast<const u32x4*>(w + ks * KS_FLOATS);
-        const u32x4 al = *reinterpret_cast<const u32x4*>(w + ks * KS_FLOATS + 256);
-        acc = mfma3(ah, al, X.h[ks], X.l[ks], acc);
-        if (T > 0) {
-            // deferred epilogue of tile T-1: pairs spread over the k-steps (two per k-step when k is short)
-            constexpr int PER = (NU_BASE >= 8) ? 1 : 4;
-#pragma unroll
-            for (int q = 0; q < PER; ++q) {
-                const int pidx = (NU_BASE >= 8) ? (ks >> 1) : (ks * PER + q);
-                const bool fire = (NU_BASE >= 8) ? ((ks & 1) == 1) : true;
-                if (fire && pidx < 8) {
-                    switch (pidx) {
-                        case 0: epi_pair<(T > 0 ? T - 1 : 0), 0, SOFTPLUS, TANGENT, NROWS>(acc_prev, e, Y, dot, h, is_val); break;
-                        case 1: epi_pair<(T > 0 ? T - 1 : 0), 1, SOFTPLUS, TANGENT, NROWS>(acc_prev, e, Y, dot, h, is_val); break;
-                        case 2: epi_pair<(T > 0 ? T - 1 : 0), 2, SOFTPLUS, TANGENT, NROWS>(acc_prev, e, Y, dot, h, is_val); break;
-                        case 3: epi_pair<(T > 0 ? T - 1 : 0), 3, SOFTPLUS, TANGENT, NROWS>(acc_prev, e, Y, dot, h, is_val); break;
-                        case 4: epi_pair<(T > 0 ? T - 1 : 0), 4, SOFTPLUS, TANGENT, NROWS>(acc_prev, e, Y, dot, h, is_val); break;
-                        case 5: epi_pair<(T > 0 ? T - 1 : 0), 5, SOFTPLUS, TANGENT, NROWS>(acc_prev, e, Y, dot, h, is_val); break;
-                        case 6: epi_pair<(T > 0 ? T - 1 : 0), 6, SOFTPLUS, TANGENT, NROWS>(acc_prev, e, Y, dot, h, is_val); break;
-                        default: epi_pair<(T > 0 ? T - 1 : 0), 7, SOFTPLUS, TANGENT, NROWS>(acc_prev, e, Y, dot, h, is_val); break;
-                    }
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int x = 0; x < NU_EXTRA_MAX; ++x) {
-        if (x < nextra) {
-            const int ks = NU_BASE + x;
-            const u32x4 ah = *reinterpret_cast<const u32x4*>(w + ks * KS_FLOATS);
-            const u32x4 al = *reinterpret_cast<const u32x4*>(w + ks * KS_FLOATS + 256);
-            acc = mfma3(ah, al, X.h[ks], X.l[ks], acc);
-        }
-    }
-    return acc;
-}
-
-// A whole dense layer.  ntiles = 7 (the 217-wide layer) or 8.
-template <int NU_BASE, int NU_EXTRA_MAX, bool SOFTPLUS, bool TANGENT, int NROWS>
-__device__ __forceinline__ void run_layer(const Act& X, Act& Y, Pipe& p, const Epi& e, float (&dot)[NROWS], int ntiles, int nextra) {
+// A whole dense layer, in place on X.  Chunk sequence (must match packing.py, bf16 plans): ceil(NU_BASE/4)
+// chunks of the base units, then (if nextra) one chunk with the nextra extra units.
+template <int NU_BASE, int NU_EXTRA_MAX, bool SOFTPLUS, bool TANGENT, bool LAST, int NROWS>
+__device__ __forceinline__ void run_layer(Act& X, Pipe& p, const Epi& e, float (&dot)[NROWS], int ntiles, int nextra) {
     const int lane = lane_id();
     const int h = lane >> 5;
     const bool is_val = !TANGENT || ((lane & 3) == 0);
-    f32x16 a0, a1;
+    const bool full8 = (ntiles == 8);
+    Acc A;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) a0[r] = 0.f;
-    a0 = tile_mma<0, NU_BASE, NU_EXTRA_MAX, SOFTPLUS, TANGENT, NROWS>(X, Y, p, e, dot, nextra, a0, h, is_val, lane);
-    a1 = tile_mma<1, NU_BASE, NU_EXTRA_MAX, SOFTPLUS, TANGENT, NROWS>(X, Y, p, e, dot, nextra, a0, h, is_val, lane);
-    a0 = tile_mma<2, NU_BASE, NU_EXTRA_MAX, SOFTPLUS, TANGENT, NROWS>(X, Y, p, e, dot, nextra, a1, h, is_val, lane);
-    a1 = tile_mma<3, NU_BASE, NU_EXTRA_MAX, SOFTPLUS, TANGENT, NROWS>(X, Y, p, e, dot, nextra, a0, h, is_val, lane);
-    a0 = tile_mma<4, NU_BASE, NU_EXTRA_MAX, SOFTPLUS, TANGENT, NROWS>(X, Y, p, e, dot, nextra, a1, h, is_val, lane);
-    a1 = tile_mma<5, NU_BASE, NU_EXTRA_MAX, SOFTPLUS, TANGENT, NROWS>(X, Y, p, e, dot, nextra, a0, h, is_val, lane);
-    a0 = tile_mma<6, NU_BASE, NU_EXTRA_MAX, SOFTPLUS, TANGENT, NROWS>(X, Y, p, e, dot, nextra, a1, h, is_val, lane);
-    if (ntiles == 8) {
-        a1 = tile_mma<7, NU_BASE, NU_EXTRA_MAX, SOFTPLUS, TANGENT, NROWS>(X, Y, p, e, dot, nextra, a0, h, is_val, lane);
-        epi_tile<7, SOFTPLUS, TANGENT, NROWS>(a1, e, Y, dot, h, is_val);
-    } else {
-        epi_tile<6, SOFTPLUS, TANGENT, NROWS>(a0, e, Y, dot, h, is_val);
+    for (int T = 0; T < 8; ++T) {
+        // start at the bias (value columns; derivative columns start at 0): register 4g + c of lane (h, j) is
+        // feature 32T + 8g + 4h + c
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(e.bias + 32 * T + 8 * g + 4 * h);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) A.t[T][4 * g + c] = is_val ? b[c] : 0.f;
+        }
     }
+#pragma unroll
+    for (int c = 0; c < (NU_BASE + CHUNK_KS - 1) / CHUNK_KS; ++c) {
+        const float* w = pipe_acquire(p) + lane * 4;
+#pragma unroll
+        for (int kk = 0; kk < CHUNK_KS; ++kk) {
+            const int ks = c * CHUNK_KS + kk;
+            if (ks < NU_BASE) mma_kstep(A, X.h[ks], X.l[ks], w + kk * KS_FLOATS, full8);
+        }
+    }
+    if (NU_EXTRA_MAX > 0) {
+        if (nextra > 0) {
+            const float* w = pipe_acquire(p) + lane * 4;
+#pragma unroll
+            for (int x = 0; x < NU_EXTRA_MAX; ++x)
+                if (x < nextra) mma_kstep(A, X.h[NU_BASE + x], X.l[NU_BASE + x], w + x * KS_FLOATS, full8);
+        }
+    }
+    epi_tile<0, SOFTPLUS, TANGENT, LAST, NROWS>(A.t[0], e, X, dot, h, is_val);
+    __builtin_amdgcn_sched_barrier(0);
+    epi_tile<1, SOFTPLUS, TANGENT, LAST, NROWS>(A.t[1], e, X, dot, h, is_val);
+    __builtin_amdgcn_sched_barrier(0);
+    epi_tile<2, SOFTPLUS, TANGENT, LAST, NROWS>(A.t[2], e, X, dot, h, is_val);
+    __builtin_amdgcn_sched_barrier(0);
+    epi_tile<3, SOFTPLUS, TANGENT, LAST, NROWS>(A.t[3], e, X, dot, h, is_val);
+    __builtin_amdgcn_sched_barrier(0);
+    epi_tile<4, SOFTPLUS, TANGENT, LAST, NROWS>(A.t[4], e, X, dot, h, is_val);
+    __builtin_amdgcn_sched_barrier(0);
+    epi_tile<5, SOFTPLUS, TANGENT, LAST, NROWS>(A.t[5], e, X, dot, h, is_val);
+    __builtin_amdgcn_sched_barrier(0);
+    epi_tile<6, SOFTPLUS, TANGENT, LAST, NROWS>(A.t[6], e, X, dot, h, is_val);
+    __builtin_amdgcn_sched_barrier(0);
+    if (full8) epi_tile<7, SOFTPLUS, TANGENT, LAST, NROWS>(A.t[7], e, X, dot, h, is_val);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -228,7 +225,7 @@ __device__ __forceinline__ void encode_units(float x, float y, float z, int h, i
         for (int pr = 0; pr < 4; ++pr) {
             float a = h ? m1[8 * q + 2 * pr] : m0[8 * q + 2 * pr];
             float b = h ? m1[8 * q + 2 * pr + 1] : m0[8 * q + 2 * pr + 1];
-            if (scale) { a = a / 1.41421356237309504880f; b = b / 1.41421356237309504880f; }
+            if (scale) { a *= 0.70710678118654752440f; b *= 0.70710678118654752440f; }
             unsigned hi, lo;
             split2(a, b, hi, lo);
             X.h[u0 + q][pr] = hi;
@@ -251,29 +248,25 @@ __device__ __forceinline__ void load_aux(float* aux_lds, const float* blob, cons
     __syncthreads();
 }
 
-__device__ __forceinline__ void copy_units(Act& X, const Act& Y) {
-#pragma unroll
-    for (int u = 0; u < 16; ++u) { X.h[u] = Y.h[u]; X.l[u] = Y.l[u]; }
-}
-
-// The 8 hidden layers of the SDF net; the last one accumulates dot[0] = row0 . h7 (and stores h7 if asked).
+// The 8 hidden layers of the SDF net, in place on X; the last one accumulates dot[0] = row0 . h7 (and stores
+// h7 if asked).  Bodies: layer 0 (3 input units), layers 1..6 (one body in a run-time loop), layer 7 (LAST).
 template <bool TANGENT>
-__device__ __forceinline__ float surface_chain(Act& X, Act& Y, float px, float py, float pz, int h, int dq, Pipe& p,
+__device__ __forceinline__ float surface_chain(Act& X, float px, float py, float pz, int h, int dq, Pipe& p,
                                                const float* aux, float* h7_lane) {
     float dot[1] = {0.f};
-    Epi e{aux, false, false, false, aux + SURF_AUX_ROW, nullptr};
+    Epi e{aux, 0.f, 1.f, aux + SURF_AUX_ROW, h7_lane};
     encode_units(px, py, pz, h, dq, false, X, 0);
-    run_layer<3, 0, true, TANGENT, 1>(X, Y, p, e, dot, 8, 0);
+    run_layer<3, 0, true, TANGENT, false, 1>(X, p, e, dot, 8, 0);
 #pragma nounroll
-    for (int L = 1; L < 8; ++L) {
-        copy_units(X, Y);
+    for (int L = 1; L < 7; ++L) {
         if (L == 4) encode_units(px, py, pz, h, dq, true, X, 14);       // skip: cat[h(217), enc(39)] / sqrt(2)
         e.bias = aux + L * 256;
-        e.scale = (L == 3);
-        e.last = (L == 7);
-        e.h7 = (L == 7) ? h7_lane : nullptr;
-        run_layer<16, 1, true, TANGENT, 1>(X, Y, p, e, dot, (L == 3) ? 7 : 8, (L == 4) ? 1 : 0);
+        e.post_mul = (L == 3) ? 0.70710678118654752440f : 1.f;
+        run_layer<16, 1, true, TANGENT, false, 1>(X, p, e, dot, (L == 3) ? 7 : 8, (L == 4) ? 1 : 0);
     }
+    e.bias = aux + 7 * 256;
+    e.post_mul = 1.f;
+    run_layer<16, 0, true, TANGENT, true, 1>(X, p, e, dot, 8, 0);
     // the two halves of a column hold complementary feature sets
     return dot[0] + __shfl_xor(dot[0], 32, 64);
 }
@@ -297,8 +290,8 @@ k_sdf_only_bf16(const float* __restrict__ blob, PointSrc src, float R_bg, float*
         p.wrap = (tile + gridDim.x) < ntiles;
         const unsigned m = tile * 128u + wv * 32 + j;
         const Pt pt = fetch_point(src, m, false);
-        Act X, Y;
-        float sdf = surface_chain<false>(X, Y, pt.x, pt.y, pt.z, h, -1, p, aux, nullptr) + aux[SURF_AUX_B8];
+        Act X;
+        float sdf = surface_chain<false>(X, pt.x, pt.y, pt.z, h, -1, p, aux, nullptr) + aux[SURF_AUX_B8];
         if (R_bg > 0.f) sdf = fminf(sdf, R_bg - sqrtf(pt.x * pt.x + pt.y * pt.y + pt.z * pt.z));
         if (h == 0 && m < src.M) {
             if (src.pts) sdf_out[m] = sdf;
@@ -331,9 +324,9 @@ k_sdf_nabla_bf16(const float* __restrict__ blob, PointSrc src, float R_bg, float
         p.wrap = (tile + gridDim.x) < ntiles;
         const unsigned m = tile * 32u + wv * 8 + (j >> 2);
         const Pt pt = fetch_point(src, m, false);
-        Act X, Y;
+        Act X;
         float* h7_lane = (h7_out != nullptr && m < src.M) ? h7_out + (size_t)m * 256 : nullptr;
-        const float v = surface_chain<true>(X, Y, pt.x, pt.y, pt.z, h, cq - 1, p, aux, h7_lane);
+        const float v = surface_chain<true>(X, pt.x, pt.y, pt.z, h, cq - 1, p, aux, h7_lane);
         if (m < src.M && h == 0) {
             if (cq == 0) {
                 float sdf = v + aux[SURF_AUX_B8];
@@ -407,7 +400,7 @@ k_radiance_bf16(const float* __restrict__ blob, PointSrc src, const float* __res
         const unsigned m = tile * 128u + wv * 32 + j;
         const bool valid = m < src.M;
         const Pt pt = fetch_point(src, m, true);
-        Act X, Y;
+        Act X;
         float nx = 0.f, ny = 0.f, nz = 0.f;
         if (valid) { nx = nabla_in[(size_t)m * 3 + 0]; ny = nabla_in[(size_t)m * 3 + 1]; nz = nabla_in[(size_t)m * 3 + 2]; }
         // h7 -> units: unit 2T+u, slot e <-> feature 32T + (r&3) + 8(r>>2) + 4h with r = 8u + e
@@ -429,15 +422,17 @@ k_radiance_bf16(const float* __restrict__ blob, PointSrc src, const float* __res
         }
         radiance_extras<VE>(pt, nx, ny, nz, h, X);
         float dot[3] = {0.f, 0.f, 0.f};
-        Epi e{aux, false, false, false, aux + RAD_AUX_ROWS, nullptr};
+        Epi e{aux, -INFINITY, 1.f, aux + RAD_AUX_ROWS, nullptr};
+        // L = 0: geometry feature (no activation); L = 1: [feat | x, v, n] -> 256 ReLU; L = 2, 3: ReLU; L = 4: LAST
 #pragma nounroll
-        for (int L = 0; L < 5; ++L) {
-            if (L > 0) copy_units(X, Y);
+        for (int L = 0; L < 4; ++L) {
             e.bias = aux + L * 256;
-            e.relu = (L != 0);
-            e.last = (L == 4);
-            run_layer<16, VE, false, false, 3>(X, Y, p, e, dot, 8, (L == 1) ? VE : 0);
+            e.floor = (L == 0) ? -INFINITY : 0.f;
+            run_layer<16, VE, false, false, false, 3>(X, p, e, dot, 8, (L == 1) ? VE : 0);
         }
+        e.bias = aux + 4 * 256;
+        e.floor = 0.f;
+        run_layer<16, 0, false, false, true, 3>(X, p, e, dot, 8, 0);
         float c[3];
 #pragma unroll
         for (int n = 0; n < 3; ++n) c[n] = sigmoidf_(dot[n] + __shfl_xor(dot[n], 32, 64) + aux[RAD_AUX_BF + n]);

@@ -238,7 +238,7 @@ def radiance_plan(view_tiles: int, W: int = 256, D: int = 4, W_geo_feat: int = 2
 # ----------------------------------------------------------------------------------------------------
 PROG_SURFACE_BF16 = 3
 PROG_RADIANCE_BF16 = 4
-KS_FLOATS = 512           # one k-step of a chunk: (hi, lo) x 64 lanes x 8 bf16 = 2 KiB
+TS_FLOATS = 512           # one (k-step, output tile) of a chunk: (hi, lo) x 64 lanes x 8 bf16 = 2 KiB
 
 
 def unit_feature_hidden(ks: int, h: int, e: int) -> int:
@@ -264,31 +264,42 @@ def unit_feature_extra(q: int, h: int, e: int, n_extra: int) -> int:
     return m if m < n_extra else -1
 
 
-def _tile_chunk_index(flat, name, out_dim, To, cols_fn, nk):
-    """Index array [nk][lane=64][e=8] for output tile To: W[32 To + i][cols_fn(ks, h, e)]."""
+def _kstep_index(flat, name, out_dim, ks, cols_fn, row0=0):
+    """Index array [T=8][lane=64][e=8] of one k-step: W[row0 + 32T + i][cols_fn(ks, h, e)] (rows >= out_dim: zero)."""
     R, C = flat.shape[name]
-    idx = np.full((nk, 64, 8), flat.zero, dtype=np.int64)
-    for ks in range(nk):
+    idx = np.full((8, 64, 8), flat.zero, dtype=np.int64)
+    i = np.arange(32)
+    for T in range(8):
+        rows = 32 * T + i
+        ok = rows < out_dim
         for h in range(2):
             for e in range(8):
                 c = cols_fn(ks, h, e)
                 if c < 0:
                     continue
-                rows = 32 * To + np.arange(32)
-                ok = rows < out_dim
-                lanes = 32 * h + np.arange(32)
-                idx[ks, lanes[ok], e] = flat.base[name] + rows[ok] * C + c
+                idx[T, (32 * h + i)[ok], e] = flat.base[name] + (row0 + rows[ok]) * C + c
     return idx.reshape(-1)
 
 
+def _layer_chunks_bf16(flat, name, out_dim, cols_fn, nu_base, nu_extra, row0=0, chunk_ks=4):
+    """ceil(nu_base/4) chunks of base k-steps, then one chunk with the extra k-steps (matches run_layer in
+    mlp_chain_bf16.hip)."""
+    chunks = []
+    for c0 in range(0, nu_base, chunk_ks):
+        chunks.append(np.concatenate([_kstep_index(flat, name, out_dim, ks, cols_fn, row0) for ks in range(c0, min(c0 + chunk_ks, nu_base))]))
+    if nu_extra:
+        chunks.append(np.concatenate([_kstep_index(flat, name, out_dim, nu_base + x, cols_fn, row0) for x in range(nu_extra)]))
+    return chunks
+
+
 class PackPlanBF16(PackPlan):
-    """Chunks hold bf16 hi/lo fragments: float[ks][term=2][lane=64][4] (= 8 bf16 per lane)."""
+    """Chunks hold bf16 hi/lo fragments, k-outer: float[k-step][T=8][term=2][lane=64][4] (= 8 bf16 per lane)."""
 
     def __init__(self, prog, flat, chunk_indices, aux):
         self.prog, self.flat = prog, flat
         offs = [HDR_INTS]
         for c in chunk_indices:
-            offs.append(offs[-1] + (len(c) // 512) * KS_FLOATS)
+            offs.append(offs[-1] + (len(c) // 512) * TS_FLOATS)
         self.nc = len(chunk_indices)
         assert self.nc + 1 <= 128
         self.aux_off = offs[-1]
@@ -303,19 +314,19 @@ class PackPlanBF16(PackPlan):
 
     def pack(self, tensors: dict) -> torch.Tensor:
         dev = tensors[self.flat.names[0]].device
-        parts = [tensors[n].detach().reshape(-1).to(torch.float32) for n in self.flat.names]
         for n in self.flat.names:
             assert tuple(tensors[n].shape) == self.flat.shape[n], n
+        parts = [tensors[n].detach().reshape(-1).to(torch.float32) for n in self.flat.names]
         parts.append(torch.zeros(1, dtype=torch.float32, device=dev))
         src = torch.cat(parts)
         key = str(dev)
         if key not in self._index_t:
             self._index_t[key] = (torch.from_numpy(self.cindex).to(dev), torch.from_numpy(self.aindex).to(dev))
         ci, ai = self._index_t[key]
-        w = src[ci].reshape(-1, 64, 8)                        # [k-steps of all chunks, lane, e]
+        w = src[ci].reshape(-1, 64, 8)                        # [(k-step, tile) of all chunks, lane, e]
         hi = w.to(torch.bfloat16)                             # round-to-nearest-even
         lo = (w - hi.to(torch.float32)).to(torch.bfloat16)
-        body = torch.stack([hi, lo], dim=1).contiguous().view(torch.float32).reshape(-1)   # [ks][term][lane][4]
+        body = torch.stack([hi, lo], dim=1).contiguous().view(torch.float32).reshape(-1)   # [..][term][lane][4]
         hdr = torch.from_numpy(self.header.copy()).view(torch.float32).to(dev)
         return torch.cat([hdr, body, src[ai]]).contiguous()
 
@@ -336,7 +347,7 @@ def surface_plan_bf16(W: int = 256, D: int = 8, skips=(4,), multires: int = 6, W
     for l in range(D):
         out_dim, in_dim = dims[l]
         if l == 0:
-            nk, fn = 3, (lambda ks, h, e: unit_feature_enc(ks, h, e))
+            chunks += _layer_chunks_bf16(flat, f"w{l}", out_dim, unit_feature_enc, 3, 0)
         elif l in skips:
             def fn(ks, h, e, hw=hw):
                 if ks < 14:
@@ -344,15 +355,12 @@ def surface_plan_bf16(W: int = 256, D: int = 8, skips=(4,), multires: int = 6, W
                     return f if f < hw else -1
                 f = unit_feature_enc(ks - 14, h, e)
                 return hw + f if f >= 0 else -1
-            nk = 17
+            chunks += _layer_chunks_bf16(flat, f"w{l}", out_dim, fn, 16, 1)
         else:
             def fn(ks, h, e, in_dim=in_dim):
                 f = unit_feature_hidden(ks, h, e)
                 return f if f < in_dim else -1
-            nk = 16
-        ntiles = (out_dim + 31) // 32
-        for To in range(ntiles):
-            chunks.append(_tile_chunk_index(flat, f"w{l}", out_dim, To, fn, nk))
+            chunks += _layer_chunks_bf16(flat, f"w{l}", out_dim, fn, 16, 0)
     ar = np.arange
     aux = [flat.vec_index(f"b{l}", _pad(ar(dims[l][0]), 256)) for l in range(D)]
     aux.append(flat.mat_index(f"w{D}", np.array([0]), ar(256)).reshape(-1))
@@ -372,23 +380,16 @@ def radiance_plan_bf16(view_tiles: int, W: int = 256, D: int = 4, W_geo_feat: in
     rdims = [(W, in0)] + [(W, W)] * (D - 1) + [(3, W)]
     for l, (o, i) in enumerate(rdims):
         flat.add(f"r{l}", (o, i)); flat.add(f"rb{l}", (o,))
-    chunks = []
-    # layer A: feat = W8[1:257] h7: rows 1.. of w8 (index the 256 rows, then shift by one row = 256 entries)
-    for To in range(8):
-        idx = _tile_chunk_index(flat, "w8", 1 + W_geo_feat - 1, To, unit_feature_hidden, 16)
-        # shift rows by one (row 32To+i of the layer = row 1+32To+i of w8)
-        idx = np.where(idx == flat.zero, idx, idx + 256)
-        chunks.append(idx)
+    # layer A: feat = W8[1:257] h7  (rows 1.. of w8)
+    chunks = _layer_chunks_bf16(flat, "w8", 256, unit_feature_hidden, 16, 0, row0=1)
 
     def fn0(ks, h, e):
         if ks < 16:
             return n_extra + unit_feature_hidden(ks, h, e)
         return unit_feature_extra(ks - 16, h, e, n_extra)
-    for To in range(8):
-        chunks.append(_tile_chunk_index(flat, "r0", W, To, fn0, 16 + view_tiles))
+    chunks += _layer_chunks_bf16(flat, "r0", W, fn0, 16, view_tiles)
     for l in range(1, D):
-        for To in range(8):
-            chunks.append(_tile_chunk_index(flat, f"r{l}", W, To, unit_feature_hidden, 16))
+        chunks += _layer_chunks_bf16(flat, f"r{l}", W, unit_feature_hidden, 16, 0)
     ar = np.arange
     aux = [flat.vec_index("b8", 1 + ar(256))]
     for l in range(D):

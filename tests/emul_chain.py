@@ -242,40 +242,50 @@ def mfma_32x32x16(a, b, c):
     return d
 
 
-def _frag(w, ks):
-    """chunk float array -> (A_hi, A_lo) [64, 8] bf16 values for k-step ks"""
-    raw = np.ascontiguousarray(w[ks * KS_FLOATS:(ks + 1) * KS_FLOATS]).view(np.uint16).reshape(2, 64, 8)
+def _frag(w, kk, T):
+    """chunk float array -> (A_hi, A_lo) [64, 8] bf16 values for k-step kk of the chunk, output tile T"""
+    o = (kk * 8 + T) * 512
+    raw = np.ascontiguousarray(w[o:o + 512]).view(np.uint16).reshape(2, 64, 8)
     f = (raw.astype(np.uint32) << 16).view(np.float32)
     return f[0], f[1]
 
 
-def run_layer_bf16(Xh, Xl, blob, bias, rows, nk, ntiles, act, tangent, scale, last, dots, h7=None):
-    """Xh/Xl: lists of [64, 8] units.  Returns (Yh, Yl) lists of 16 units (None when last)."""
-    Yh, Yl = [None] * 19, [None] * 19
+def run_layer_bf16(Xh, Xl, blob, bias, rows, nu_base, nextra, ntiles, act, tangent, post_mul, last, dots, h7=None):
+    """k-outer: Xh/Xl lists of [64, 8] units, updated in place (units 0..15) unless last."""
     is_val = (LANE & 3) == 0 if tangent else np.ones(64, bool)
-    for T in range(ntiles):
+    r16 = np.arange(16)[None, :]
+    acc = []
+    for T in range(8):
+        feat = 32 * T + (r16 & 3) + 8 * (r16 >> 2) + 4 * H2[:, None]
+        acc.append(np.where(is_val[:, None], bias[feat], 0).astype(np.float32))
+    def kstep(ks, w, kk):
+        for T in range(ntiles):
+            ah, al = _frag(w, kk, T)
+            acc[T] = mfma_32x32x16(ah, Xh[ks], acc[T])
+            acc[T] = mfma_32x32x16(ah, Xl[ks], acc[T])
+            acc[T] = mfma_32x32x16(al, Xh[ks], acc[T])
+    for c0 in range(0, nu_base, 4):
         w = blob.acquire()
-        acc = np.zeros((64, 16), np.float32)
-        for ks in range(nk):
-            ah, al = _frag(w, ks)
-            acc = mfma_32x32x16(ah, Xh[ks], acc)
-            acc = mfma_32x32x16(ah, Xl[ks], acc)
-            acc = mfma_32x32x16(al, Xh[ks], acc)
-        feat = 32 * T + (np.arange(16)[None, :] & 3) + 8 * (np.arange(16)[None, :] >> 2) + 4 * H2[:, None]    # [64,16]
-        b = bias[feat]
-        z = acc + np.where(is_val[:, None], b, 0).astype(np.float32)
+        for kk, ks in enumerate(range(c0, min(c0 + 4, nu_base))):
+            kstep(ks, w, kk)
+    if nextra:
+        w = blob.acquire()
+        for x in range(nextra):
+            kstep(nu_base + x, w, x)
+    for T in range(ntiles):
+        feat = 32 * T + (r16 & 3) + 8 * (r16 >> 2) + 4 * H2[:, None]
+        a = acc[T]
         if act == "softplus":
             if tangent:
-                d = softplus100_grad(z)[LANE & ~3]
-                y = np.where(is_val[:, None], softplus100(z), d * acc).astype(np.float32)
+                d = softplus100_grad(a)[LANE & ~3]
+                y = np.where(is_val[:, None], softplus100(a), d * a).astype(np.float32)
             else:
-                y = softplus100(z)
+                y = softplus100(a)
         elif act == "relu":
-            y = np.maximum(z, 0).astype(np.float32)
+            y = np.maximum(a, 0).astype(np.float32)
         else:
-            y = z.astype(np.float32)
-        if scale:
-            y = (y / np.float32(1.41421356237309504880)).astype(np.float32)
+            y = a.astype(np.float32)
+        y = (y * np.float32(post_mul)).astype(np.float32)
         if last:
             for n in range(len(dots)):
                 dots[n] += (y * rows[n * 256 + feat]).sum(1).astype(np.float32)
@@ -285,9 +295,7 @@ def run_layer_bf16(Xh, Xl, blob, bias, rows, nk, ntiles, act, tangent, scale, la
                         h7[J2[lane] >> 2 if tangent else J2[lane], feat[lane]] = y[lane]
         else:
             for u in range(2):
-                hi, lo = split2(y[:, 8 * u: 8 * u + 8])
-                Yh[2 * T + u], Yl[2 * T + u] = hi, lo
-    return Yh, Yl
+                Xh[2 * T + u], Xl[2 * T + u] = split2(y[:, 8 * u: 8 * u + 8])
 
 
 def encode_units_bf16(p, dq, scale):
@@ -308,7 +316,7 @@ def encode_units_bf16(p, dq, scale):
             m1[:, 6 * k + c] = vs; m1[:, 3 + 6 * k + c] = vc
     m = np.where((H2 == 1)[:, None], m1, m0).astype(np.float32)
     if scale:
-        m = (m / np.float32(1.41421356237309504880)).astype(np.float32)
+        m = (m * np.float32(0.70710678118654752440)).astype(np.float32)
     out = []
     for q in range(3):
         out.append(split2(m[:, 8 * q: 8 * q + 8]))
@@ -321,16 +329,13 @@ def surface_chain_bf16(blob, p, dq, tangent, h7=None):
         Xh[q], Xl[q] = hi, lo
     dots = [np.zeros(64, np.float32)]
     rows = blob.aux[2048:2304]
-    Yh, Yl = run_layer_bf16(Xh, Xl, blob, blob.aux[0:256], rows, 3, 8, "softplus", tangent, False, False, dots)
+    run_layer_bf16(Xh, Xl, blob, blob.aux[0:256], rows, 3, 0, 8, "softplus", tangent, 1.0, False, dots)
     for L in range(1, 8):
-        Xh[:16], Xl[:16] = Yh[:16], Yl[:16]
-        nk = 16
         if L == 4:
             for q, (hi, lo) in enumerate(encode_units_bf16(p, dq, True)):
                 Xh[14 + q], Xl[14 + q] = hi, lo
-            nk = 17
-        Yh, Yl = run_layer_bf16(Xh, Xl, blob, blob.aux[L * 256:(L + 1) * 256], rows, nk, 7 if L == 3 else 8, "softplus",
-                                tangent, L == 3, L == 7, dots, h7 if L == 7 else None)
+        run_layer_bf16(Xh, Xl, blob, blob.aux[L * 256:(L + 1) * 256], rows, 16, 1 if L == 4 else 0, 7 if L == 3 else 8, "softplus",
+                       tangent, 0.70710678118654752440 if L == 3 else 1.0, L == 7, dots, h7 if L == 7 else None)
     d = dots[0]
     return d + d[LANE ^ 32]
 
@@ -389,10 +394,8 @@ def emul_radiance_bf16(blob_np, view_tiles, pts32, view32, nabla32, h7_32):
     dots = [np.zeros(64, np.float32) for _ in range(3)]
     rows = blob.aux[1280:1280 + 768]
     for L in range(5):
-        Yh, Yl = run_layer_bf16(Xh, Xl, blob, blob.aux[L * 256:(L + 1) * 256], rows, 16 + (view_tiles if L == 1 else 0), 8,
-                                "none" if L == 0 else "relu", False, False, L == 4, dots)
-        if L < 4:
-            Xh[:16], Xl[:16] = Yh[:16], Yl[:16]
+        run_layer_bf16(Xh, Xl, blob, blob.aux[L * 256:(L + 1) * 256], rows, 16, view_tiles if L == 1 else 0, 8,
+                       "none" if L == 0 else "relu", False, 1.0, L == 4, dots)
     rgb = np.zeros((32, 3), np.float32)
     for c in range(3):
         z = dots[c] + dots[c][LANE ^ 32] + blob.aux[2048 + c]

@@ -89,11 +89,11 @@ def _blobs_bf16(fw):
 
 def test_bf16_blob_header():
     _, surf, rad, _ = _blobs_bf16("VolSDF")
-    for blob, nc in ((surf, 63), (rad, 40)):
+    for blob, nc in ((surf, 30), (rad, 21)):
         hdr = blob[:512].view(np.int32)
         assert hdr[0] == packing.MAGIC and hdr[2] == nc and hdr[3] == blob.size
         offs = hdr[16:16 + nc + 1]
-        assert set(np.diff(offs).tolist()) <= {3 * 512, 16 * 512, 17 * 512} and offs[-1] == hdr[4]
+        assert set(np.diff(offs).tolist()) <= {4096, 3 * 4096, 4 * 4096} and offs[-1] == hdr[4]
 
 
 def test_emulated_bf16_sdf_only_matches_oracle():
