@@ -64,23 +64,62 @@ __device__ __forceinline__ f32x16 mfma3(const u32x4 ah, const u32x4 al, const u3
 struct Epi {
     const float* bias;     // LDS, natural feature order
     float floor;           // ReLU family: 0 (ReLU) or -inf (no activation)
-    float post_mul;        // 1, or 1/sqrt(2) for the layer feeding the skip connection
     const float* rows;     // LDS: NROWS x 256 weights of the final linear layer (LAST bodies)
     float* h7;             // per-lane destination of the fp32 activations (tangent kernel, LAST body) or null
 };
 
 struct Acc { f32x16 t[8]; };
 
-// one k-step: 8 output tiles x 3 MFMAs; tile 7 is skipped for the 217-wide layer (ntiles == 7)
-__device__ __forceinline__ void mma_kstep(Acc& A, const u32x4 xh, const u32x4 xl, const float* w, bool full8) {
-#pragma unroll
-    for (int T = 0; T < 8; ++T) {
-        if (T < 7 || full8) {
-            const u32x4 ah = *reinterpret_cast<const u32x4*>(w + T * TS_FLOATS);
-            const u32x4 al = *reinterpret_cast<const u32x4*>(w + T * TS_FLOATS + 256);
-            A.t[T] = mfma3(ah, al, xh, xl, A.t[T]);
+// The MFMAs of one weight chunk: NKS k-steps x 8 output tiles, 3 MFMAs each.  The A fragments (two
+// ds_read_b128 per item) are fetched TWO ITEMS AHEAD through a ring of three register pairs.  hipcc cannot be
+// talked into this (it sinks every read back to its use and waits lgkmcnt(0), exposing the LDS latency every 96
+// cycles), so the reads are inline asm and the waits are counted by hand (cdna_hip_programming.md 5.7, form
+// ii: the wait statement names the destinations "+v", which is what orders the MFMAs behind it).  LDS returns
+// in order: with items it, it+1, it+2 outstanding (2 reads each) item it has landed at lgkmcnt(4).
+// (The 217-wide layer simply runs its zero-padded 8th tile: a branch here would break the pipeline.)
+struct Ring { u32x4 h0, l0, h1, l1, h2, l2; };
+
+template <int OFF>
+__device__ __forceinline__ void lds_read_pair(u32x4& fh, u32x4& fl, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
+                 : "=&v"(fh), "=&v"(fl) : "v"(addr), "i"(OFF), "i"(OFF + 1024));
+}
+template <int CNT>
+__device__ __forceinline__ void lds_wait_pair(u32x4& fh, u32x4& fl) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fh), "+v"(fl) : "i"(CNT));
+}
+
+template <int IT, int N>
+struct ChunkSteps {
+    static __device__ __forceinline__ void run(Acc& A, const Act& X, int ks0, unsigned addr, Ring& r) {
+        if constexpr (IT < N) {
+            constexpr int S = IT % 3, S2 = (IT + 2) % 3;
+            if constexpr (IT + 2 < N) {
+                if constexpr (S2 == 0) lds_read_pair<(IT + 2) * 2048>(r.h0, r.l0, addr);
+                else if constexpr (S2 == 1) lds_read_pair<(IT + 2) * 2048>(r.h1, r.l1, addr);
+                else lds_read_pair<(IT + 2) * 2048>(r.h2, r.l2, addr);
+            }
+            constexpr int PENDING = (IT + 2 < N) ? 4 : ((IT + 1 < N) ? 2 : 0);
+            constexpr int kk = IT >> 3, T = IT & 7;
+            if constexpr (S == 0) { lds_wait_pair<PENDING>(r.h0, r.l0); A.t[T] = mfma3(r.h0, r.l0, X.h[ks0 + kk], X.l[ks0 + kk], A.t[T]); }
+            else if constexpr (S == 1) { lds_wait_pair<PENDING>(r.h1, r.l1); A.t[T] = mfma3(r.h1, r.l1, X.h[ks0 + kk], X.l[ks0 + kk], A.t[T]); }
+            else { lds_wait_pair<PENDING>(r.h2, r.l2); A.t[T] = mfma3(r.h2, r.l2, X.h[ks0 + kk], X.l[ks0 + kk], A.t[T]); }
+            ChunkSteps<IT + 1, N>::run(A, X, ks0, addr, r);
         }
     }
+};
+
+template <int NKS>
+__device__ __forceinline__ void chunk_mma(Acc& A, const Act& X, int ks0, const float* w) {
+    constexpr int N = NKS * 8;
+    const unsigned addr = (unsigned)(size_t)w;          // LDS byte address of this lane's 16 bytes of item 0
+    // everything the compiler itself has in flight on the LDS queue must be drained first: the counted waits
+    // below assume only these reads are outstanding
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    Ring r;
+    lds_read_pair<0>(r.h0, r.l0, addr);
+    if constexpr (N > 1) lds_read_pair<2048>(r.h1, r.l1, addr);
+    ChunkSteps<0, N>::run(A, X, ks0, addr, r);
 }
 
 // Epilogue of output tile T, pair P (registers 2P, 2P+1): activation, then either the next layer's
@@ -105,7 +144,6 @@ __device__ __forceinline__ void epi_pair(const f32x16& acc, const Epi& e, Act& X
         } else {
             y[k] = fmaxf(a, e.floor);
         }
-        y[k] *= e.post_mul;
     }
     if (LAST) {
 #pragma unroll
@@ -144,7 +182,7 @@ __device__ __forceinline__ void run_layer(Act& X, Pipe& p, const Epi& e, float (
     const int lane = lane_id();
     const int h = lane >> 5;
     const bool is_val = !TANGENT || ((lane & 3) == 0);
-    const bool full8 = (ntiles == 8);
+    (void)ntiles;
     Acc A;
 #pragma unroll
     for (int T = 0; T < 8; ++T) {
@@ -160,18 +198,15 @@ __device__ __forceinline__ void run_layer(Act& X, Pipe& p, const Epi& e, float (
 #pragma unroll
     for (int c = 0; c < (NU_BASE + CHUNK_KS - 1) / CHUNK_KS; ++c) {
         const float* w = pipe_acquire(p) + lane * 4;
-#pragma unroll
-        for (int kk = 0; kk < CHUNK_KS; ++kk) {
-            const int ks = c * CHUNK_KS + kk;
-            if (ks < NU_BASE) mma_kstep(A, X.h[ks], X.l[ks], w + kk * KS_FLOATS, full8);
-        }
+        constexpr int REM = NU_BASE % CHUNK_KS;
+        if (REM != 0 && c == NU_BASE / CHUNK_KS) chunk_mma<(REM ? REM : 1)>(A, X, c * CHUNK_KS, w);
+        else chunk_mma<CHUNK_KS>(A, X, c * CHUNK_KS, w);
     }
     if (NU_EXTRA_MAX > 0) {
         if (nextra > 0) {
             const float* w = pipe_acquire(p) + lane * 4;
-#pragma unroll
-            for (int x = 0; x < NU_EXTRA_MAX; ++x)
-                if (x < nextra) mma_kstep(A, X.h[NU_BASE + x], X.l[NU_BASE + x], w + x * KS_FLOATS, full8);
+            if (NU_EXTRA_MAX == 1 || nextra == 1) chunk_mma<1>(A, X, NU_BASE, w);
+            else chunk_mma<(NU_EXTRA_MAX > 1 ? NU_EXTRA_MAX : 1)>(A, X, NU_BASE, w);
         }
     }
     epi_tile<0, SOFTPLUS, TANGENT, LAST, NROWS>(A.t[0], e, X, dot, h, is_val);
@@ -188,7 +223,7 @@ __device__ __forceinline__ void run_layer(Act& X, Pipe& p, const Epi& e, float (
     __builtin_amdgcn_sched_barrier(0);
     epi_tile<6, SOFTPLUS, TANGENT, LAST, NROWS>(A.t[6], e, X, dot, h, is_val);
     __builtin_amdgcn_sched_barrier(0);
-    if (full8) epi_tile<7, SOFTPLUS, TANGENT, LAST, NROWS>(A.t[7], e, X, dot, h, is_val);
+    epi_tile<7, SOFTPLUS, TANGENT, LAST, NROWS>(A.t[7], e, X, dot, h, is_val);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -254,18 +289,17 @@ template <bool TANGENT>
 __device__ __forceinline__ float surface_chain(Act& X, float px, float py, float pz, int h, int dq, Pipe& p,
                                                const float* aux, float* h7_lane) {
     float dot[1] = {0.f};
-    Epi e{aux, 0.f, 1.f, aux + SURF_AUX_ROW, h7_lane};
+    Epi e{aux, 0.f, aux + SURF_AUX_ROW, h7_lane};
     encode_units(px, py, pz, h, dq, false, X, 0);
     run_layer<3, 0, true, TANGENT, false, 1>(X, p, e, dot, 8, 0);
 #pragma nounroll
     for (int L = 1; L < 7; ++L) {
-        if (L == 4) encode_units(px, py, pz, h, dq, true, X, 14);       // skip: cat[h(217), enc(39)] / sqrt(2)
+        // skip: cat[h(217), enc(39)] / sqrt(2) - the 1/sqrt(2) is folded into layer 4's packed weights
+        if (L == 4) encode_units(px, py, pz, h, dq, false, X, 14);
         e.bias = aux + L * 256;
-        e.post_mul = (L == 3) ? 0.70710678118654752440f : 1.f;
         run_layer<16, 1, true, TANGENT, false, 1>(X, p, e, dot, (L == 3) ? 7 : 8, (L == 4) ? 1 : 0);
     }
     e.bias = aux + 7 * 256;
-    e.post_mul = 1.f;
     run_layer<16, 0, true, TANGENT, true, 1>(X, p, e, dot, 8, 0);
     // the two halves of a column hold complementary feature sets
     return dot[0] + __shfl_xor(dot[0], 32, 64);
@@ -422,7 +456,7 @@ k_radiance_bf16(const float* __restrict__ blob, PointSrc src, const float* __res
         }
         radiance_extras<VE>(pt, nx, ny, nz, h, X);
         float dot[3] = {0.f, 0.f, 0.f};
-        Epi e{aux, -INFINITY, 1.f, aux + RAD_AUX_ROWS, nullptr};
+        Epi e{aux, -INFINITY, aux + RAD_AUX_ROWS, nullptr};
         // L = 0: geometry feature (no activation); L = 1: [feat | x, v, n] -> 256 ReLU; L = 2, 3: ReLU; L = 4: LAST
 #pragma nounroll
         for (int L = 0; L < 4; ++L) {

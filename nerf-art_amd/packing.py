@@ -316,7 +316,9 @@ class PackPlanBF16(PackPlan):
         dev = tensors[self.flat.names[0]].device
         for n in self.flat.names:
             assert tuple(tensors[n].shape) == self.flat.shape[n], n
-        parts = [tensors[n].detach().reshape(-1).to(torch.float32) for n in self.flat.names]
+        scale = getattr(self, "scale", {})
+        parts = [(tensors[n].detach().to(torch.float32) * scale[n] if n in scale else tensors[n].detach().to(torch.float32)).reshape(-1)
+                 for n in self.flat.names]
         parts.append(torch.zeros(1, dtype=torch.float32, device=dev))
         src = torch.cat(parts)
         key = str(dev)
@@ -367,7 +369,10 @@ def surface_plan_bf16(W: int = 256, D: int = 8, skips=(4,), multires: int = 6, W
     aux.append(flat.vec_index(f"b{D}", _pad(np.array([0]), 4)))
     aux = np.concatenate(aux)
     assert len(aux) == SURF_AUX_FLOATS
-    return PackPlanBF16(PROG_SURFACE_BF16, flat, chunks, aux)
+    plan = PackPlanBF16(PROG_SURFACE_BF16, flat, chunks, aux)
+    # cat[h, enc] / sqrt(2) (base.py:250) is applied to the skip layer's weights instead of its inputs
+    plan.scale = {f"w{l}": 1.0 / float(np.sqrt(2.0)) for l in skips}
+    return plan
 
 
 def radiance_plan_bf16(view_tiles: int, W: int = 256, D: int = 4, W_geo_feat: int = 256) -> PackPlanBF16:

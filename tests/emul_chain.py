@@ -331,11 +331,11 @@ def surface_chain_bf16(blob, p, dq, tangent, h7=None):
     rows = blob.aux[2048:2304]
     run_layer_bf16(Xh, Xl, blob, blob.aux[0:256], rows, 3, 0, 8, "softplus", tangent, 1.0, False, dots)
     for L in range(1, 8):
-        if L == 4:
-            for q, (hi, lo) in enumerate(encode_units_bf16(p, dq, True)):
+        if L == 4:          # 1/sqrt(2) of the skip concat lives in layer 4's packed weights
+            for q, (hi, lo) in enumerate(encode_units_bf16(p, dq, False)):
                 Xh[14 + q], Xl[14 + q] = hi, lo
-        run_layer_bf16(Xh, Xl, blob, blob.aux[L * 256:(L + 1) * 256], rows, 16, 1 if L == 4 else 0, 7 if L == 3 else 8, "softplus",
-                       tangent, 0.70710678118654752440 if L == 3 else 1.0, L == 7, dots, h7 if L == 7 else None)
+        run_layer_bf16(Xh, Xl, blob, blob.aux[L * 256:(L + 1) * 256], rows, 16, 1 if L == 4 else 0, 8, "softplus",
+                       tangent, 1.0, L == 7, dots, h7 if L == 7 else None)
     d = dots[0]
     return d + d[LANE ^ 32]
 
