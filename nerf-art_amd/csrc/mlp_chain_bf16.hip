@@ -54,6 +54,10 @@ __device__ __forceinline__ void split2(float y0, float y1, unsigned& hi, unsigne
     lo = pack_bf16(y0 - h0, y1 - h1);
 }
 __device__ __forceinline__ f32x16 mfma3(const u32x4 ah, const u32x4 al, const u32x4 bh, const u32x4 bl, f32x16 acc) {
+#ifdef NERFART_ABLATE_MFMA      // timing experiments only: keep the operands live, skip the matrix work
+    asm volatile("" :: "v"(ah), "v"(al), "v"(bh), "v"(bl));
+    return acc;
+#endif
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), acc, 0, 0, 0);
@@ -128,6 +132,11 @@ template <int T, int P, bool SOFTPLUS, bool TANGENT, bool LAST, int NROWS>
 __device__ __forceinline__ void epi_pair(const f32x16& acc, const Epi& e, Act& X, float (&dot)[NROWS], int h, bool is_val) {
     constexpr int g = P >> 1, c = 2 * (P & 1);                 // feature = 32T + 8g + 4h + c + {0,1}
     const int fo = 32 * T + 8 * g + 4 * h;
+#ifdef NERFART_ABLATE_EPI       // timing experiments only: no activation / split arithmetic
+    if (!LAST) { X.h[2 * T + (P >> 2)][P & 3] = __float_as_uint(acc[2 * P]); X.l[2 * T + (P >> 2)][P & 3] = __float_as_uint(acc[2 * P + 1]); }
+    else dot[0] += acc[2 * P] + acc[2 * P + 1];
+    return;
+#endif
     float y[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {

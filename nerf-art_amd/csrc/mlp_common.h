@@ -66,8 +66,12 @@ __device__ __forceinline__ void pipe_issue_range(const PipeT<NWAVES, CHUNK_FLOAT
     const int npieces = (o1 - o0) >> 8;                       // 1 KiB (256 floats) per wave-instruction
     const float* src = p.blob + o0 + lane_id() * 4;
     const unsigned dst = lds_addr(p.lds + buf * CHUNK_FLOATS);
+#ifndef NERFART_ABLATE_DMA      // timing experiments only (tools/ablate_bf16.sh): skip the weight stream
     for (int q = wave_id(); q < npieces; q += NWAVES)
         glds16(src + q * 256, __builtin_amdgcn_readfirstlane(dst + q * 1024));
+#else
+    (void)src; (void)dst; (void)npieces;
+#endif
 }
 
 template <int NWAVES, int CHUNK_FLOATS>

@@ -1,0 +1,48 @@
+#!/usr/bin/env python
+"""Timing ablation of k_sdf_only_bf16: builds variant libraries with one component compiled out
+(weight DMA / epilogue / MFMA) and times nerfart_sdf_fwd on 4M points with each.  Results are WRONG by
+construction - this only attributes time.   build:  python tools/ablate_bf16.py build ;  run (GPU): ... run"""
+import os, subprocess, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "nerf-art_amd", "csrc")
+VARIANTS = {"full": [], "nodma": ["-DNERFART_ABLATE_DMA"], "noepi": ["-DNERFART_ABLATE_EPI"], "nomfma": ["-DNERFART_ABLATE_MFMA"],
+            "nodma_noepi": ["-DNERFART_ABLATE_DMA", "-DNERFART_ABLATE_EPI"]}
+OUT = os.path.join(ROOT, "gpurun_ablate")
+
+def build():
+    os.makedirs(OUT, exist_ok=True)
+    srcs = ["capi_common.cpp", "mlp_chain.hip", "mlp_chain_bf16.hip", "volsdf_render.hip", "neus_render.hip", "raygen.hip"]
+    for name, flags in VARIANTS.items():
+        lib = os.path.join(OUT, f"lib_{name}.so")
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip"] + flags + \
+              [os.path.join(CSRC, s) for s in srcs] + ["-o", lib]
+        print(" ".join(cmd[-3:]), flush=True)
+        subprocess.check_call(cmd)
+
+def run():
+    import json
+    res = {}
+    for name in VARIANTS:
+        env = dict(os.environ, NERFART_HIP_LIB=os.path.join(OUT, f"lib_{name}.so"))
+        code = r'''
+import sys, time, torch
+sys.path.insert(0, %r)
+from nerfart_amd import scene, hip
+m, rk, fn = scene.build_model("VolSDF", device="cuda", precision="bf16x3")
+blob, _ = m.packed()
+pts = torch.rand(4*1024*1024, 3, device="cuda") * 4 - 2
+for _ in range(2): hip.sdf_fwd(blob, pts, 3.0, precision=1)
+torch.cuda.synchronize(); t = time.perf_counter()
+for _ in range(5): hip.sdf_fwd(blob, pts, 3.0, precision=1)
+torch.cuda.synchronize(); print((time.perf_counter() - t) / 5 * 1e3)
+''' % ROOT
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+        try:
+            res[name] = float(out.stdout.strip().splitlines()[-1])
+        except Exception:
+            res[name] = out.stderr[-300:]
+        print(name, res[name], flush=True)
+    print(json.dumps(res))
+
+if __name__ == "__main__":
+    {"build": build, "run": run}[sys.argv[1]]()
