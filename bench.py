@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--beta", type=float, default=0.01)
     ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
-                    help="fp32: exact v_mfma_f32_16x16x4_f32; bf16x3: split-bf16 operands on v_mfma_f32_32x32x16_bf16")
+                    help="fp32: exact v_mfma_f32_16x16x4_f32; bf16x3: split-bf16 operands on v_mfma_f32_16x16x32_bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=768)
     args = ap.parse_args()

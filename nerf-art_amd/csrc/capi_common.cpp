@@ -24,19 +24,19 @@ bool profile_enabled() { return g_prof_on; }
 void profile_open(int cls, long long units, hipStream_t s, void** handle) {
     ProfRec r{cls, units, nullptr, nullptr};
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { *handle = nullptr; return; }
-    hipEventRecord(r.a, s);
+    (void)hipEventRecord(r.a, s);
     g_prof.push_back(r);
     *handle = (void*)(size_t)g_prof.size();
 }
 void profile_close(void* handle, hipStream_t s) {
     if (!handle) return;
-    hipEventRecord(g_prof[(size_t)handle - 1].b, s);
+    (void)hipEventRecord(g_prof[(size_t)handle - 1].b, s);
 }
 }  // namespace nerfart
 
 extern "C" {
 int nerfart_profile_begin(void) {
-    for (auto& r : nerfart::g_prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    for (auto& r : nerfart::g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     nerfart::g_prof.clear();
     nerfart::g_prof_on = true;
     return 0;
@@ -50,7 +50,7 @@ int nerfart_profile_end(double* ms, long long* launches, long long* units) {
         if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess && r.cls >= 0 && r.cls < 3) {
             ms[r.cls] += t; launches[r.cls] += 1; units[r.cls] += r.units;
         }
-        hipEventDestroy(r.a); hipEventDestroy(r.b);
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
     }
     nerfart::g_prof.clear();
     return 0;

@@ -122,7 +122,7 @@ class _PackedModel(nn.Module):
 
     def set_precision(self, precision: str):
         """'fp32'  : v_mfma_f32_16x16x4_f32, exact fp32 FMA chains (157 TFLOP/s peak);
-        'bf16x3': operands split hi+lo in bf16, 3 x v_mfma_f32_32x32x16_bf16 per k-step, fp32 accumulate
+        'bf16x3': operands split hi+lo in bf16, 3 x v_mfma_f32_16x16x32_bf16 per k-step, fp32 accumulate
                   (~2^-16 relative per product, 5.3x the fp32 MFMA rate)."""
         if precision not in hip.PRECISIONS:
             raise ValueError(f"precision must be one of {list(hip.PRECISIONS)}")

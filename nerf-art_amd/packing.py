@@ -241,49 +241,55 @@ PROG_RADIANCE_BF16 = 4
 TS_FLOATS = 512           # one (k-step, output tile) of a chunk: (hi, lo) x 64 lanes x 8 bf16 = 2 KiB
 
 
-def unit_feature_hidden(ks: int, h: int, e: int) -> int:
-    """Slot (k-step ks, lane half h, element e) of a hidden-layer input -> feature index.  The C layout of
-    v_mfma_f32_32x32x16_bf16 puts row (r&3) + 8(r>>2) + 4h in register r; registers 8u..8u+7 of output tile T
-    are unit 2T+u of the next layer."""
-    T, u = ks >> 1, ks & 1
-    r = 8 * u + e
-    return 32 * T + (r & 3) + 8 * (r >> 2) + 4 * h
+def unit_feature_hidden(ks: int, g: int, e: int) -> int:
+    """Slot (k-step = unit ks, lane group g, element e) of a hidden-layer input -> feature index.  The C layout of
+    v_mfma_f32_16x16x32_bf16 puts row 4g + r of output tile T in register r; unit U of the next layer's input
+    is (tile 2U regs 0..3, tile 2U+1 regs 0..3)."""
+    return 32 * ks + (4 * g + e if e < 4 else 16 + 4 * g + (e - 4))
 
 
-def unit_feature_enc(q: int, h: int, e: int) -> int:
-    """Slot of the 3 positional-encoding units -> reference feature (0..38) or -1: half 0 holds features 0..20
-    (x, y, z, bands 0..2), half 1 features 21..38 (bands 3..5), both in the reference's own order."""
+def unit_feature_enc(q: int, g: int, e: int) -> int:
+    """Slot of the 2 positional-encoding units -> reference feature (0..38) or -1.  Lane group g < 3 owns
+    coordinate g: local index m = 8q + e: 0 raw, 1 + 2k sin(2^k x_g), 2 + 2k cos(2^k x_g) (k < 6); group 3 pads."""
     m = 8 * q + e
-    if h == 0:
-        return m if m < 21 else -1
-    return 21 + m if m < 18 else -1
+    if g >= 3 or m > 12:
+        return -1
+    if m == 0:
+        return g
+    k, is_cos = divmod(m - 1, 2)
+    return 3 + 6 * k + 3 * is_cos + g
 
 
-def unit_feature_extra(q: int, h: int, e: int, n_extra: int) -> int:
-    m = 16 * q + 8 * h + e
+def unit_feature_extra(q: int, g: int, e: int, n_extra: int) -> int:
+    m = 32 * q + 8 * g + e
     return m if m < n_extra else -1
 
 
 def _kstep_index(flat, name, out_dim, ks, cols_fn, row0=0):
-    """Index array [T=8][lane=64][e=8] of one k-step: W[row0 + 32T + i][cols_fn(ks, h, e)] (rows >= out_dim: zero)."""
+    """Index array [T=16][lane=64][e=8] of one k-step: W[row0 + 16T + i][cols_fn(ks, g, e)], lane = 16g + i
+    (rows >= out_dim: zero)."""
     R, C = flat.shape[name]
-    idx = np.full((8, 64, 8), flat.zero, dtype=np.int64)
-    i = np.arange(32)
-    for T in range(8):
-        rows = 32 * T + i
+    idx = np.full((16, 64, 8), flat.zero, dtype=np.int64)
+    i = np.arange(16)
+    for T in range(16):
+        rows = 16 * T + i
         ok = rows < out_dim
-        for h in range(2):
+        for g in range(4):
             for e in range(8):
-                c = cols_fn(ks, h, e)
+                c = cols_fn(ks, g, e)
                 if c < 0:
                     continue
-                idx[T, (32 * h + i)[ok], e] = flat.base[name] + (row0 + rows[ok]) * C + c
+                idx[T, (16 * g + i)[ok], e] = flat.base[name] + (row0 + rows[ok]) * C + c
     return idx.reshape(-1)
 
 
-def _layer_chunks_bf16(flat, name, out_dim, cols_fn, nu_base, nu_extra, row0=0, chunk_ks=4):
-    """ceil(nu_base/4) chunks of base k-steps, then one chunk with the extra k-steps (matches run_layer in
+CHUNK_KS = 2              # k-steps per chunk (64 KiB)
+
+
+def _layer_chunks_bf16(flat, name, out_dim, cols_fn, nu_base, nu_extra, row0=0, chunk_ks=CHUNK_KS):
+    """ceil(nu_base/2) chunks of base k-steps, then one chunk with the (<= 2) extra k-steps (matches run_layer in
     mlp_chain_bf16.hip)."""
+    assert nu_extra <= chunk_ks
     chunks = []
     for c0 in range(0, nu_base, chunk_ks):
         chunks.append(np.concatenate([_kstep_index(flat, name, out_dim, ks, cols_fn, row0) for ks in range(c0, min(c0 + chunk_ks, nu_base))]))
@@ -293,7 +299,7 @@ def _layer_chunks_bf16(flat, name, out_dim, cols_fn, nu_base, nu_extra, row0=0, 
 
 
 class PackPlanBF16(PackPlan):
-    """Chunks hold bf16 hi/lo fragments, k-outer: float[k-step][T=8][term=2][lane=64][4] (= 8 bf16 per lane)."""
+    """Chunks hold bf16 hi/lo fragments, k-outer: float[k-step][T=16][term=2][lane=64][4] (= 8 bf16 per lane)."""
 
     def __init__(self, prog, flat, chunk_indices, aux):
         self.prog, self.flat = prog, flat
@@ -349,20 +355,22 @@ def surface_plan_bf16(W: int = 256, D: int = 8, skips=(4,), multires: int = 6, W
     for l in range(D):
         out_dim, in_dim = dims[l]
         if l == 0:
-            chunks += _layer_chunks_bf16(flat, f"w{l}", out_dim, unit_feature_enc, 3, 0)
+            chunks += _layer_chunks_bf16(flat, f"w{l}", out_dim, unit_feature_enc, 2, 0)
         elif l in skips:
-            def fn(ks, h, e, hw=hw):
-                if ks < 14:
-                    f = unit_feature_hidden(ks, h, e)
+            # input = 7 hidden units (217 features), then the 2 encoding units (the first one closes the base
+            # chunks, the second is the extra chunk)
+            def fn(ks, g, e, hw=hw):
+                if ks < 7:
+                    f = unit_feature_hidden(ks, g, e)
                     return f if f < hw else -1
-                f = unit_feature_enc(ks - 14, h, e)
+                f = unit_feature_enc(ks - 7, g, e)
                 return hw + f if f >= 0 else -1
-            chunks += _layer_chunks_bf16(flat, f"w{l}", out_dim, fn, 16, 1)
+            chunks += _layer_chunks_bf16(flat, f"w{l}", out_dim, fn, 8, 1)
         else:
-            def fn(ks, h, e, in_dim=in_dim):
-                f = unit_feature_hidden(ks, h, e)
+            def fn(ks, g, e, in_dim=in_dim):
+                f = unit_feature_hidden(ks, g, e)
                 return f if f < in_dim else -1
-            chunks += _layer_chunks_bf16(flat, f"w{l}", out_dim, fn, 16, 0)
+            chunks += _layer_chunks_bf16(flat, f"w{l}", out_dim, fn, 8, 0)
     ar = np.arange
     aux = [flat.vec_index(f"b{l}", _pad(ar(dims[l][0]), 256)) for l in range(D)]
     aux.append(flat.mat_index(f"w{D}", np.array([0]), ar(256)).reshape(-1))
@@ -386,15 +394,16 @@ def radiance_plan_bf16(view_tiles: int, W: int = 256, D: int = 4, W_geo_feat: in
     for l, (o, i) in enumerate(rdims):
         flat.add(f"r{l}", (o, i)); flat.add(f"rb{l}", (o,))
     # layer A: feat = W8[1:257] h7  (rows 1.. of w8)
-    chunks = _layer_chunks_bf16(flat, "w8", 256, unit_feature_hidden, 16, 0, row0=1)
+    chunks = _layer_chunks_bf16(flat, "w8", 256, unit_feature_hidden, 8, 0, row0=1)
+    extra_units = 1 if view_tiles == 1 else 2
 
-    def fn0(ks, h, e):
-        if ks < 16:
-            return n_extra + unit_feature_hidden(ks, h, e)
-        return unit_feature_extra(ks - 16, h, e, n_extra)
-    chunks += _layer_chunks_bf16(flat, "r0", W, fn0, 16, view_tiles)
+    def fn0(ks, g, e):
+        if ks < 8:
+            return n_extra + unit_feature_hidden(ks, g, e)
+        return unit_feature_extra(ks - 8, g, e, n_extra)
+    chunks += _layer_chunks_bf16(flat, "r0", W, fn0, 8, extra_units)
     for l in range(1, D):
-        chunks += _layer_chunks_bf16(flat, f"r{l}", W, unit_feature_hidden, 16, 0)
+        chunks += _layer_chunks_bf16(flat, f"r{l}", W, unit_feature_hidden, 8, 0)
     ar = np.arange
     aux = [flat.vec_index("b8", 1 + ar(256))]
     for l in range(D):

@@ -210,12 +210,12 @@ def emul_radiance(blob_np, view_tiles, pts16, view16, nabla16, h7_16):
 
 
 # ======================================================================================================
-# Software model of csrc/mlp_chain_bf16.hip (split-bf16 "bf16x3", v_mfma_f32_32x32x16_bf16 layouts)
+# Software model of csrc/mlp_chain_bf16.hip (split-bf16 "bf16x3", v_mfma_f32_16x16x32_bf16 layouts).
+# One call emulates one wave: 16 columns, lane = 16 g + j.
 # ======================================================================================================
 import torch as _torch
 
-H2, J2 = LANE // 32, LANE % 32
-KS_FLOATS = 512
+TS_FLOATS = 512
 
 
 def _bf16(x):
@@ -228,52 +228,53 @@ def split2(x):
     return hi, lo
 
 
-def mfma_32x32x16(a, b, c):
-    """a, b: [64 lanes, 8] (bf16 values as float32); c: [64, 16].  Slot (h, e) of A pairs with slot (h, e) of B;
-    C register r of lane (h, j) is row (r&3) + 8(r>>2) + 4h, column j."""
-    A = np.zeros((32, 16), np.float64); B = np.zeros((16, 32), np.float64)
+def mfma_16x16x32(a, b, c):
+    """a, b: [64 lanes, 8] (bf16 values as float32); c: [64, 4].  Slot (g, e) of A (lane 16g + i = row i) pairs
+    with slot (g, e) of B (lane 16g + j = column j); C register r of lane (g, j) is row 4g + r, column j."""
+    A = np.zeros((16, 32), np.float64); B = np.zeros((32, 16), np.float64)
     for e in range(8):
-        A[J2, 8 * H2 + e] = a[:, e]
-        B[8 * H2 + e, J2] = b[:, e]
+        A[J, 8 * G + e] = a[:, e]
+        B[8 * G + e, J] = b[:, e]
     Cm = A @ B
     d = c.copy()
-    for r in range(16):
-        d[:, r] = (d[:, r].astype(np.float64) + Cm[(r & 3) + 8 * (r >> 2) + 4 * H2, J2]).astype(np.float32)
+    for r in range(4):
+        d[:, r] = (d[:, r].astype(np.float64) + Cm[4 * G + r, J]).astype(np.float32)
     return d
 
 
 def _frag(w, kk, T):
     """chunk float array -> (A_hi, A_lo) [64, 8] bf16 values for k-step kk of the chunk, output tile T"""
-    o = (kk * 8 + T) * 512
-    raw = np.ascontiguousarray(w[o:o + 512]).view(np.uint16).reshape(2, 64, 8)
+    o = (kk * 16 + T) * TS_FLOATS
+    raw = np.ascontiguousarray(w[o:o + TS_FLOATS]).view(np.uint16).reshape(2, 64, 8)
     f = (raw.astype(np.uint32) << 16).view(np.float32)
     return f[0], f[1]
 
 
-def run_layer_bf16(Xh, Xl, blob, bias, rows, nu_base, nextra, ntiles, act, tangent, post_mul, last, dots, h7=None):
-    """k-outer: Xh/Xl lists of [64, 8] units, updated in place (units 0..15) unless last."""
+def _tile_feat(T):
+    return 16 * T + 4 * G[:, None] + np.arange(4)[None, :]          # [64, 4]
+
+
+def run_layer_bf16(Xh, Xl, blob, bias, rows, nu_base, nextra, act, tangent, last, dots, h7=None):
+    """k-outer: Xh/Xl lists of [64, 8] units, updated in place (units 0..7) unless last."""
     is_val = (LANE & 3) == 0 if tangent else np.ones(64, bool)
-    r16 = np.arange(16)[None, :]
-    acc = []
-    for T in range(8):
-        feat = 32 * T + (r16 & 3) + 8 * (r16 >> 2) + 4 * H2[:, None]
-        acc.append(np.where(is_val[:, None], bias[feat], 0).astype(np.float32))
+    acc = [np.where(is_val[:, None], bias[_tile_feat(T)], 0).astype(np.float32) for T in range(16)]
+
     def kstep(ks, w, kk):
-        for T in range(ntiles):
+        for T in range(16):
             ah, al = _frag(w, kk, T)
-            acc[T] = mfma_32x32x16(ah, Xh[ks], acc[T])
-            acc[T] = mfma_32x32x16(ah, Xl[ks], acc[T])
-            acc[T] = mfma_32x32x16(al, Xh[ks], acc[T])
-    for c0 in range(0, nu_base, 4):
+            acc[T] = mfma_16x16x32(ah, Xh[ks], acc[T])
+            acc[T] = mfma_16x16x32(ah, Xl[ks], acc[T])
+            acc[T] = mfma_16x16x32(al, Xh[ks], acc[T])
+    for c0 in range(0, nu_base, 2):
         w = blob.acquire()
-        for kk, ks in enumerate(range(c0, min(c0 + 4, nu_base))):
+        for kk, ks in enumerate(range(c0, min(c0 + 2, nu_base))):
             kstep(ks, w, kk)
     if nextra:
         w = blob.acquire()
         for x in range(nextra):
             kstep(nu_base + x, w, x)
-    for T in range(ntiles):
-        feat = 32 * T + (r16 & 3) + 8 * (r16 >> 2) + 4 * H2[:, None]
+    Y = []
+    for T in range(16):
         a = acc[T]
         if act == "softplus":
             if tangent:
@@ -285,78 +286,74 @@ def run_layer_bf16(Xh, Xl, blob, bias, rows, nu_base, nextra, ntiles, act, tange
             y = np.maximum(a, 0).astype(np.float32)
         else:
             y = a.astype(np.float32)
-        y = (y * np.float32(post_mul)).astype(np.float32)
-        if last:
+        Y.append(y)
+    if last:
+        for T in range(16):
+            feat = _tile_feat(T)
             for n in range(len(dots)):
-                dots[n] += (y * rows[n * 256 + feat]).sum(1).astype(np.float32)
+                dots[n] += (Y[T] * rows[n * 256 + feat]).sum(1).astype(np.float32)
             if h7 is not None:
                 for lane in range(64):
                     if is_val[lane]:
-                        h7[J2[lane] >> 2 if tangent else J2[lane], feat[lane]] = y[lane]
-        else:
-            for u in range(2):
-                Xh[2 * T + u], Xl[2 * T + u] = split2(y[:, 8 * u: 8 * u + 8])
+                        h7[J[lane] >> 2 if tangent else J[lane], feat[lane]] = Y[T][lane]
+    else:
+        for U in range(8):
+            Xh[U], Xl[U] = split2(np.concatenate([Y[2 * U], Y[2 * U + 1]], axis=1))
 
 
-def encode_units_bf16(p, dq, scale):
-    x, y, z = p[:, 0], p[:, 1], p[:, 2]
-    co = [x, y, z]
-    m0 = np.zeros((64, 24), np.float32); m1 = np.zeros((64, 24), np.float32)
+def encode_units_bf16(p, dq):
+    """2 units of [64, 8]: lane group g < 3 owns coordinate g; m = 8q + e: 0 raw, 1 + 2k sin, 2 + 2k cos (k < 6)."""
+    cg = np.where(G == 0, p[:, 0], np.where(G == 1, p[:, 1], p[:, 2])).astype(np.float32)
     val = dq < 0
-    fb = np.where(H2 == 1, 8.0, 1.0).astype(np.float32)
-    for c in range(3):
-        m0[:, c] = np.where(val, co[c], (dq == c).astype(np.float32))
-    for k in range(3):
-        f = fb * np.float32(1 << k)
-        for c in range(3):
-            s = np.sin(co[c] * f, dtype=np.float32); cs = np.cos(co[c] * f, dtype=np.float32)
-            vs = np.where(val, s, np.where(dq == c, cs * f, 0.0)).astype(np.float32)
-            vc = np.where(val, cs, np.where(dq == c, -(s * f), 0.0)).astype(np.float32)
-            m0[:, 3 + 6 * k + c] = vs; m0[:, 6 + 6 * k + c] = vc
-            m1[:, 6 * k + c] = vs; m1[:, 3 + 6 * k + c] = vc
-    m = np.where((H2 == 1)[:, None], m1, m0).astype(np.float32)
-    if scale:
-        m = (m * np.float32(0.70710678118654752440)).astype(np.float32)
-    out = []
-    for q in range(3):
-        out.append(split2(m[:, 8 * q: 8 * q + 8]))
-    return out
+    own = dq == G
+    m = np.zeros((64, 16), np.float32)
+    m[:, 0] = np.where(val, cg, own.astype(np.float32))
+    for k in range(6):
+        f = np.float32(1 << k)
+        s = np.sin(cg * f, dtype=np.float32); c = np.cos(cg * f, dtype=np.float32)
+        m[:, 1 + 2 * k] = np.where(val, s, np.where(own, c * f, 0.0))
+        m[:, 2 + 2 * k] = np.where(val, c, np.where(own, -(s * f), 0.0))
+    m[G == 3] = 0
+    return [split2(m[:, 8 * q: 8 * q + 8]) for q in range(2)]
+
+
+def _group_sum(d):
+    return d.reshape(4, 16).sum(0)[J]
 
 
 def surface_chain_bf16(blob, p, dq, tangent, h7=None):
-    Xh, Xl = [None] * 19, [None] * 19
-    for q, (hi, lo) in enumerate(encode_units_bf16(p, dq, False)):
+    Xh, Xl = [None] * 10, [None] * 10
+    for q, (hi, lo) in enumerate(encode_units_bf16(p, dq)):
         Xh[q], Xl[q] = hi, lo
     dots = [np.zeros(64, np.float32)]
     rows = blob.aux[2048:2304]
-    run_layer_bf16(Xh, Xl, blob, blob.aux[0:256], rows, 3, 0, 8, "softplus", tangent, 1.0, False, dots)
+    run_layer_bf16(Xh, Xl, blob, blob.aux[0:256], rows, 2, 0, "softplus", tangent, False, dots)
     for L in range(1, 8):
         if L == 4:          # 1/sqrt(2) of the skip concat lives in layer 4's packed weights
-            for q, (hi, lo) in enumerate(encode_units_bf16(p, dq, False)):
-                Xh[14 + q], Xl[14 + q] = hi, lo
-        run_layer_bf16(Xh, Xl, blob, blob.aux[L * 256:(L + 1) * 256], rows, 16, 1 if L == 4 else 0, 8, "softplus",
-                       tangent, 1.0, L == 7, dots, h7 if L == 7 else None)
-    d = dots[0]
-    return d + d[LANE ^ 32]
+            for q, (hi, lo) in enumerate(encode_units_bf16(p, dq)):
+                Xh[7 + q], Xl[7 + q] = hi, lo
+        run_layer_bf16(Xh, Xl, blob, blob.aux[L * 256:(L + 1) * 256], rows, 8, 1 if L == 4 else 0, "softplus",
+                       tangent, L == 7, dots, h7 if L == 7 else None)
+    return _group_sum(dots[0])
 
 
-def emul_sdf_only_bf16(blob_np, pts32, R_bg):
+def emul_sdf_only_bf16(blob_np, pts16, R_bg):
     blob = Blob(blob_np)
-    p = pts32[J2].astype(np.float32)
+    p = pts16[J].astype(np.float32)
     sdf = surface_chain_bf16(blob, p, np.full(64, -1), False) + blob.aux[2304]
     if R_bg > 0:
         sdf = np.minimum(sdf, R_bg - np.sqrt((p ** 2).sum(1)))
-    return sdf[:32]
+    return sdf[:16]
 
 
-def emul_sdf_nabla_bf16(blob_np, pts8, R_bg):
+def emul_sdf_nabla_bf16(blob_np, pts4, R_bg):
     blob = Blob(blob_np)
-    p = pts8[J2 >> 2].astype(np.float32)
-    cq = J2 & 3
-    h7 = np.zeros((8, 256), np.float32)
+    p = pts4[J >> 2].astype(np.float32)
+    cq = J & 3
+    h7 = np.zeros((4, 256), np.float32)
     v = surface_chain_bf16(blob, p, cq - 1, True, h7)
-    sdf = np.zeros(8, np.float32); nab = np.zeros((8, 3), np.float32)
-    for lane in range(32):
+    sdf = np.zeros(4, np.float32); nab = np.zeros((4, 3), np.float32)
+    for lane in range(16):
         pi = lane >> 2
         if cq[lane] == 0:
             sv = v[lane] + blob.aux[2304]
@@ -369,18 +366,17 @@ def emul_sdf_nabla_bf16(blob_np, pts8, R_bg):
     return sdf, nab, h7
 
 
-def emul_radiance_bf16(blob_np, view_tiles, pts32, view32, nabla32, h7_32):
+def emul_radiance_bf16(blob_np, view_tiles, pts16, view16, nabla16, h7_16):
     blob = Blob(blob_np)
-    p, v, n = pts32[J2].astype(np.float32), view32[J2].astype(np.float32), nabla32[J2].astype(np.float32)
-    Xh, Xl = [None] * 19, [None] * 19
+    p, v, n = pts16[J].astype(np.float32), view16[J].astype(np.float32), nabla16[J].astype(np.float32)
+    Xh, Xl = [None] * 10, [None] * 10
     e8 = np.arange(8)
-    for u in range(16):
-        T, uu = u >> 1, u & 1
-        r = 8 * uu + e8
-        feat = 32 * T + (r[None, :] & 3) + 8 * (r[None, :] >> 2) + 4 * H2[:, None]
-        Xh[u], Xl[u] = split2(h7_32[J2[:, None], feat].astype(np.float32))
+    for u in range(8):
+        feat = 32 * u + np.where(e8[None, :] < 4, 4 * G[:, None] + e8[None, :], 16 + 4 * G[:, None] + e8[None, :] - 4)
+        Xh[u], Xl[u] = split2(h7_16[J[:, None], feat].astype(np.float32))
     ne = 9 if view_tiles == 1 else 33
-    ex = np.zeros((64, 16 * view_tiles), np.float32)
+    ve = 1 if view_tiles == 1 else 2
+    ex = np.zeros((64, 32 * ve), np.float32)
     ex[:, 0:3] = p; ex[:, 3:6] = v
     if view_tiles == 3:
         for k in range(4):
@@ -388,16 +384,16 @@ def emul_radiance_bf16(blob_np, view_tiles, pts32, view32, nabla32, h7_32):
             ex[:, 6 + 6 * k: 9 + 6 * k] = np.sin(v * f, dtype=np.float32)
             ex[:, 9 + 6 * k: 12 + 6 * k] = np.cos(v * f, dtype=np.float32)
     ex[:, ne - 3: ne] = n
-    for q in range(view_tiles):
-        idx = 16 * q + 8 * H2[:, None] + e8[None, :]
-        Xh[16 + q], Xl[16 + q] = split2(ex[np.arange(64)[:, None], idx])
+    for q in range(ve):
+        idx = 32 * q + 8 * G[:, None] + e8[None, :]
+        Xh[8 + q], Xl[8 + q] = split2(ex[np.arange(64)[:, None], idx])
     dots = [np.zeros(64, np.float32) for _ in range(3)]
     rows = blob.aux[1280:1280 + 768]
     for L in range(5):
-        run_layer_bf16(Xh, Xl, blob, blob.aux[L * 256:(L + 1) * 256], rows, 16, view_tiles if L == 1 else 0, 8,
-                       "none" if L == 0 else "relu", False, 1.0, L == 4, dots)
-    rgb = np.zeros((32, 3), np.float32)
+        run_layer_bf16(Xh, Xl, blob, blob.aux[L * 256:(L + 1) * 256], rows, 8, ve if L == 1 else 0,
+                       "none" if L == 0 else "relu", False, L == 4, dots)
+    rgb = np.zeros((16, 3), np.float32)
     for c in range(3):
-        z = dots[c] + dots[c][LANE ^ 32] + blob.aux[2048 + c]
-        rgb[:, c] = (1.0 / (1.0 + np.exp(-z)))[:32]
+        z = _group_sum(dots[c]) + blob.aux[2048 + c]
+        rgb[:, c] = (1.0 / (1.0 + np.exp(-z)))[:16]
     return rgb

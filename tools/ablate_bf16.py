@@ -6,7 +6,8 @@ import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "nerf-art_amd", "csrc")
 VARIANTS = {"full": [], "nodma": ["-DNERFART_ABLATE_DMA"], "noepi": ["-DNERFART_ABLATE_EPI"], "nomfma": ["-DNERFART_ABLATE_MFMA"],
-            "nodma_noepi": ["-DNERFART_ABLATE_DMA", "-DNERFART_ABLATE_EPI"]}
+            "nodma_noepi": ["-DNERFART_ABLATE_DMA", "-DNERFART_ABLATE_EPI"], "noldsread": ["-DNERFART_ABLATE_LDSREAD"],
+            "mfma_only": ["-DNERFART_ABLATE_DMA", "-DNERFART_ABLATE_EPI", "-DNERFART_ABLATE_LDSREAD"]}
 OUT = os.path.join(ROOT, "gpurun_ablate")
 
 def build():
