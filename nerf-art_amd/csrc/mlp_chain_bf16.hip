@@ -7,21 +7,27 @@
 // TF32 (what the reference's published RTX 3090 number used) has 11.  The bf16 MFMA rate is 16x the
 // fp32 MFMA rate, so the split form is 16/3 = 5.3x the fp32-exact kernels of mlp_chain.hip.
 //
-// Structure = mlp_chain.hip's (8 waves x 16 columns per workgroup, two waves per SIMD so that one wave's
-// epilogue / barrier / LDS-DMA wait hides under the other's MFMAs; k-outer; activations never leave
-// registers), with the 16x16x32 layouts:
-//   * lane (g = lane>>4, j = lane&15).  A: lane (g,i) holds 8 k-slots of row i; B: lane (g,j) holds 8
-//     k-slots of column j; C: reg r of tile T <-> row 16T + 4g + r.  Which feature a k-slot means is our
-//     choice (the MFMA only pairs slot (g,e) of A with slot (g,e) of B): the 4+4 registers of output tiles
-//     2u and 2u+1 become, after activation + split + v_cvt_pk_bf16_f32, "unit" u (32 slots) of the next
-//     layer's B operand directly in registers; packing.py (bf16 plans) applies the matching permutation.
-//   * the 16 accumulator tiles of a layer (64 VGPRs) stay live; a weight chunk = 2 k-steps x 16 tiles x
-//     (hi, lo) fragments = 64 KiB, LDS-DMA double buffered, one barrier per chunk (96 MFMAs per wave).
-//   * A fragments are read from LDS two items ahead with inline-asm ds_read_b128 and counted lgkmcnt waits
+// Structure: 8 waves x 16 columns (points) per workgroup, two waves per SIMD; activations never leave
+// registers; weights stream L2 -> LDS by LDS-DMA in 64 KiB chunks (2 k-steps x 16 output tiles x (hi, lo)
+// fragments), double buffered, one barrier per chunk.
+//   * 16x16x32 layouts: lane (g = lane>>4, j = lane&15).  A: lane (g,i) holds 8 k-slots of row i; B: lane
+//     (g,j) holds 8 k-slots of column j; C: reg r of tile T <-> row 16T + 4g + r.  Which feature a k-slot
+//     means is our choice (the MFMA only pairs slot (g,e) of A with slot (g,e) of B): the 4+4 registers of
+//     output tiles 2u and 2u+1 become, after activation + split + v_cvt_pk_bf16_f32, "unit" u (32 slots) of
+//     the next layer's B operand directly in registers; packing.py (bf16 plans) applies the permutation.
+//   * SOFTWARE PIPELINE ACROSS LAYERS.  All 8 waves of a workgroup meet at the chunk barrier, so the two
+//     waves of a SIMD are in the same phase: an epilogue (softplus + split: ~10 VALU issues and 2
+//     transcendentals per value) executed between layers leaves the matrix cores idle in both.  Instead a
+//     layer keeps TWO accumulator sets: Q (being accumulated) and P (the previous layer's pre-activations).
+//     k-step u of the layer needs only input unit u = act(P tiles 2u, 2u+1), which is computed in slices
+//     placed between the MFMA triples of k-step u-1 (unit 0: in the last k-step of the previous layer, whose
+//     tiles 0 and 1 are final by then).  Every MFMA triple is followed by ~5 independent VALU instructions
+//     and (first 4 triples of a k-step) one 1 KiB LDS-DMA piece of the next chunk, so VALU, DMA issue and
+//     matrix work overlap inside each wave and across the two waves of the SIMD.
+//   * A fragments are read from LDS two triples ahead with inline-asm ds_read_b128 and counted lgkmcnt waits
 //     (hipcc sinks plain reads back to their use and waits lgkmcnt(0) every 3 MFMAs).
-// An earlier variant (32x32x16, 4 waves x 32 columns, one wave per SIMD; git history) ran at 42 % MFMA
-// utilisation: an ablation attributed 24 % of its time to exposed LDS-DMA waits and 24 % to the epilogue,
-// neither of which a single wave per SIMD can hide.
+// History (git): 32x32x16, one wave per SIMD: 42 % MFMA utilisation; 16x16x32 with the epilogue between
+// layers: 51 %; ablations attributed the rest to the serialised epilogue (25 %) and LDS-DMA issue (18 %).
 #include "mlp_common.h"
 
 namespace nerfart {
@@ -33,17 +39,20 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WG_THREADS = 512;
 constexpr int WAVES = 8;
-constexpr int XU_MAX = 10;                          // input units (32 feature slots each)
 constexpr int TS_FLOATS = 512;                      // one item = (k-step, output tile): (hi, lo) x 64 lanes x 16 B = 2 KiB
 constexpr int KS_FLOATS = 16 * TS_FLOATS;           // one k-step of a chunk: 16 output tiles = 32 KiB
 constexpr int CHUNK_KS = 2;                         // k-steps per chunk
-constexpr int CHUNK_FLOATS_MAX = CHUNK_KS * KS_FLOATS;   // 64 KiB
+constexpr int CHUNK_FLOATS = CHUNK_KS * KS_FLOATS;  // 64 KiB
 constexpr int AUX_FLOATS_MAX = 2560;
-constexpr int LDS_FLOATS = 2 * CHUNK_FLOATS_MAX + AUX_FLOATS_MAX + TAB_INTS;   // 141,824 B
-using Pipe = PipeT<WAVES, CHUNK_FLOATS_MAX>;
+constexpr int LDS_FLOATS = 2 * CHUNK_FLOATS + AUX_FLOATS_MAX + TAB_INTS;   // 141,824 B
 
-struct Act { u32x4 h[XU_MAX]; u32x4 l[XU_MAX]; };   // packed bf16 pairs: hi and lo terms of 8 slots per unit
+struct Unit { u32x4 h, l; };                        // 32 feature slots: packed bf16 pairs, hi and lo terms
 struct Acc { f32x4 t[16]; };
+struct Work { float e0, e1, r0, r1, y0, y1; };      // values carried between the slices of one epilogue pair
+struct EpiCtx {
+    float floor_p, floor_q;                         // ReLU family: activation floor of the previous / this layer's output
+    bool is_val;                                    // tangent kernels: this lane is a value column
+};
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     typedef float f32x2_ __attribute__((ext_vector_type(2)));
@@ -60,16 +69,144 @@ __device__ __forceinline__ f32x4 mfma3(const u32x4 ah, const u32x4 al, const u32
     asm volatile("" :: "v"(ah), "v"(al), "v"(bh), "v"(bl));
     return acc;
 #endif
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), acc, 0, 0, 0);
+    // One asm statement so that nothing is scheduled BETWEEN the three MFMAs of an accumulator chain (an extra
+    // issue slot there costs ~43 cycles, MI355X_MICROARCH.md "per-instruction cycle constants"); fillers go
+    // between triples.  Hazards the compiler no longer pads: a VALU write of an A/B operand just before the
+    // statement (s_nop 1 inside); the result read by a VALU after it (readers are >= 2 triples away, except at
+    // the end of a layer: layer() ends with explicit nops).
+    asm volatile("s_nop 1\n\t"
+                 "v_mfma_f32_16x16x32_bf16 %0, %1, %3, %0\n\t"
+                 "v_mfma_f32_16x16x32_bf16 %0, %1, %4, %0\n\t"
+                 "v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0"
+                 : "+v"(acc) : "v"(ah), "v"(al), "v"(bh), "v"(bl));
     return acc;
 }
 
 // ---------------------------------------------------------------------------------------
-// The MFMAs of one weight chunk: NKS k-steps x 16 output tiles, 3 MFMAs each.  LDS returns in order: with
-// items it, it+1, it+2 outstanding (2 reads each) item it has landed at lgkmcnt(4)
-// (cdna_hip_programming.md 5.7, form ii: the wait statement names the destinations "+v").
+// Weight stream: chunk c is consumed from LDS buffer pb while chunk c+1 is streamed into buffer pb^1 in
+// 1 KiB pieces issued BETWEEN the MFMAs of chunk c (stream_piece), not in a burst after the barrier.
+// ---------------------------------------------------------------------------------------
+struct Stream {
+    const float* blob;
+    const int* tab;            // LDS copy of the chunk offset table
+    float* lds;
+    int nc;
+    const float* iss_src;      // this wave's 8 KiB share of the chunk being streamed during the current chunk
+    unsigned iss_dst;          // LDS byte address of that share
+    unsigned voff_a, voff_b;   // per-lane byte offsets of pieces 0..3 / 4..7 (lane * 16, + 4096)
+    int nxt, nxt_o0;           // the chunk to stream during the NEXT chunk (offset looked up one acquire ahead)
+    int pb;
+    bool wrap;                 // another tile follows: chunk 0 comes after chunk nc-1
+};
+
+__device__ __forceinline__ void stream_lookup(Stream& s, int chunk) {
+    s.nxt = chunk;
+    // no next chunk: stream chunk 0 again (never read) - keeps stream_piece branch free
+    s.nxt_o0 = __builtin_amdgcn_readfirstlane(s.tab[chunk >= 0 ? chunk : 0]);
+}
+__device__ __forceinline__ int stream_next_of(const Stream& s, int c) {
+    if (c < 0) return -1;
+    return (c + 1 == s.nc) ? (s.wrap ? 0 : -1) : c + 1;
+}
+// Piece J (1 KiB) of this wave's share.  Wave w streams bytes [8192 w, 8192 w + 8192) of the chunk - for a
+// one-k-step chunk (32 KiB) waves 4..7 copy the bytes that follow it in the blob into the unused half of the
+// buffer (the last chunk of a program is always a full one, packing.py).  M0 = LDS destination base, written in
+// the same statement that uses it (cdna_hip_programming.md 5.7); the instruction's immediate offset applies to
+// BOTH the global address and the LDS address.
+template <int J>
+__device__ __forceinline__ void stream_piece(const Stream& s) {
+#ifndef NERFART_ABLATE_DMA
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_add_u32 m0, %3, %4\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:%5\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(J < 4 ? s.voff_a : s.voff_b), "s"(s.iss_src), "s"(s.iss_dst), "i"((J & 4) * 1024), "i"((J & 3) * 1024)
+                 : "memory", "scc");
+#endif
+}
+__device__ __forceinline__ void stream_target(Stream& s, int o0, int buf) {
+    const int w = wave_id();
+    s.iss_src = s.blob + o0 + w * 2048;
+    s.iss_dst = lds_addr(s.lds + buf * CHUNK_FLOATS) + w * 8192;
+}
+// once per workgroup, after the table is in LDS: chunk 0 in a burst into buffer 0
+__device__ __forceinline__ void stream_start(Stream& s) {
+    s.voff_a = lane_id() * 16;
+    s.voff_b = lane_id() * 16 + 4096;
+    stream_lookup(s, 0);
+    stream_target(s, s.nxt_o0, 0);
+    stream_piece<0>(s); stream_piece<1>(s); stream_piece<2>(s); stream_piece<3>(s);
+    stream_piece<4>(s); stream_piece<5>(s); stream_piece<6>(s); stream_piece<7>(s);
+    s.pb = 0;
+    stream_lookup(s, stream_next_of(s, 0));
+}
+__device__ __forceinline__ const float* stream_acquire(Stream& s) {
+    wait_glds();          // my pieces of the current chunk have landed
+    __syncthreads();      // everyone's pieces landed; everyone is done reading buffer pb^1
+    const float* w = s.lds + s.pb * CHUNK_FLOATS;
+    stream_target(s, s.nxt_o0, s.pb ^ 1);
+    stream_lookup(s, stream_next_of(s, s.nxt));
+    s.pb ^= 1;
+    return w;
+}
+
+// ---------------------------------------------------------------------------------------
+// Epilogue slices.  MODE 0: softplus(beta = 100); 1: softplus value / tangent columns (quads); 2: max(z, floor).
+// One pair of values goes through three slices: PH 0 (exp, rcp) -> PH 1 (log, select) -> PH 2 (split to bf16 hi/lo).
+// ---------------------------------------------------------------------------------------
+// max(z, 0) in one instruction (fmaxf() first canonicalises z with a v_max_f32 z, z)
+__device__ __forceinline__ float relu1(float z) {
+    float y;
+    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(z));
+    return y;
+}
+
+template <int MODE, int PH>
+__device__ __forceinline__ void epi_phase(float z0, float z1, Work& w, unsigned& hi, unsigned& lo, float floor, bool is_val) {
+#ifdef NERFART_ABLATE_EPI       // timing experiments only: no activation arithmetic
+    if (PH == 2) { hi = __float_as_uint(z0); lo = __float_as_uint(z1); }
+    return;
+#endif
+    if constexpr (PH == 0) {
+        if constexpr (MODE != 2) {
+            w.e0 = __builtin_amdgcn_exp2f(fabsf(z0) * -144.269504088896340736f);     // exp(-|100 z|)
+            w.e1 = __builtin_amdgcn_exp2f(fabsf(z1) * -144.269504088896340736f);
+        }
+        if constexpr (MODE == 1) {
+            w.r0 = __builtin_amdgcn_rcpf(1.0f + w.e0);
+            w.r1 = __builtin_amdgcn_rcpf(1.0f + w.e1);
+        }
+    } else if constexpr (PH == 1) {
+        if constexpr (MODE == 2) {
+            w.y0 = fmaxf(z0, floor);
+            w.y1 = fmaxf(z1, floor);
+        } else {
+            const float v0 = relu1(z0) + __builtin_amdgcn_logf(1.0f + w.e0) * (0.69314718055994530942f / 100.0f);
+            const float v1 = relu1(z1) + __builtin_amdgcn_logf(1.0f + w.e1) * (0.69314718055994530942f / 100.0f);
+            if constexpr (MODE == 1) {
+                // value lanes carry z (bias included); tangent lanes carry dz and take softplus'(z) from their quad's lane 0
+                const float d0 = quad_bcast0((z0 >= 0.f) ? w.r0 : w.e0 * w.r0);
+                const float d1 = quad_bcast0((z1 >= 0.f) ? w.r1 : w.e1 * w.r1);
+                w.y0 = is_val ? v0 : d0 * z0;
+                w.y1 = is_val ? v1 : d1 * z1;
+            } else {
+                w.y0 = v0;
+                w.y1 = v1;
+            }
+        }
+    } else {
+        split2(w.y0, w.y1, hi, lo);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// The work of one weight chunk, one "item" = (k-step, output tile) at a time: wait for the item's A fragments,
+// 3 MFMAs, then the fillers: the fragment reads two items ahead, an LDS-DMA piece (first 4 items of a k-step),
+// one epilogue slice (last 12 items of a hosting k-step).  LDS returns in order: with items it, it+1, it+2
+// outstanding (2 reads each) item it has landed at lgkmcnt(4) (cdna_hip_programming.md 5.7, form ii).
 // ---------------------------------------------------------------------------------------
 struct Ring { u32x4 h0, l0, h1, l1, h2, l2; };
 
@@ -87,148 +224,125 @@ __device__ __forceinline__ void lds_wait_pair(u32x4& fh, u32x4& fl) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fh), "+v"(fl) : "i"(CNT));
 }
 
-template <int IT, int N>
-struct ChunkSteps {
-    static __device__ __forceinline__ void run(Acc& A, const Act& X, int ks0, unsigned addr, Ring& r) {
+// Layer shape: NH input units come from the previous layer's accumulators P (k-steps 0..NH-1, built just in
+// time), NX are ready-made units xs[] (k-steps NH..NH+NX-1: encodings, extras, activations from memory).
+// NEXT0: the last k-step also builds unit 0 of the NEXT layer from this layer's tiles 0 and 1.
+template <int MODE, int NH, int NX, bool NEXT0, int C, int NKC, int IT>
+struct Items {
+    static constexpr int NXA = NX > 0 ? NX : 1;
+    static __device__ __forceinline__ void run(const Acc& P, Acc& Q, Unit (&xb)[2], const Unit (&xs)[NXA], Unit& x0n, Work& w,
+                                               Ring& r, unsigned addr, const Stream& s, const EpiCtx& ec) {
+        constexpr int N = NKC * 16;
         if constexpr (IT < N) {
+            constexpr int kk = IT >> 4, T = IT & 15, ks = CHUNK_KS * C + kk, NKS = NH + NX;
             constexpr int S = IT % 3, S2 = (IT + 2) % 3;
+            constexpr int PENDING = (IT + 2 < N) ? 4 : ((IT + 1 < N) ? 2 : 0);
             if constexpr (IT + 2 < N) {
                 if constexpr (S2 == 0) lds_read_pair<(IT + 2) * 2048>(r.h0, r.l0, addr);
                 else if constexpr (S2 == 1) lds_read_pair<(IT + 2) * 2048>(r.h1, r.l1, addr);
                 else lds_read_pair<(IT + 2) * 2048>(r.h2, r.l2, addr);
             }
-            constexpr int PENDING = (IT + 2 < N) ? 4 : ((IT + 1 < N) ? 2 : 0);
-            constexpr int kk = IT >> 4, T = IT & 15;
-            if constexpr (S == 0) { lds_wait_pair<PENDING>(r.h0, r.l0); A.t[T] = mfma3(r.h0, r.l0, X.h[ks0 + kk], X.l[ks0 + kk], A.t[T]); }
-            else if constexpr (S == 1) { lds_wait_pair<PENDING>(r.h1, r.l1); A.t[T] = mfma3(r.h1, r.l1, X.h[ks0 + kk], X.l[ks0 + kk], A.t[T]); }
-            else { lds_wait_pair<PENDING>(r.h2, r.l2); A.t[T] = mfma3(r.h2, r.l2, X.h[ks0 + kk], X.l[ks0 + kk], A.t[T]); }
-            ChunkSteps<IT + 1, N>::run(A, X, ks0, addr, r);
+            u32x4 bh, bl;
+            if constexpr (ks < NH) { bh = xb[ks & 1].h; bl = xb[ks & 1].l; }
+            else { bh = xs[ks - NH].h; bl = xs[ks - NH].l; }
+            if constexpr (S == 0) { lds_wait_pair<PENDING>(r.h0, r.l0); Q.t[T] = mfma3(r.h0, r.l0, bh, bl, Q.t[T]); }
+            else if constexpr (S == 1) { lds_wait_pair<PENDING>(r.h1, r.l1); Q.t[T] = mfma3(r.h1, r.l1, bh, bl, Q.t[T]); }
+            else { lds_wait_pair<PENDING>(r.h2, r.l2); Q.t[T] = mfma3(r.h2, r.l2, bh, bl, Q.t[T]); }
+            // LDS-DMA: the 8 pieces per wave of the next chunk go out during the first 4 items of each k-step
+            if constexpr (T < 4) {
+                if constexpr (NKC == 2) stream_piece<kk * 4 + T>(s);
+                else { stream_piece<2 * T>(s); stream_piece<2 * T + 1>(s); }
+            }
+            // epilogue slice hosted by this item
+            constexpr int HU = (ks + 1 < NH) ? ks + 1 : ((NEXT0 && ks == NKS - 1) ? 100 : -1);
+            if constexpr (HU >= 0 && T >= 4) {
+                constexpr int pr = (T - 4) / 3, ph = (T - 4) % 3;
+                constexpr int tile = (HU == 100 ? 0 : 2 * HU) + (pr >> 1), r0 = 2 * (pr & 1);
+                unsigned hi = 0, lo = 0;
+                if constexpr (HU == 100) {
+                    epi_phase<MODE, ph>(Q.t[tile][r0], Q.t[tile][r0 + 1], w, hi, lo, ec.floor_q, ec.is_val);
+                    if constexpr (ph == 2) { x0n.h[pr] = hi; x0n.l[pr] = lo; }
+                } else {
+                    epi_phase<MODE, ph>(P.t[tile][r0], P.t[tile][r0 + 1], w, hi, lo, ec.floor_p, ec.is_val);
+                    if constexpr (ph == 2) { xb[HU & 1].h[pr] = hi; xb[HU & 1].l[pr] = lo; }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            Items<MODE, NH, NX, NEXT0, C, NKC, IT + 1>::run(P, Q, xb, xs, x0n, w, r, addr, s, ec);
         }
     }
 };
 
-template <int NKS>
-__device__ __forceinline__ void chunk_mma(Acc& A, const Act& X, int ks0, const float* w) {
-    constexpr int N = NKS * 16;
-    const unsigned addr = (unsigned)(size_t)w;          // LDS byte address of this lane's 16 bytes of item 0
-    // everything the compiler itself has in flight on the LDS queue must be drained first: the counted waits
-    // below assume only these reads are outstanding
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    Ring r;
-    lds_read_pair<0>(r.h0, r.l0, addr);
-    lds_read_pair<2048>(r.h1, r.l1, addr);
-    ChunkSteps<0, N>::run(A, X, ks0, addr, r);
-}
-
-// Run-time (wave-uniform) description of what a layer's epilogue does (branch free: run-time branches in the
-// epilogue split it into small basic blocks and stop hipcc from overlapping anything).
-struct Epi {
-    const float* bias;     // LDS, natural feature order
-    float floor;           // ReLU family: 0 (ReLU) or -inf (no activation)
-    const float* rows;     // LDS: NROWS x 256 weights of the final linear layer (LAST bodies)
-    float* h7;             // per-lane destination of the fp32 activations (tangent kernel, LAST body) or null
-};
-
-// activation of one accumulator tile (features 16T + 4g + r)
-template <bool SOFTPLUS, bool TANGENT>
-__device__ __forceinline__ f32x4 activate(const f32x4 a, const Epi& e, bool is_val) {
-    f32x4 y;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#ifdef NERFART_ABLATE_EPI       // timing experiments only: no activation arithmetic
-        y[r] = a[r];
-        continue;
-#endif
-        if (SOFTPLUS) {
-            if (TANGENT) {
-                float v, d;
-                softplus100_vd(a[r], v, d);       // value lanes carry the bias from the accumulator init
-                d = quad_bcast0(d);
-                y[r] = is_val ? v : d * a[r];
-            } else {
-                y[r] = softplus100(a[r]);
-            }
-        } else {
-            y[r] = fmaxf(a[r], e.floor);
-        }
-    }
-    return y;
-}
-
-// Epilogue of unit U = output tiles 2U and 2U+1: either the next layer's input unit (slot e < 4: tile 2U reg e,
-// e >= 4: tile 2U+1 reg e-4) or, in LAST bodies, the final rows' dot products (+ the fp32 activations h7).
-template <int U, bool SOFTPLUS, bool TANGENT, bool LAST, int NROWS>
-__device__ __forceinline__ void epi_unit(const Acc& A, const Epi& e, Act& X, float (&dot)[NROWS], int g, bool is_val) {
-    const f32x4 y0 = activate<SOFTPLUS, TANGENT>(A.t[2 * U], e, is_val);
-    const f32x4 y1 = activate<SOFTPLUS, TANGENT>(A.t[2 * U + 1], e, is_val);
-    if (LAST) {
-#pragma unroll
-        for (int n = 0; n < NROWS; ++n) {
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(e.rows + n * 256 + 32 * U + 4 * g);
-            const f32x4 w1 = *reinterpret_cast<const f32x4*>(e.rows + n * 256 + 32 * U + 16 + 4 * g);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { dot[n] = fmaf(y0[r], w0[r], dot[n]); dot[n] = fmaf(y1[r], w1[r], dot[n]); }
-        }
-        if (TANGENT) {
-            if (e.h7 != nullptr && is_val) {
-                *reinterpret_cast<f32x4*>(e.h7 + 32 * U + 4 * g) = y0;
-                *reinterpret_cast<f32x4*>(e.h7 + 32 * U + 16 + 4 * g) = y1;
-            }
-        }
-    } else {
-#ifdef NERFART_ABLATE_EPI
-        X.h[U] = u32x4{__float_as_uint(y0[0]), __float_as_uint(y0[1]), __float_as_uint(y0[2]), __float_as_uint(y0[3])};
-        X.l[U] = u32x4{__float_as_uint(y1[0]), __float_as_uint(y1[1]), __float_as_uint(y1[2]), __float_as_uint(y1[3])};
-        return;
-#endif
-        u32x4 hi, lo;
-        unsigned a, b;
-        split2(y0[0], y0[1], a, b); hi[0] = a; lo[0] = b;
-        split2(y0[2], y0[3], a, b); hi[1] = a; lo[1] = b;
-        split2(y1[0], y1[1], a, b); hi[2] = a; lo[2] = b;
-        split2(y1[2], y1[3], a, b); hi[3] = a; lo[3] = b;
-        X.h[U] = hi;
-        X.l[U] = lo;
+template <int MODE, int NH, int NX, bool NEXT0, int C>
+__device__ __forceinline__ void run_chunk(const Acc& P, Acc& Q, Unit (&xb)[2], const Unit (&xs)[NX > 0 ? NX : 1], Unit& x0n,
+                                          Work& w, Stream& s, const EpiCtx& ec) {
+    constexpr int NKS = NH + NX;
+    constexpr int NKC = (NKS - CHUNK_KS * C) >= CHUNK_KS ? CHUNK_KS : (NKS - CHUNK_KS * C);
+    if constexpr (NKC > 0) {
+        const float* wp = stream_acquire(s) + lane_id() * 4;
+        const unsigned addr = (unsigned)(size_t)wp;        // LDS byte address of this lane's 16 bytes of item 0
+        // everything the compiler itself has in flight on the LDS queue must be drained first: the counted
+        // waits below assume only the ring's reads are outstanding
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        Ring r;
+        lds_read_pair<0>(r.h0, r.l0, addr);
+        lds_read_pair<2048>(r.h1, r.l1, addr);
+        Items<MODE, NH, NX, NEXT0, C, NKC, 0>::run(P, Q, xb, xs, x0n, w, r, addr, s, ec);
+        run_chunk<MODE, NH, NX, NEXT0, C + 1>(P, Q, xb, xs, x0n, w, s, ec);
     }
 }
 
-// A whole dense layer, in place on X.  Chunk sequence (must match packing.py, bf16 plans): ceil(NU_BASE/2)
-// chunks of the base units, then (if nextra) one chunk with the nextra (<= 2) extra units.
-template <int NU_BASE, int NU_EXTRA_MAX, bool SOFTPLUS, bool TANGENT, bool LAST, int NROWS>
-__device__ __forceinline__ void run_layer(Act& X, Pipe& p, const Epi& e, float (&dot)[NROWS], int nextra) {
-    const int lane = lane_id();
-    const int g = lane >> 4;
-    const bool is_val = !TANGENT || ((lane & 3) == 0);
-    Acc A;
-    // start at the bias (value columns; derivative columns start at 0): reg r of tile T is feature 16T + 4g + r
+// One dense layer: Q = bias + W . [act(P) | xs].  x0 = unit 0 of act(P) (built by the previous layer).
+template <int MODE, int NH, int NX, bool NEXT0>
+__device__ __forceinline__ void layer(const Acc& P, Acc& Q, const Unit& x0, const Unit (&xs)[NX > 0 ? NX : 1], Unit& x0n,
+                                      Stream& s, const float* bias, const EpiCtx& ec) {
+    const int g = lane_id() >> 4;
+    Unit xb[2];
+    xb[0] = x0;
+    xb[1] = x0;
+    // start at the bias (value columns; tangent columns start at 0): reg r of tile T is feature 16T + 4g + r
 #pragma unroll
     for (int T = 0; T < 16; ++T) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(e.bias + 16 * T + 4 * g);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + 16 * T + 4 * g);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) A.t[T][r] = is_val ? b[r] : 0.f;
+        for (int r = 0; r < 4; ++r) Q.t[T][r] = ec.is_val ? b[r] : 0.f;
     }
+    Work w = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    run_chunk<MODE, NH, NX, NEXT0, 0>(P, Q, xb, xs, x0n, w, s, ec);
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");     // last MFMA result -> first VALU reader (see mfma3)
+}
+
+// Epilogue of the last hidden layer: dot products of act(Q) with NROWS rows (+ the fp32 activations h7).
+template <int MODE, int NROWS>
+__device__ __forceinline__ void last_epilogue(const Acc& Q, const float* rows, float (&dot)[NROWS], float* h7, const EpiCtx& ec) {
+    const int g = lane_id() >> 4;
 #pragma unroll
-    for (int c = 0; c < (NU_BASE + CHUNK_KS - 1) / CHUNK_KS; ++c) {
-        const float* w = pipe_acquire(p) + lane * 4;
-        constexpr int REM = NU_BASE % CHUNK_KS;
-        if (REM != 0 && c == NU_BASE / CHUNK_KS) chunk_mma<1>(A, X, c * CHUNK_KS, w);
-        else chunk_mma<CHUNK_KS>(A, X, c * CHUNK_KS, w);
-    }
-    if (NU_EXTRA_MAX > 0) {
-        if (nextra > 0) {
-            const float* w = pipe_acquire(p) + lane * 4;
-            if (NU_EXTRA_MAX == 1 || nextra == 1) chunk_mma<1>(A, X, NU_BASE, w);
-            else chunk_mma<2>(A, X, NU_BASE, w);
+    for (int T = 0; T < 16; ++T) {
+        f32x4 y;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float a = Q.t[T][r];
+            if constexpr (MODE == 2) {
+                y[r] = fmaxf(a, ec.floor_q);
+            } else if constexpr (MODE == 1) {
+                float v, d;
+                softplus100_vd(a, v, d);
+                d = quad_bcast0(d);
+                y[r] = ec.is_val ? v : d * a;
+            } else {
+                y[r] = softplus100(a);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NROWS; ++n) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(rows + n * 256 + 16 * T + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dot[n] = fmaf(y[r], w[r], dot[n]);
+        }
+        if constexpr (MODE == 1) {
+            if (h7 != nullptr && ec.is_val) *reinterpret_cast<f32x4*>(h7 + 16 * T + 4 * g) = y;
         }
     }
-    epi_unit<0, SOFTPLUS, TANGENT, LAST, NROWS>(A, e, X, dot, g, is_val);
-    epi_unit<1, SOFTPLUS, TANGENT, LAST, NROWS>(A, e, X, dot, g, is_val);
-    epi_unit<2, SOFTPLUS, TANGENT, LAST, NROWS>(A, e, X, dot, g, is_val);
-    epi_unit<3, SOFTPLUS, TANGENT, LAST, NROWS>(A, e, X, dot, g, is_val);
-    epi_unit<4, SOFTPLUS, TANGENT, LAST, NROWS>(A, e, X, dot, g, is_val);
-    epi_unit<5, SOFTPLUS, TANGENT, LAST, NROWS>(A, e, X, dot, g, is_val);
-    epi_unit<6, SOFTPLUS, TANGENT, LAST, NROWS>(A, e, X, dot, g, is_val);
-    epi_unit<7, SOFTPLUS, TANGENT, LAST, NROWS>(A, e, X, dot, g, is_val);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -237,7 +351,7 @@ __device__ __forceinline__ void run_layer(Act& X, Pipe& p, const Epi& e, float (
 // cos(2^k x_g) for k < 6, m = 13..15 pad; lane group 3 is padding (reference Embedder, models/base.py:38-64;
 // slot map packing.unit_feature_enc).  dq < 0: values; dq = 0..2: derivative w.r.t. coordinate dq.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void encode_units(float x, float y, float z, int g, int dq, Act& X, int u0) {
+__device__ __forceinline__ void encode_units(float x, float y, float z, int g, int dq, Unit (&X)[2]) {
     const float cg = (g == 0) ? x : ((g == 1) ? y : z);
     const bool live = g < 3;
     const bool own = (dq == g);
@@ -263,8 +377,8 @@ __device__ __forceinline__ void encode_units(float x, float y, float z, int g, i
             split2(a, b, sh, sl);
             hi[pr] = sh; lo[pr] = sl;
         }
-        X.h[u0 + q] = hi;
-        X.l[u0 + q] = lo;
+        X[q].h = hi;
+        X[q].l = lo;
     }
 }
 
@@ -283,25 +397,42 @@ __device__ __forceinline__ void load_aux(float* aux_lds, const float* blob, cons
     __syncthreads();
 }
 
-// The 8 hidden layers of the SDF net, in place on X; the last one accumulates dot[0] = row0 . h7 (and stores
-// h7 if asked).  Bodies: layer 0 (2 input units), layers 1..6 (one body in a run-time loop), layer 7 (LAST).
-template <bool TANGENT>
-__device__ __forceinline__ float surface_chain(Act& X, float px, float py, float pz, int g, int dq, Pipe& p,
-                                               const float* aux, float* h7_lane) {
-    float dot[1] = {0.f};
-    Epi e{aux, 0.f, aux + SURF_AUX_ROW, h7_lane};
-    encode_units(px, py, pz, g, dq, X, 0);
-    run_layer<2, 0, true, TANGENT, false, 1>(X, p, e, dot, 0);
+// The 8 hidden layers of the SDF net; returns row0 . h7 summed over the wave's lane groups (and stores h7 if
+// asked).  Layer bodies: layer 0 (2 encoding units), one body for layers 1..3, 5, 6, the skip layer 4 (7 hidden
+// units + 2 encoding units; the 1/sqrt(2) of cat[h, enc]/sqrt(2) is folded into its weights), layer 7.
+template <int MODE>
+__device__ __forceinline__ float surface_chain(float px, float py, float pz, int g, int dq, Stream& s, const float* aux,
+                                               float* h7_lane, bool is_val) {
+    const EpiCtx ec{0.f, 0.f, is_val};
+    Acc A, B;
+    Unit x0, x0n, enc[2], none[1];
+    encode_units(px, py, pz, g, dq, enc);
+    none[0] = enc[0];
+    x0 = enc[0];
+    layer<MODE, 0, 2, true>(B, A, x0, enc, x0n, s, aux, ec);
+    x0 = x0n;
 #pragma nounroll
     for (int L = 1; L < 7; ++L) {
-        // skip: cat[h(217 -> 7 units), enc(2 units)] / sqrt(2) - the 1/sqrt(2) is folded into layer 4's weights
-        if (L == 4) encode_units(px, py, pz, g, dq, X, 7);
-        e.bias = aux + L * 256;
-        run_layer<8, 1, true, TANGENT, false, 1>(X, p, e, dot, (L == 4) ? 1 : 0);
+        if (L == 4) {
+            encode_units(px, py, pz, g, dq, enc);
+            layer<MODE, 7, 2, true>(A, B, x0, enc, x0n, s, aux + L * 256, ec);
+        } else {
+            layer<MODE, 8, 0, true>(A, B, x0, none, x0n, s, aux + L * 256, ec);
+        }
+        A = B;
+        x0 = x0n;
     }
-    e.bias = aux + 7 * 256;
-    run_layer<8, 0, true, TANGENT, true, 1>(X, p, e, dot, 0);
+    layer<MODE, 8, 0, false>(A, B, x0, none, x0n, s, aux + 7 * 256, ec);
+    float dot[1] = {0.f};
+    last_epilogue<MODE, 1>(B, aux + SURF_AUX_ROW, dot, h7_lane, ec);
     return sum_over_groups(dot[0]);        // the 4 lane groups of a column hold complementary feature sets
+}
+
+__device__ __forceinline__ Stream make_stream(const float* blob, const float* aux, float* smem, int nc) {
+    Stream s;
+    s.blob = blob; s.tab = reinterpret_cast<const int*>(aux + AUX_FLOATS_MAX); s.lds = smem; s.nc = nc;
+    s.iss_src = blob; s.iss_dst = 0; s.voff_a = 0; s.voff_b = 0; s.nxt = -1; s.nxt_o0 = 0; s.pb = 0; s.wrap = false;
+    return s;
 }
 
 // =======================================================================================
@@ -311,20 +442,19 @@ __global__ void __launch_bounds__(WG_THREADS, 2)
 k_sdf_only_bf16(const float* __restrict__ blob, PointSrc src, float R_bg, float* __restrict__ sdf_out, int out_stride) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int* hdr = reinterpret_cast<const int*>(blob);
-    float* aux = smem + 2 * CHUNK_FLOATS_MAX;
+    float* aux = smem + 2 * CHUNK_FLOATS;
     const int lane = lane_id(), g = lane >> 4, j = lane & 15, wv = wave_id();
     load_aux(aux, blob, hdr, SURF_AUX_FLOATS);
     const unsigned ntiles = (src.M + 127u) / 128u;
     if (blockIdx.x >= ntiles) return;
-    Pipe p{blob, reinterpret_cast<const int*>(aux + AUX_FLOATS_MAX), smem, hdr[2], 0, 0, 0, 0, false};
-    p.wrap = (blockIdx.x + gridDim.x) < ntiles;
-    pipe_start(p);
+    Stream s = make_stream(blob, aux, smem, hdr[2]);
+    s.wrap = (blockIdx.x + gridDim.x) < ntiles;
+    stream_start(s);
     for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        p.wrap = (tile + gridDim.x) < ntiles;
+        s.wrap = (tile + gridDim.x) < ntiles;
         const unsigned m = tile * 128u + wv * 16 + j;
         const Pt pt = fetch_point(src, m, false);
-        Act X;
-        float sdf = surface_chain<false>(X, pt.x, pt.y, pt.z, g, -1, p, aux, nullptr) + aux[SURF_AUX_B8];
+        float sdf = surface_chain<0>(pt.x, pt.y, pt.z, g, -1, s, aux, nullptr, true) + aux[SURF_AUX_B8];
         if (R_bg > 0.f) sdf = fminf(sdf, R_bg - sqrtf(pt.x * pt.x + pt.y * pt.y + pt.z * pt.z));
         if (g == 0 && m < src.M) {
             if (src.pts) sdf_out[m] = sdf;
@@ -337,29 +467,29 @@ k_sdf_only_bf16(const float* __restrict__ blob, PointSrc src, float R_bg, float*
 }
 
 // =======================================================================================
-// K3a (split bf16): sdf + nabla + h7, forward mode; 32 points per workgroup tile (4 per wave, quads).
+// K3a (split bf16): sdf + nabla + h7, forward mode; 32 points per workgroup tile (4 per wave, quads:
+// column 4i = value, 4i+1..3 = d/dx, d/dy, d/dz).
 // =======================================================================================
 __global__ void __launch_bounds__(WG_THREADS, 2)
 k_sdf_nabla_bf16(const float* __restrict__ blob, PointSrc src, float R_bg, float* __restrict__ sdf_out,
                  float* __restrict__ nabla_out, float* __restrict__ h7_out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int* hdr = reinterpret_cast<const int*>(blob);
-    float* aux = smem + 2 * CHUNK_FLOATS_MAX;
+    float* aux = smem + 2 * CHUNK_FLOATS;
     const int lane = lane_id(), g = lane >> 4, j = lane & 15, wv = wave_id();
     const int cq = j & 3;
     load_aux(aux, blob, hdr, SURF_AUX_FLOATS);
     const unsigned ntiles = (src.M + 31u) / 32u;
     if (blockIdx.x >= ntiles) return;
-    Pipe p{blob, reinterpret_cast<const int*>(aux + AUX_FLOATS_MAX), smem, hdr[2], 0, 0, 0, 0, false};
-    p.wrap = (blockIdx.x + gridDim.x) < ntiles;
-    pipe_start(p);
+    Stream s = make_stream(blob, aux, smem, hdr[2]);
+    s.wrap = (blockIdx.x + gridDim.x) < ntiles;
+    stream_start(s);
     for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        p.wrap = (tile + gridDim.x) < ntiles;
+        s.wrap = (tile + gridDim.x) < ntiles;
         const unsigned m = tile * 32u + wv * 4 + (j >> 2);
         const Pt pt = fetch_point(src, m, false);
-        Act X;
         float* h7_lane = (h7_out != nullptr && m < src.M) ? h7_out + (size_t)m * 256 : nullptr;
-        const float v = surface_chain<true>(X, pt.x, pt.y, pt.z, g, cq - 1, p, aux, h7_lane);
+        const float v = surface_chain<1>(pt.x, pt.y, pt.z, g, cq - 1, s, aux, h7_lane, cq == 0);
         if (m < src.M && g == 0) {
             if (cq == 0) {
                 float sdf = v + aux[SURF_AUX_B8];
@@ -379,7 +509,7 @@ k_sdf_nabla_bf16(const float* __restrict__ blob, PointSrc src, float R_bg, float
 // K3b (split bf16): radiance net.  VE extra units: 1 (VolSDF, 9 extras) or 2 (NeuS, 33 extras).
 // =======================================================================================
 template <int VE>
-__device__ __forceinline__ void radiance_extras(const Pt& pt, float nx, float ny, float nz, int g, Act& X) {
+__device__ __forceinline__ void radiance_extras(const Pt& pt, float nx, float ny, float nz, int g, Unit (&X)[VE]) {
     constexpr int NE = (VE == 1) ? 9 : 33;
     float ex[VE * 32];
 #pragma unroll
@@ -393,9 +523,9 @@ __device__ __forceinline__ void radiance_extras(const Pt& pt, float nx, float ny
         for (int k = 0; k < 4; ++k)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                float s, co;
-                sincosf(v[c] * (float)(1 << k), &s, &co);
-                ex[6 + 6 * k + c] = s;
+                float sn, co;
+                sincosf(v[c] * (float)(1 << k), &sn, &co);
+                ex[6 + 6 * k + c] = sn;
                 ex[6 + 6 * k + 3 + c] = co;
             }
     }
@@ -413,8 +543,8 @@ __device__ __forceinline__ void radiance_extras(const Pt& pt, float nx, float ny
             split2(a, b, sh, sl);
             hi[pr] = sh; lo[pr] = sl;
         }
-        X.h[8 + q] = hi;
-        X.l[8 + q] = lo;
+        X[q].h = hi;
+        X[q].l = lo;
     }
 }
 
@@ -424,52 +554,68 @@ k_radiance_bf16(const float* __restrict__ blob, PointSrc src, const float* __res
                 const float* __restrict__ h7_in, float* __restrict__ rgb_out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int* hdr = reinterpret_cast<const int*>(blob);
-    float* aux = smem + 2 * CHUNK_FLOATS_MAX;
+    float* aux = smem + 2 * CHUNK_FLOATS;
     const int lane = lane_id(), g = lane >> 4, j = lane & 15, wv = wave_id();
     load_aux(aux, blob, hdr, RAD_AUX_FLOATS);
     const unsigned ntiles = (src.M + 127u) / 128u;
     if (blockIdx.x >= ntiles) return;
-    Pipe p{blob, reinterpret_cast<const int*>(aux + AUX_FLOATS_MAX), smem, hdr[2], 0, 0, 0, 0, false};
-    p.wrap = (blockIdx.x + gridDim.x) < ntiles;
-    pipe_start(p);
+    Stream s = make_stream(blob, aux, smem, hdr[2]);
+    s.wrap = (blockIdx.x + gridDim.x) < ntiles;
+    stream_start(s);
     for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        p.wrap = (tile + gridDim.x) < ntiles;
+        s.wrap = (tile + gridDim.x) < ntiles;
         const unsigned m = tile * 128u + wv * 16 + j;
         const bool valid = m < src.M;
         const Pt pt = fetch_point(src, m, true);
-        Act X;
         float nx = 0.f, ny = 0.f, nz = 0.f;
         if (valid) { nx = nabla_in[(size_t)m * 3 + 0]; ny = nabla_in[(size_t)m * 3 + 1]; nz = nabla_in[(size_t)m * 3 + 2]; }
-        // h7 -> units: unit u slot e < 4: feature 32u + 4g + e; e >= 4: 32u + 16 + 4g + (e - 4)
+        Acc A, B;
+        Unit x0, x0n, none[1];
+        {
+            // h7 -> units: unit u slot e < 4: feature 32u + 4g + e; e >= 4: 32u + 16 + 4g + (e - 4)
+            Unit hu[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            f32x4 lo4 = {0.f, 0.f, 0.f, 0.f}, hi4 = {0.f, 0.f, 0.f, 0.f};
-            if (valid) {
-                const float* s0 = h7_in + (size_t)m * 256 + 32 * u + 4 * g;
-                lo4 = *reinterpret_cast<const f32x4*>(s0);
-                hi4 = *reinterpret_cast<const f32x4*>(s0 + 16);
+            for (int u = 0; u < 8; ++u) {
+                f32x4 lo4 = {0.f, 0.f, 0.f, 0.f}, hi4 = {0.f, 0.f, 0.f, 0.f};
+                if (valid) {
+                    const float* s0 = h7_in + (size_t)m * 256 + 32 * u + 4 * g;
+                    lo4 = *reinterpret_cast<const f32x4*>(s0);
+                    hi4 = *reinterpret_cast<const f32x4*>(s0 + 16);
+                }
+                unsigned sh[4], sl[4];
+                split2(lo4[0], lo4[1], sh[0], sl[0]);
+                split2(lo4[2], lo4[3], sh[1], sl[1]);
+                split2(hi4[0], hi4[1], sh[2], sl[2]);
+                split2(hi4[2], hi4[3], sh[3], sl[3]);
+                hu[u].h = u32x4{sh[0], sh[1], sh[2], sh[3]};
+                hu[u].l = u32x4{sl[0], sl[1], sl[2], sl[3]};
             }
-            unsigned sh[4], sl[4];
-            split2(lo4[0], lo4[1], sh[0], sl[0]);
-            split2(lo4[2], lo4[3], sh[1], sl[1]);
-            split2(hi4[0], hi4[1], sh[2], sl[2]);
-            split2(hi4[2], hi4[3], sh[3], sl[3]);
-            X.h[u] = u32x4{sh[0], sh[1], sh[2], sh[3]};
-            X.l[u] = u32x4{sl[0], sl[1], sl[2], sl[3]};
+            none[0] = hu[0];
+            x0 = hu[0];
+            // geometry feature = W8[1:] h7 + b8[1:] (no activation)
+            const EpiCtx ec{-INFINITY, -INFINITY, true};
+            layer<2, 0, 8, true>(B, A, x0, hu, x0n, s, aux, ec);
         }
-        radiance_extras<VE>(pt, nx, ny, nz, g, X);
-        float dot[3] = {0.f, 0.f, 0.f};
-        Epi e{aux, -INFINITY, aux + RAD_AUX_ROWS, nullptr};
-        // L = 0: geometry feature (no activation); L = 1: [feat | x, v, n] -> 256 ReLU; L = 2, 3: ReLU; L = 4: LAST
+        x0 = x0n;
+        {
+            // [feat | x, v, n] -> 256, ReLU
+            Unit ex[VE];
+            radiance_extras<VE>(pt, nx, ny, nz, g, ex);
+            const EpiCtx ec{-INFINITY, 0.f, true};
+            layer<2, 8, VE, true>(A, B, x0, ex, x0n, s, aux + 256, ec);
+        }
+        A = B;
+        x0 = x0n;
+        const EpiCtx ec{0.f, 0.f, true};
 #pragma nounroll
-        for (int L = 0; L < 4; ++L) {
-            e.bias = aux + L * 256;
-            e.floor = (L == 0) ? -INFINITY : 0.f;
-            run_layer<8, VE, false, false, false, 3>(X, p, e, dot, (L == 1) ? VE : 0);
+        for (int L = 2; L < 4; ++L) {
+            layer<2, 8, 0, true>(A, B, x0, none, x0n, s, aux + L * 256, ec);
+            A = B;
+            x0 = x0n;
         }
-        e.bias = aux + 4 * 256;
-        e.floor = 0.f;
-        run_layer<8, 0, false, false, true, 3>(X, p, e, dot, 0);
+        layer<2, 8, 0, false>(A, B, x0, none, x0n, s, aux + 4 * 256, ec);
+        float dot[3] = {0.f, 0.f, 0.f};
+        last_epilogue<2, 3>(B, aux + RAD_AUX_ROWS, dot, nullptr, ec);
         float c[3];
 #pragma unroll
         for (int n = 0; n < 3; ++n) c[n] = sigmoidf_(sum_over_groups(dot[n]) + aux[RAD_AUX_BF + n]);

@@ -308,6 +308,8 @@ class PackPlanBF16(PackPlan):
             offs.append(offs[-1] + (len(c) // 512) * TS_FLOATS)
         self.nc = len(chunk_indices)
         assert self.nc + 1 <= 128
+        # the kernel's weight stream always copies 64 KiB per chunk: a short chunk must be followed by more blob
+        assert offs[-1] - offs[-2] == CHUNK_KS * 16 * TS_FLOATS, "last chunk of a bf16 program must be a full one"
         self.aux_off = offs[-1]
         self.cindex = np.concatenate(chunk_indices)
         self.aindex = aux
