@@ -12,10 +12,12 @@ own view per step (views of a camera orbit round-robin over ranks - how the refe
 shards) and the rendered tiles are all-gathered over RCCL: weak scaling, value = all rays of all ranks /
 max-over-ranks time.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel k_sdf_only (fused encode + SDF MLP on
-`v_mfma_f32_16x16x4_f32`): achieved = algorithmic flops per launch (F_sdf = 1,049,088 per point, SURVEY.md
-8d) / average launch duration from HIP events recorded on the launching stream during the timed steps;
-peak = 157.3 TFLOP/s (fp32-input MFMA, MI355X_MICROARCH.md).  `cpu_baseline` times the CPU oracle (a
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (fused encode + SDF MLP): achieved =
+algorithmic flops per launch (F_sdf = 1,049,088 per point) / average launch duration from HIP
+events recorded on the launching stream during the timed steps.  --precision bf16x3 (default): k_sdf_only_bf16,
+fp32 operands split into two bf16 terms, three v_mfma_f32_16x16x32_bf16 per product, fp32 accumulate (error
+~2^-17, parity tests at 1e-3 like fp32); peak = 2,500 TFLOP/s dense bf16, of which a 3-MFMA product can reach
+1/3.  --precision fp32: k_sdf_only on v_mfma_f32_16x16x4_f32 (exact fp32 products), peak = 157.3 TFLOP/s.  `cpu_baseline` times the CPU oracle (a
 PyTorch port of the reference algorithm; kind "port") on a strided subset of the same frame's rays.
 """
 import argparse
@@ -43,7 +45,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--beta", type=float, default=0.01)
-    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
+    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="bf16x3",
                     help="fp32: exact v_mfma_f32_16x16x4_f32; bf16x3: split-bf16 operands on v_mfma_f32_16x16x32_bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=768)
@@ -132,6 +134,9 @@ def main():
                     "launches": int(launches), "avg_launch_ms": round(ms / launches, 4),
                     "points_per_launch": int(points / launches),
                     "flops_per_point": F_SDF}
+        if args.precision == "bf16x3":
+            # every algorithmic product is three bf16 MFMAs (hi.hi + hi.lo + lo.hi): the matrix cores do 3x `achieved`
+            roofline["mfma_hw_frac"] = round(3.0 * achieved / peak, 4)
         # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
         # separate runs; (2*FETCH + WRITE) KiB with the gfx950 FETCH_SIZE correction) - bench.py itself cannot
         # read hardware counters.
