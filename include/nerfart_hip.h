@@ -15,8 +15,11 @@
  *     there and in DESIGN.md): `surf_blob` = SDF net, `rad_blob` = geometry-feature rows + radiance net.
  *   - `precision` selects the matrix-core path AND the blob format it expects:
  *       0 = fp32-exact (v_mfma_f32_16x16x4_f32; blobs from surface_plan()/radiance_plan()),
- *       1 = split bf16 "bf16x3" (3 x v_mfma_f32_32x32x16_bf16 per k-step on hi/lo operand splits, ~2^-16
- *           relative per product; blobs from surface_plan_bf16()/radiance_plan_bf16()).
+ *       1 = split bf16 "bf16x3" (3 x v_mfma_f32_16x16x32_bf16 per k-step on hi/lo operand splits, ~2^-16
+ *           relative per product; blobs from surface_plan_bf16()/radiance_plan_bf16()).  nerfart_sdf_nabla_fwd*
+ *           then runs REVERSE mode (forward sweep + transposed-weight sweep in one kernel) and keeps one 117 MiB
+ *           scratch per (device, stream) inside the library for the life of the process; precision 2 (these two
+ *           entry points only) selects the forward-mode tangent kernel on the same blob (cross-checks).
  *   - point sources: either an explicit array pts[M,3], or ("_rays" variants) rays + per-ray depths:
  *     point m = slot m / n_per_ray, sample m % n_per_ray, ray = ray_idx ? ray_idx[slot] : slot,
  *     x = rays_o[ray] + rays_d[ray] * depth[slot * depth_stride + sample]  (two roundings, as the

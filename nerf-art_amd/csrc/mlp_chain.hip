@@ -435,10 +435,22 @@ namespace nerfart {
 int sdf_bf16(const float* blob, const PointSrc& s, float R_bg, float* out, int out_stride, hipStream_t st);
 int sdf_nabla_bf16(const float* blob, const PointSrc& s, float R_bg, float* sdf, float* nabla, float* h7, hipStream_t st);
 int radiance_bf16(const float* blob, int view_tiles, const PointSrc& s, const float* nabla, const float* h7, float* rgb, hipStream_t st);
-static int check_precision(int precision) {
-    if (precision == 0 || precision == 1) return 0;
+size_t sdf_grad_ws_bytes();
+int sdf_grad_bf16(const float* blob, const PointSrc& s, float R_bg, float* sdf, float* nabla, float* h7, void* ws, hipStream_t st);
+void* grad_scratch(hipStream_t st, size_t bytes);
+static int check_precision(int precision, bool allow_fwd_tangents = false) {
+    if (precision == 0 || precision == 1 || (allow_fwd_tangents && precision == 2)) return 0;
     set_last_error("precision must be 0 (fp32-exact MFMA) or 1 (split-bf16 'bf16x3' MFMA)");
     return 2;
+}
+// precision 1: reverse-mode kernel (one column per point); precision 2: the forward-mode tangent quads (kept for
+// cross-checks - same blob, 2.1x the matrix work)
+static int sdf_nabla_bf16_dispatch(int precision, const float* blob, const PointSrc& s, float R_bg, float* sdf, float* nabla,
+                                   float* h7, hipStream_t st) {
+    if (precision == 2) return sdf_nabla_bf16(blob, s, R_bg, sdf, nabla, h7, st);
+    void* ws = grad_scratch(st, sdf_grad_ws_bytes());
+    if (!ws) { set_last_error("sdf_nabla_fwd: could not allocate the reverse-mode scratch (117 MiB per stream)"); return 1; }
+    return sdf_grad_bf16(blob, s, R_bg, sdf, nabla, h7, ws, st);
 }
 }  // namespace nerfart
 
@@ -473,8 +485,8 @@ int nerfart_sdf_nabla_fwd(const float* blob, int precision, const float* pts, lo
     if (M == 0) return 0;
     PointSrc s = make_src(pts, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, M);
     if (int rc = validate_src(s)) return rc;
-    if (int rc = check_precision(precision)) return rc;
-    if (precision == 1) return sdf_nabla_bf16(blob, s, R_bg, sdf_out, nabla_out, h7_out, (hipStream_t)stream);
+    if (int rc = check_precision(precision, true)) return rc;
+    if (precision >= 1) return sdf_nabla_bf16_dispatch(precision, blob, s, R_bg, sdf_out, nabla_out, h7_out, (hipStream_t)stream);
     return launch_chain(1, M, k_sdf_nabla, (unsigned)((M + 31) / 32), (hipStream_t)stream, blob, s, R_bg, sdf_out, nabla_out, h7_out);
 }
 
@@ -486,8 +498,8 @@ int nerfart_sdf_nabla_fwd_rays(const float* blob, int precision, const float* ra
     if (M == 0) return 0;
     PointSrc s = make_src(nullptr, nullptr, rays_o, rays_d, ray_idx, depth, n_per_ray, depth_stride, M);
     if (int rc = validate_src(s)) return rc;
-    if (int rc = check_precision(precision)) return rc;
-    if (precision == 1) return sdf_nabla_bf16(blob, s, R_bg, sdf_out, nabla_out, h7_out, (hipStream_t)stream);
+    if (int rc = check_precision(precision, true)) return rc;
+    if (precision >= 1) return sdf_nabla_bf16_dispatch(precision, blob, s, R_bg, sdf_out, nabla_out, h7_out, (hipStream_t)stream);
     return launch_chain(1, M, k_sdf_nabla, (unsigned)((M + 31) / 32), (hipStream_t)stream, blob, s, R_bg, sdf_out, nabla_out, h7_out);
 }
 

@@ -154,8 +154,12 @@ __device__ __forceinline__ const float* stream_acquire(Stream& s) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Epilogue slices.  MODE 0: softplus(beta = 100); 1: softplus value / tangent columns (quads); 2: max(z, floor).
-// One pair of values goes through three slices: PH 0 (exp, rcp) -> PH 1 (log, select) -> PH 2 (split to bf16 hi/lo).
+// Epilogue slices.  One pair of values goes through three slices: PH 0 (exp, rcp / decode) -> PH 1 (log, select /
+// multiply) -> PH 2 (split to bf16 hi/lo).  MODE:
+//   0 softplus(beta = 100)                         3 reverse sweep: z * softplus'(z_l), softplus' from the unorm16 pair `din`
+//   1 softplus value / tangent columns (quads)     4 reverse sweep, first step: softplus'(z) itself
+//   2 max(z, floor)                                5 forward sweep of the reverse-mode kernel: softplus + `dout` =
+//                                                    softplus'(z) of the pair as packed unorm16
 // ---------------------------------------------------------------------------------------
 // max(z, 0) in one instruction (fmaxf() first canonicalises z with a v_max_f32 z, z)
 __device__ __forceinline__ float relu1(float z) {
@@ -165,24 +169,35 @@ __device__ __forceinline__ float relu1(float z) {
 }
 
 template <int MODE, int PH>
-__device__ __forceinline__ void epi_phase(float z0, float z1, Work& w, unsigned& hi, unsigned& lo, float floor, bool is_val) {
+__device__ __forceinline__ void epi_phase(float z0, float z1, Work& w, unsigned& hi, unsigned& lo, float floor, bool is_val,
+                                          unsigned din, unsigned& dout) {
 #ifdef NERFART_ABLATE_EPI       // timing experiments only: no activation arithmetic
     if (PH == 2) { hi = __float_as_uint(z0); lo = __float_as_uint(z1); }
     return;
 #endif
     if constexpr (PH == 0) {
-        if constexpr (MODE != 2) {
+        if constexpr (MODE == 0 || MODE == 1 || MODE == 4 || MODE == 5) {
             w.e0 = __builtin_amdgcn_exp2f(fabsf(z0) * -144.269504088896340736f);     // exp(-|100 z|)
             w.e1 = __builtin_amdgcn_exp2f(fabsf(z1) * -144.269504088896340736f);
         }
-        if constexpr (MODE == 1) {
+        if constexpr (MODE == 1 || MODE == 4 || MODE == 5) {
             w.r0 = __builtin_amdgcn_rcpf(1.0f + w.e0);
             w.r1 = __builtin_amdgcn_rcpf(1.0f + w.e1);
+        }
+        if constexpr (MODE == 3) {
+            w.r0 = (float)(din & 0xffffu);          // 65535 * softplus'(z_l): the 1/65535 lives in the packed weights
+            w.r1 = (float)(din >> 16);
         }
     } else if constexpr (PH == 1) {
         if constexpr (MODE == 2) {
             w.y0 = fmaxf(z0, floor);
             w.y1 = fmaxf(z1, floor);
+        } else if constexpr (MODE == 3) {
+            w.y0 = z0 * w.r0;
+            w.y1 = z1 * w.r1;
+        } else if constexpr (MODE == 4) {
+            w.y0 = (z0 >= 0.f) ? w.r0 : w.e0 * w.r0;
+            w.y1 = (z1 >= 0.f) ? w.r1 : w.e1 * w.r1;
         } else {
             const float v0 = relu1(z0) + __builtin_amdgcn_logf(1.0f + w.e0) * (0.69314718055994530942f / 100.0f);
             const float v1 = relu1(z1) + __builtin_amdgcn_logf(1.0f + w.e1) * (0.69314718055994530942f / 100.0f);
@@ -196,6 +211,12 @@ __device__ __forceinline__ void epi_phase(float z0, float z1, Work& w, unsigned&
                 w.y0 = v0;
                 w.y1 = v1;
             }
+            if constexpr (MODE == 5) {
+                const float d0 = (z0 >= 0.f) ? w.r0 : w.e0 * w.r0;
+                const float d1 = (z1 >= 0.f) ? w.r1 : w.e1 * w.r1;
+                typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+                dout = __builtin_bit_cast(unsigned, (u16x2)__builtin_amdgcn_cvt_pknorm_u16(d0, d1));
+            }
         }
     } else {
         split2(w.y0, w.y1, hi, lo);
@@ -203,8 +224,29 @@ __device__ __forceinline__ void epi_phase(float z0, float z1, Work& w, unsigned&
 }
 
 // ---------------------------------------------------------------------------------------
+// Reverse-mode kernel only: softplus'(z_l) travels from the forward to the backward sweep through a per-workgroup
+// scratch in global memory (stays in L2 / Infinity Cache): unit u of layer l = 16 B per lane (4 pairs of unorm16) at
+// ws + ((8 l + u) * 8 + wave) * 1024 + lane * 16.
+// ---------------------------------------------------------------------------------------
+struct GradCtx {
+    char* ws;                 // scratch of this wave: workgroup base + wave * 1024 (wave uniform)
+    unsigned voff;            // lane * 16
+    int layer;                // layer whose weights are being applied (wave uniform)
+    u32x4 dbuf[2];            // backward sweep: softplus' units, k-step parity double buffer
+    u32x4 dacc;               // forward sweep: unit being packed
+    u32x4 dpend;              // forward sweep: finished unit, stored at the first triple of the next k-step
+    char* pend_ptr;
+};
+// Plain (compiler-visible) loads: hipcc then keeps its own vmcnt bookkeeping for them - with the LDS-DMA pieces it
+// cannot see this can only make its wait stricter.  (Hand-counted asm loads gave wrong gradients on random waves.)
+__device__ __forceinline__ void d_load(GradCtx& gc, int idx, int buf) {
+    const char* ptr = gc.ws + (size_t)idx * 8192;
+    gc.dbuf[buf] = *reinterpret_cast<const u32x4*>(ptr + gc.voff);
+}
+
+// ---------------------------------------------------------------------------------------
 // The work of one weight chunk, one "item" = (k-step, output tile) at a time: wait for the item's A fragments,
-// 3 MFMAs, then the fillers: the fragment reads two items ahead, an LDS-DMA piece (first 4 items of a k-step),
+// 3 MFMAs, then the fillers: the fragment reads two items ahead, an LDS-DMA piece (items 5..8 of a k-step),
 // one epilogue slice (last 12 items of a hosting k-step).  LDS returns in order: with items it, it+1, it+2
 // outstanding (2 reads each) item it has landed at lgkmcnt(4) (cdna_hip_programming.md 5.7, form ii).
 // ---------------------------------------------------------------------------------------
@@ -225,16 +267,26 @@ __device__ __forceinline__ void lds_wait_pair(u32x4& fh, u32x4& fl) {
 }
 
 // Layer shape: NH input units come from the previous layer's accumulators P (k-steps 0..NH-1, built just in
-// time), NX are ready-made units xs[] (k-steps NH..NH+NX-1: encodings, extras, activations from memory).
-// NEXT0: the last k-step also builds unit 0 of the NEXT layer from this layer's tiles 0 and 1.
-template <int MODE, int NH, int NX, bool NEXT0, int C, int NKC, int IT>
+// time with epilogue MODE), NX are ready-made units xs[] (k-steps NH..NH+NX-1: encodings, extras, activations
+// from memory).  NEXT0: the last k-step also builds unit 0 of the NEXT layer from this layer's tiles 0 and 1, with
+// epilogue MQ.  ZINIT: accumulators start at 0 instead of the bias.  PEND_IN / LOADNEXT (reverse-mode kernel): a
+// softplus' unit of the previous layer is waiting to be stored / the following layer's first unit needs its load.
+template <int MODE_, int MQ_, int NH_, int NX_, bool NEXT0_, bool ZINIT_ = false, bool PEND_IN_ = false, bool LOADNEXT_ = false>
+struct Cfg {
+    static constexpr int MODE = MODE_, MQ = MQ_, NH = NH_, NX = NX_, NXA = NX_ > 0 ? NX_ : 1, NKS = NH_ + NX_;
+    static constexpr bool NEXT0 = NEXT0_, ZINIT = ZINIT_, PEND_IN = PEND_IN_, LOADNEXT = LOADNEXT_;
+    // unit whose epilogue is hosted by k-step ks: a unit of act(P) (0..7), 100 = unit 0 of act(Q), -1 = none
+    static constexpr int hosted(int ks) { return (ks + 1 < NH_) ? ks + 1 : ((NEXT0_ && ks == NH_ + NX_ - 1) ? 100 : -1); }
+    static constexpr int mode_of(int hu) { return hu == 100 ? MQ_ : MODE_; }
+};
+
+template <class L, int C, int NKC, int IT>
 struct Items {
-    static constexpr int NXA = NX > 0 ? NX : 1;
-    static __device__ __forceinline__ void run(const Acc& P, Acc& Q, Unit (&xb)[2], const Unit (&xs)[NXA], Unit& x0n, Work& w,
-                                               Ring& r, unsigned addr, const Stream& s, const EpiCtx& ec) {
+    static __device__ __forceinline__ void run(const Acc& P, Acc& Q, Unit (&xb)[2], const Unit (&xs)[L::NXA], Unit& x0n, Work& w,
+                                               Ring& r, unsigned addr, const Stream& s, const EpiCtx& ec, GradCtx& gc) {
         constexpr int N = NKC * 16;
         if constexpr (IT < N) {
-            constexpr int kk = IT >> 4, T = IT & 15, ks = CHUNK_KS * C + kk, NKS = NH + NX;
+            constexpr int kk = IT >> 4, T = IT & 15, ks = CHUNK_KS * C + kk;
             constexpr int S = IT % 3, S2 = (IT + 2) % 3;
             constexpr int PENDING = (IT + 2 < N) ? 4 : ((IT + 1 < N) ? 2 : 0);
             if constexpr (IT + 2 < N) {
@@ -243,41 +295,66 @@ struct Items {
                 else lds_read_pair<(IT + 2) * 2048>(r.h2, r.l2, addr);
             }
             u32x4 bh, bl;
-            if constexpr (ks < NH) { bh = xb[ks & 1].h; bl = xb[ks & 1].l; }
-            else { bh = xs[ks - NH].h; bl = xs[ks - NH].l; }
+            if constexpr (ks < L::NH) { bh = xb[ks & 1].h; bl = xb[ks & 1].l; }
+            else { bh = xs[ks - L::NH].h; bl = xs[ks - L::NH].l; }
             if constexpr (S == 0) { lds_wait_pair<PENDING>(r.h0, r.l0); Q.t[T] = mfma3(r.h0, r.l0, bh, bl, Q.t[T]); }
             else if constexpr (S == 1) { lds_wait_pair<PENDING>(r.h1, r.l1); Q.t[T] = mfma3(r.h1, r.l1, bh, bl, Q.t[T]); }
             else { lds_wait_pair<PENDING>(r.h2, r.l2); Q.t[T] = mfma3(r.h2, r.l2, bh, bl, Q.t[T]); }
-            // LDS-DMA: the 8 pieces per wave of the next chunk go out during the first 4 items of each k-step
-            if constexpr (T < 4) {
-                if constexpr (NKC == 2) stream_piece<kk * 4 + T>(s);
-                else { stream_piece<2 * T>(s); stream_piece<2 * T + 1>(s); }
+            constexpr int HU = L::hosted(ks);
+            constexpr int HM = L::mode_of(HU);
+            if constexpr (T == 0) {
+                // reverse-mode kernel, forward sweep: store the softplus' unit finished in the previous k-step
+                constexpr int HUP = (ks == 0) ? (L::PEND_IN ? 100 : -1) : L::hosted(ks - 1);
+                constexpr bool STORE = (ks == 0) ? L::PEND_IN : (HUP >= 0 && L::mode_of(HUP) == 5);
+                if constexpr (STORE) *reinterpret_cast<u32x4*>(gc.pend_ptr + gc.voff) = gc.dpend;
+                // backward sweep: load the softplus' unit needed by the slices of the NEXT k-step
+                if constexpr (ks + 1 < L::NKS) {
+                    constexpr int HN = L::hosted(ks + 1);
+                    if constexpr (HN >= 0 && L::mode_of(HN) == 3) {
+                        if constexpr (HN == 100) d_load(gc, (gc.layer - 1) * 8, (ks + 1) & 1);
+                        else d_load(gc, gc.layer * 8 + HN, (ks + 1) & 1);
+                    }
+                } else if constexpr (L::LOADNEXT) {
+                    d_load(gc, (gc.layer - 1) * 8 + 1, (ks + 1) & 1);
+                }
+            }
+            // LDS-DMA: the 8 pieces per wave of the next chunk go out during items 5..8 of each k-step (after the
+            // first use of a softplus' unit in item 4: the compiler's wait for that load drains the VMEM queue)
+            if constexpr (T >= 5 && T < 9) {
+                if constexpr (NKC == 2) stream_piece<kk * 4 + T - 5>(s);
+                else { stream_piece<2 * (T - 5)>(s); stream_piece<2 * (T - 5) + 1>(s); }
             }
             // epilogue slice hosted by this item
-            constexpr int HU = (ks + 1 < NH) ? ks + 1 : ((NEXT0 && ks == NKS - 1) ? 100 : -1);
             if constexpr (HU >= 0 && T >= 4) {
                 constexpr int pr = (T - 4) / 3, ph = (T - 4) % 3;
                 constexpr int tile = (HU == 100 ? 0 : 2 * HU) + (pr >> 1), r0 = 2 * (pr & 1);
-                unsigned hi = 0, lo = 0;
+                unsigned hi = 0, lo = 0, dout = 0;
+                const unsigned din = (HM == 3) ? gc.dbuf[ks & 1][pr] : 0u;
                 if constexpr (HU == 100) {
-                    epi_phase<MODE, ph>(Q.t[tile][r0], Q.t[tile][r0 + 1], w, hi, lo, ec.floor_q, ec.is_val);
+                    epi_phase<HM, ph>(Q.t[tile][r0], Q.t[tile][r0 + 1], w, hi, lo, ec.floor_q, ec.is_val, din, dout);
                     if constexpr (ph == 2) { x0n.h[pr] = hi; x0n.l[pr] = lo; }
                 } else {
-                    epi_phase<MODE, ph>(P.t[tile][r0], P.t[tile][r0 + 1], w, hi, lo, ec.floor_p, ec.is_val);
+                    epi_phase<HM, ph>(P.t[tile][r0], P.t[tile][r0 + 1], w, hi, lo, ec.floor_p, ec.is_val, din, dout);
                     if constexpr (ph == 2) { xb[HU & 1].h[pr] = hi; xb[HU & 1].l[pr] = lo; }
+                }
+                if constexpr (HM == 5) {
+                    if constexpr (ph == 1) gc.dacc[pr] = dout;
+                    if constexpr (T == 15) {
+                        gc.dpend = gc.dacc;
+                        gc.pend_ptr = gc.ws + (size_t)((HU == 100 ? gc.layer * 8 : (gc.layer - 1) * 8 + HU)) * 8192;
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            Items<MODE, NH, NX, NEXT0, C, NKC, IT + 1>::run(P, Q, xb, xs, x0n, w, r, addr, s, ec);
+            Items<L, C, NKC, IT + 1>::run(P, Q, xb, xs, x0n, w, r, addr, s, ec, gc);
         }
     }
 };
 
-template <int MODE, int NH, int NX, bool NEXT0, int C>
-__device__ __forceinline__ void run_chunk(const Acc& P, Acc& Q, Unit (&xb)[2], const Unit (&xs)[NX > 0 ? NX : 1], Unit& x0n,
-                                          Work& w, Stream& s, const EpiCtx& ec) {
-    constexpr int NKS = NH + NX;
-    constexpr int NKC = (NKS - CHUNK_KS * C) >= CHUNK_KS ? CHUNK_KS : (NKS - CHUNK_KS * C);
+template <class L, int C>
+__device__ __forceinline__ void run_chunk(const Acc& P, Acc& Q, Unit (&xb)[2], const Unit (&xs)[L::NXA], Unit& x0n,
+                                          Work& w, Stream& s, const EpiCtx& ec, GradCtx& gc) {
+    constexpr int NKC = (L::NKS - CHUNK_KS * C) >= CHUNK_KS ? CHUNK_KS : (L::NKS - CHUNK_KS * C);
     if constexpr (NKC > 0) {
         const float* wp = stream_acquire(s) + lane_id() * 4;
         const unsigned addr = (unsigned)(size_t)wp;        // LDS byte address of this lane's 16 bytes of item 0
@@ -287,15 +364,15 @@ __device__ __forceinline__ void run_chunk(const Acc& P, Acc& Q, Unit (&xb)[2], c
         Ring r;
         lds_read_pair<0>(r.h0, r.l0, addr);
         lds_read_pair<2048>(r.h1, r.l1, addr);
-        Items<MODE, NH, NX, NEXT0, C, NKC, 0>::run(P, Q, xb, xs, x0n, w, r, addr, s, ec);
-        run_chunk<MODE, NH, NX, NEXT0, C + 1>(P, Q, xb, xs, x0n, w, s, ec);
+        Items<L, C, NKC, 0>::run(P, Q, xb, xs, x0n, w, r, addr, s, ec, gc);
+        run_chunk<L, C + 1>(P, Q, xb, xs, x0n, w, s, ec, gc);
     }
 }
 
 // One dense layer: Q = bias + W . [act(P) | xs].  x0 = unit 0 of act(P) (built by the previous layer).
-template <int MODE, int NH, int NX, bool NEXT0>
-__device__ __forceinline__ void layer(const Acc& P, Acc& Q, const Unit& x0, const Unit (&xs)[NX > 0 ? NX : 1], Unit& x0n,
-                                      Stream& s, const float* bias, const EpiCtx& ec) {
+template <class L>
+__device__ __forceinline__ void layer(const Acc& P, Acc& Q, const Unit& x0, const Unit (&xs)[L::NXA], Unit& x0n,
+                                      Stream& s, const float* bias, const EpiCtx& ec, GradCtx& gc) {
     const int g = lane_id() >> 4;
     Unit xb[2];
     xb[0] = x0;
@@ -303,12 +380,16 @@ __device__ __forceinline__ void layer(const Acc& P, Acc& Q, const Unit& x0, cons
     // start at the bias (value columns; tangent columns start at 0): reg r of tile T is feature 16T + 4g + r
 #pragma unroll
     for (int T = 0; T < 16; ++T) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + 16 * T + 4 * g);
+        if constexpr (L::ZINIT) {
+            Q.t[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(bias + 16 * T + 4 * g);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Q.t[T][r] = ec.is_val ? b[r] : 0.f;
+            for (int r = 0; r < 4; ++r) Q.t[T][r] = ec.is_val ? b[r] : 0.f;
+        }
     }
     Work w = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    run_chunk<MODE, NH, NX, NEXT0, 0>(P, Q, xb, xs, x0n, w, s, ec);
+    run_chunk<L, 0>(P, Q, xb, xs, x0n, w, s, ec, gc);
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");     // last MFMA result -> first VALU reader (see mfma3)
 }
 
@@ -339,7 +420,7 @@ __device__ __forceinline__ void last_epilogue(const Acc& Q, const float* rows, f
 #pragma unroll
             for (int r = 0; r < 4; ++r) dot[n] = fmaf(y[r], w[r], dot[n]);
         }
-        if constexpr (MODE == 1) {
+        if constexpr (MODE != 2) {
             if (h7 != nullptr && ec.is_val) *reinterpret_cast<f32x4*>(h7 + 16 * T + 4 * g) = y;
         }
     }
@@ -409,20 +490,21 @@ __device__ __forceinline__ float surface_chain(float px, float py, float pz, int
     encode_units(px, py, pz, g, dq, enc);
     none[0] = enc[0];
     x0 = enc[0];
-    layer<MODE, 0, 2, true>(B, A, x0, enc, x0n, s, aux, ec);
+    GradCtx gc;
+    layer<Cfg<MODE, MODE, 0, 2, true>>(B, A, x0, enc, x0n, s, aux, ec, gc);
     x0 = x0n;
 #pragma nounroll
     for (int L = 1; L < 7; ++L) {
         if (L == 4) {
             encode_units(px, py, pz, g, dq, enc);
-            layer<MODE, 7, 2, true>(A, B, x0, enc, x0n, s, aux + L * 256, ec);
+            layer<Cfg<MODE, MODE, 7, 2, true>>(A, B, x0, enc, x0n, s, aux + L * 256, ec, gc);
         } else {
-            layer<MODE, 8, 0, true>(A, B, x0, none, x0n, s, aux + L * 256, ec);
+            layer<Cfg<MODE, MODE, 8, 0, true>>(A, B, x0, none, x0n, s, aux + L * 256, ec, gc);
         }
         A = B;
         x0 = x0n;
     }
-    layer<MODE, 8, 0, false>(A, B, x0, none, x0n, s, aux + 7 * 256, ec);
+    layer<Cfg<MODE, MODE, 8, 0, false>>(A, B, x0, none, x0n, s, aux + 7 * 256, ec, gc);
     float dot[1] = {0.f};
     last_epilogue<MODE, 1>(B, aux + SURF_AUX_ROW, dot, h7_lane, ec);
     return sum_over_groups(dot[0]);        // the 4 lane groups of a column hold complementary feature sets
@@ -506,6 +588,171 @@ k_sdf_nabla_bf16(const float* __restrict__ blob, PointSrc src, float R_bg, float
 }
 
 // =======================================================================================
+// K3a, reverse mode (split bf16): sdf + nabla + h7 with ONE column per point.  Forward sweep = K2 plus
+// softplus'(z_l) of layers 0..6 to the scratch; then d sdf / d a_{l-1} = W_l^T (d sdf / d a_l * softplus'(z_l))
+// for l = 7..0 through the transposed-weight chunks that follow the forward program in the blob
+// (packing.surface_plan_bf16): 1.97 M algorithmic flop per point instead of the 4.2 M of the forward-mode
+// quads, and a cheap multiply epilogue.  Rows 217..255 of the layer-4 and layer-0 steps are d sdf / d enc
+// (3 accumulator tiles kept from layer 4 to the end) and meet the encoding's Jacobian in registers.
+// =======================================================================================
+constexpr int GRAD_WS_PER_WG = 7 * 8 * 8 * 1024;           // 7 layers x 8 units x 8 waves x 1 KiB
+
+template <int IT>
+struct TailItems {     // layer-0 step: 8 k-steps x 3 output tiles from one 48 KiB chunk
+    static __device__ __forceinline__ void run(f32x4 (&E)[3], const Unit (&X)[8], Ring& r, unsigned addr, const Stream& s) {
+        constexpr int N = 24;
+        if constexpr (IT < N) {
+            constexpr int ks = IT / 3, t = IT % 3;
+            constexpr int S = IT % 3, S2 = (IT + 2) % 3;
+            constexpr int PENDING = (IT + 2 < N) ? 4 : ((IT + 1 < N) ? 2 : 0);
+            if constexpr (IT + 2 < N) {
+                if constexpr (S2 == 0) lds_read_pair<(IT + 2) * 2048>(r.h0, r.l0, addr);
+                else if constexpr (S2 == 1) lds_read_pair<(IT + 2) * 2048>(r.h1, r.l1, addr);
+                else lds_read_pair<(IT + 2) * 2048>(r.h2, r.l2, addr);
+            }
+            if constexpr (S == 0) { lds_wait_pair<PENDING>(r.h0, r.l0); E[t] = mfma3(r.h0, r.l0, X[ks].h, X[ks].l, E[t]); }
+            else if constexpr (S == 1) { lds_wait_pair<PENDING>(r.h1, r.l1); E[t] = mfma3(r.h1, r.l1, X[ks].h, X[ks].l, E[t]); }
+            else { lds_wait_pair<PENDING>(r.h2, r.l2); E[t] = mfma3(r.h2, r.l2, X[ks].h, X[ks].l, E[t]); }
+            if constexpr (IT < 8) stream_piece<IT>(s);
+            __builtin_amdgcn_sched_barrier(0);
+            TailItems<IT + 1>::run(E, X, r, addr, s);
+        }
+    }
+};
+
+__global__ void __launch_bounds__(WG_THREADS, 2)
+k_sdf_grad_bf16(const float* __restrict__ blob, PointSrc src, float R_bg, float* __restrict__ sdf_out,
+                float* __restrict__ nabla_out, float* __restrict__ h7_out, char* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int* hdr = reinterpret_cast<const int*>(blob);
+    float* aux = smem + 2 * CHUNK_FLOATS;
+    const int lane = lane_id(), g = lane >> 4, j = lane & 15, wv = wave_id();
+    load_aux(aux, blob, hdr, SURF_AUX_FLOATS);
+    const unsigned ntiles = (src.M + 127u) / 128u;
+    if (blockIdx.x >= ntiles) return;
+    Stream s = make_stream(blob, aux, smem, hdr[6]);          // forward + backward chunks
+    s.wrap = (blockIdx.x + gridDim.x) < ntiles;
+    stream_start(s);
+    GradCtx gc;
+    gc.ws = ws + (size_t)blockIdx.x * GRAD_WS_PER_WG + wv * 1024;
+    gc.voff = lane * 16;
+    gc.pend_ptr = gc.ws;
+    const EpiCtx ec{0.f, 0.f, true};
+    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        s.wrap = (tile + gridDim.x) < ntiles;
+        const unsigned m = tile * 128u + wv * 16 + j;
+        const Pt pt = fetch_point(src, m, false);
+        Acc A, B;
+        Unit x0, x0n, enc[2], none[1];
+        // ---------------- forward sweep ----------------
+        encode_units(pt.x, pt.y, pt.z, g, -1, enc);
+        none[0] = enc[0];
+        x0 = enc[0];
+        gc.layer = 0;
+        layer<Cfg<5, 5, 0, 2, true, false, false>>(B, A, x0, enc, x0n, s, aux, ec, gc);
+        x0 = x0n;
+#pragma nounroll
+        for (int L = 1; L < 7; ++L) {
+            gc.layer = L;
+            if (L == 4) {
+                encode_units(pt.x, pt.y, pt.z, g, -1, enc);
+                layer<Cfg<5, 5, 7, 2, true, false, true>>(A, B, x0, enc, x0n, s, aux + L * 256, ec, gc);
+            } else {
+                layer<Cfg<5, 5, 8, 0, true, false, true>>(A, B, x0, none, x0n, s, aux + L * 256, ec, gc);
+            }
+            A = B;
+            x0 = x0n;
+        }
+        gc.layer = 7;
+        // layer 7: its last k-step prepares unit 0 of softplus'(z_7) for the first backward step
+        layer<Cfg<5, 4, 8, 0, true, false, true>>(A, B, x0, none, x0n, s, aux + 7 * 256, ec, gc);
+        x0 = x0n;
+        {
+            float dot[1] = {0.f};
+            float* h7_lane = (h7_out != nullptr && m < src.M) ? h7_out + (size_t)m * 256 : nullptr;
+            last_epilogue<0, 1>(B, aux + SURF_AUX_ROW, dot, h7_lane, ec);
+            float sdf = sum_over_groups(dot[0]) + aux[SURF_AUX_B8];
+            if (R_bg > 0.f) {
+                const float d_bg = R_bg - sqrtf(pt.x * pt.x + pt.y * pt.y + pt.z * pt.z);
+                sdf = (d_bg < sdf) ? d_bg : sdf;
+            }
+            if (g == 0 && m < src.M) sdf_out[m] = sdf;
+        }
+        // ---------------- backward sweep: B = z_7 ----------------
+        layer<Cfg<4, 3, 8, 0, true, true, false, true>>(B, A, x0, none, x0n, s, aux, ec, gc);
+        x0 = x0n;
+        f32x4 E[3];
+#pragma nounroll
+        for (int L = 6; L > 1; --L) {
+            gc.layer = L;
+            layer<Cfg<3, 3, 8, 0, true, true, false, true>>(A, B, x0, none, x0n, s, aux, ec, gc);
+            if (L == 4) { E[0] = B.t[13]; E[1] = B.t[14]; E[2] = B.t[15]; }
+            A = B;
+            x0 = x0n;
+        }
+        gc.layer = 1;
+        layer<Cfg<3, 3, 8, 0, false, true, false, false>>(A, B, x0, none, x0n, s, aux, ec, gc);
+        // ---------------- layer 0: only the 39 encoding rows, on top of layer 4's ----------------
+        {
+            u32x4 d0[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const char* ptr = gc.ws + (size_t)u * 8192;
+                d0[u] = *reinterpret_cast<const u32x4*>(ptr + gc.voff);
+            }
+            Unit X[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) {
+                    const int tile = 2 * u + (pr >> 1), r0 = 2 * (pr & 1);
+                    const float y0 = B.t[tile][r0] * (float)(d0[u][pr] & 0xffffu);
+                    const float y1 = B.t[tile][r0 + 1] * (float)(d0[u][pr] >> 16);
+                    unsigned hi, lo;
+                    split2(y0, y1, hi, lo);
+                    X[u].h[pr] = hi; X[u].l[pr] = lo;
+                }
+            }
+            const float* wp = stream_acquire(s) + lane * 4;
+            const unsigned addr = (unsigned)(size_t)wp;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            Ring r;
+            lds_read_pair<0>(r.h0, r.l0, addr);
+            lds_read_pair<2048>(r.h1, r.l1, addr);
+            TailItems<0>::run(E, X, r, addr, s);
+            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+        }
+        // d sdf / d x = J_enc^T E: lane (g, j), tile t, reg r holds d sdf / d enc[f], f = 16 t + 4 g + r - 9
+        float part[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = 16 * t + 4 * g + r - 9;
+                const bool ok = (f >= 0) && (f < 39);
+                const int q = (f >= 3) ? f - 3 : 0;
+                const int k = q / 6, rem = q - 6 * k;
+                const int isc = rem / 3;
+                const int c = (f < 3) ? f : rem - 3 * isc;
+                const float xc = (c == 0) ? pt.x : ((c == 1) ? pt.y : pt.z);
+                const float fr = (float)(1 << k);
+                float sn, cs;
+                sincosf(xc * fr, &sn, &cs);
+                float jac = (f < 3) ? 1.f : ((isc == 0) ? cs * fr : -(sn * fr));
+                jac = ok ? jac : 0.f;
+                const float v = E[t][r] * jac;
+                part[0] += (c == 0) ? v : 0.f;
+                part[1] += (c == 1) ? v : 0.f;
+                part[2] += (c == 2) ? v : 0.f;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) part[c] = sum_over_groups(part[c]);
+        if (m < src.M && g < 3) nabla_out[(size_t)m * 3 + g] = (g == 0) ? part[0] : ((g == 1) ? part[1] : part[2]);
+    }
+}
+
+// =======================================================================================
 // K3b (split bf16): radiance net.  VE extra units: 1 (VolSDF, 9 extras) or 2 (NeuS, 33 extras).
 // =======================================================================================
 template <int VE>
@@ -571,6 +818,7 @@ k_radiance_bf16(const float* __restrict__ blob, PointSrc src, const float* __res
         if (valid) { nx = nabla_in[(size_t)m * 3 + 0]; ny = nabla_in[(size_t)m * 3 + 1]; nz = nabla_in[(size_t)m * 3 + 2]; }
         Acc A, B;
         Unit x0, x0n, none[1];
+        GradCtx gc;
         {
             // h7 -> units: unit u slot e < 4: feature 32u + 4g + e; e >= 4: 32u + 16 + 4g + (e - 4)
             Unit hu[8];
@@ -594,7 +842,7 @@ k_radiance_bf16(const float* __restrict__ blob, PointSrc src, const float* __res
             x0 = hu[0];
             // geometry feature = W8[1:] h7 + b8[1:] (no activation)
             const EpiCtx ec{-INFINITY, -INFINITY, true};
-            layer<2, 0, 8, true>(B, A, x0, hu, x0n, s, aux, ec);
+            layer<Cfg<2, 2, 0, 8, true>>(B, A, x0, hu, x0n, s, aux, ec, gc);
         }
         x0 = x0n;
         {
@@ -602,18 +850,18 @@ k_radiance_bf16(const float* __restrict__ blob, PointSrc src, const float* __res
             Unit ex[VE];
             radiance_extras<VE>(pt, nx, ny, nz, g, ex);
             const EpiCtx ec{-INFINITY, 0.f, true};
-            layer<2, 8, VE, true>(A, B, x0, ex, x0n, s, aux + 256, ec);
+            layer<Cfg<2, 2, 8, VE, true>>(A, B, x0, ex, x0n, s, aux + 256, ec, gc);
         }
         A = B;
         x0 = x0n;
         const EpiCtx ec{0.f, 0.f, true};
 #pragma nounroll
         for (int L = 2; L < 4; ++L) {
-            layer<2, 8, 0, true>(A, B, x0, none, x0n, s, aux + L * 256, ec);
+            layer<Cfg<2, 2, 8, 0, true>>(A, B, x0, none, x0n, s, aux + L * 256, ec, gc);
             A = B;
             x0 = x0n;
         }
-        layer<2, 8, 0, false>(A, B, x0, none, x0n, s, aux + 4 * 256, ec);
+        layer<Cfg<2, 2, 8, 0, false>>(A, B, x0, none, x0n, s, aux + 4 * 256, ec, gc);
         float dot[3] = {0.f, 0.f, 0.f};
         last_epilogue<2, 3>(B, aux + RAD_AUX_ROWS, dot, nullptr, ec);
         float c[3];
@@ -648,6 +896,10 @@ int sdf_bf16(const float* blob, const PointSrc& s, float R_bg, float* out, int o
 }
 int sdf_nabla_bf16(const float* blob, const PointSrc& s, float R_bg, float* sdf, float* nabla, float* h7, hipStream_t st) {
     return b16::launch_chain(1, (long long)s.M, b16::k_sdf_nabla_bf16, (s.M + 31u) / 32u, st, blob, s, R_bg, sdf, nabla, h7);
+}
+size_t sdf_grad_ws_bytes() { return (size_t)num_cus() * b16::GRAD_WS_PER_WG; }
+int sdf_grad_bf16(const float* blob, const PointSrc& s, float R_bg, float* sdf, float* nabla, float* h7, void* ws, hipStream_t st) {
+    return b16::launch_chain(1, (long long)s.M, b16::k_sdf_grad_bf16, (s.M + 127u) / 128u, st, blob, s, R_bg, sdf, nabla, h7, (char*)ws);
 }
 int radiance_bf16(const float* blob, int view_tiles, const PointSrc& s, const float* nabla, const float* h7, float* rgb, hipStream_t st) {
     const unsigned nt = (s.M + 127u) / 128u;

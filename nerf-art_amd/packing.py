@@ -299,24 +299,38 @@ def _layer_chunks_bf16(flat, name, out_dim, cols_fn, nu_base, nu_extra, row0=0, 
 
 
 class PackPlanBF16(PackPlan):
-    """Chunks hold bf16 hi/lo fragments, k-outer: float[k-step][T=16][term=2][lane=64][4] (= 8 bf16 per lane)."""
+    """Chunks hold bf16 hi/lo fragments, k-outer: float[k-step][T=16][term=2][lane=64][4] (= 8 bf16 per lane).
 
-    def __init__(self, prog, flat, chunk_indices, aux):
+    chunk_mul: optional per-chunk second gather (same length as the chunk's index) whose values multiply the
+    first (used to fold a row vector into a transposed matrix); chunk_scale: optional per-chunk constant.
+    nc_main: number of leading chunks that form the forward program (header word 2); header word 6 = all chunks."""
+
+    def __init__(self, prog, flat, chunk_indices, aux, chunk_mul=None, chunk_scale=None, nc_main=None):
         self.prog, self.flat = prog, flat
         offs = [HDR_INTS]
         for c in chunk_indices:
             offs.append(offs[-1] + (len(c) // 512) * TS_FLOATS)
-        self.nc = len(chunk_indices)
-        assert self.nc + 1 <= 128
-        # the kernel's weight stream always copies 64 KiB per chunk: a short chunk must be followed by more blob
-        assert offs[-1] - offs[-2] == CHUNK_KS * 16 * TS_FLOATS, "last chunk of a bf16 program must be a full one"
+        self.nc_all = len(chunk_indices)
+        self.nc = self.nc_all if nc_main is None else nc_main
+        assert self.nc_all + 1 <= 128
         self.aux_off = offs[-1]
         self.cindex = np.concatenate(chunk_indices)
+        self.cmul = None
+        if chunk_mul is not None:
+            one = flat.zero + 1                                  # pack() appends [0.0, 1.0] to the source vector
+            self.cmul = np.concatenate([m if m is not None else np.full(len(c), one, dtype=np.int64)
+                                        for m, c in zip(chunk_mul, chunk_indices)])
+        self.cscale = None
+        if chunk_scale is not None:
+            self.cscale = np.concatenate([np.full(len(c), sc, dtype=np.float32) for sc, c in zip(chunk_scale, chunk_indices)])
         self.aindex = aux
-        self.total = self.aux_off + len(aux)
+        # the kernels' weight stream always copies 64 KiB per chunk: zero padding keeps the copy of a short last
+        # chunk inside the blob
+        self.total = max(self.aux_off + len(aux), offs[-2] + CHUNK_KS * 16 * TS_FLOATS)
+        self.pad = self.total - (self.aux_off + len(aux))
         hdr = np.zeros(HDR_INTS, dtype=np.int32)
-        hdr[0], hdr[1], hdr[2], hdr[3], hdr[4], hdr[5] = MAGIC, prog, self.nc, self.total, self.aux_off, len(aux)
-        hdr[HDR_OFFS: HDR_OFFS + self.nc + 1] = offs
+        hdr[0], hdr[1], hdr[2], hdr[3], hdr[4], hdr[5], hdr[6] = MAGIC, prog, self.nc, self.total, self.aux_off, len(aux), self.nc_all
+        hdr[HDR_OFFS: HDR_OFFS + self.nc_all + 1] = offs
         self.header = hdr
         self._index_t = {}
 
@@ -327,18 +341,61 @@ class PackPlanBF16(PackPlan):
         scale = getattr(self, "scale", {})
         parts = [(tensors[n].detach().to(torch.float32) * scale[n] if n in scale else tensors[n].detach().to(torch.float32)).reshape(-1)
                  for n in self.flat.names]
-        parts.append(torch.zeros(1, dtype=torch.float32, device=dev))
+        parts.append(torch.tensor([0.0, 1.0], dtype=torch.float32, device=dev))
         src = torch.cat(parts)
         key = str(dev)
         if key not in self._index_t:
-            self._index_t[key] = (torch.from_numpy(self.cindex).to(dev), torch.from_numpy(self.aindex).to(dev))
-        ci, ai = self._index_t[key]
-        w = src[ci].reshape(-1, 64, 8)                        # [(k-step, tile) of all chunks, lane, e]
+            self._index_t[key] = (torch.from_numpy(self.cindex).to(dev), torch.from_numpy(self.aindex).to(dev),
+                                  None if self.cmul is None else torch.from_numpy(self.cmul).to(dev),
+                                  None if self.cscale is None else torch.from_numpy(self.cscale).to(dev))
+        ci, ai, cm, cs = self._index_t[key]
+        w = src[ci]
+        if cm is not None:
+            w = w * src[cm]
+        if cs is not None:
+            w = w * cs
+        w = w.reshape(-1, 64, 8)                              # [(k-step, tile) of all chunks, lane, e]
         hi = w.to(torch.bfloat16)                             # round-to-nearest-even
         lo = (w - hi.to(torch.float32)).to(torch.bfloat16)
         body = torch.stack([hi, lo], dim=1).contiguous().view(torch.float32).reshape(-1)   # [..][term][lane][4]
         hdr = torch.from_numpy(self.header.copy()).view(torch.float32).to(dev)
-        return torch.cat([hdr, body, src[ai]]).contiguous()
+        return torch.cat([hdr, body, src[ai], torch.zeros(self.pad, dtype=torch.float32, device=dev)]).contiguous()
+
+
+def _kstep_index_T(flat, name, ks, kfeat_fn, row_feature, tiles=range(16)):
+    """Transposed gather for the reverse-mode chain: index array [T in tiles][lane=64][e=8] of one k-step with
+    A[row][k] = W[kfeat][rowfeat]: W's ROW index comes from the k slot (kfeat_fn(ks, g, e), -1 = zero), W's COLUMN
+    index from the output row 16T + i (row_feature[16T + i], -1 = zero)."""
+    R, C = flat.shape[name]
+    tiles = list(tiles)
+    idx = np.full((len(tiles), 64, 8), flat.zero, dtype=np.int64)
+    i = np.arange(16)
+    for n, T in enumerate(tiles):
+        rf = row_feature[16 * T + i]
+        ok = rf >= 0
+        for g in range(4):
+            for e in range(8):
+                kf = kfeat_fn(ks, g, e)
+                if kf < 0 or kf >= R:
+                    continue
+                idx[n, (16 * g + i)[ok], e] = flat.base[name] + kf * C + rf[ok]
+    return idx.reshape(-1)
+
+
+def _kstep_mul_index(flat, name, row, ks, kfeat_fn, ntiles=16):
+    """Second gather matching _kstep_index_T: W2[row][kfeat] for every element (the value depends on the k slot only)."""
+    R, C = flat.shape[name]
+    idx = np.full((ntiles, 64, 8), flat.zero + 1, dtype=np.int64)
+    for g in range(4):
+        for e in range(8):
+            kf = kfeat_fn(ks, g, e)
+            if 0 <= kf < C:
+                idx[:, 16 * g: 16 * g + 16, e] = flat.base[name] + row * C + kf
+    return idx.reshape(-1)
+
+
+D_UNORM = 65535.0         # softplus'(z) in [0, 1] is handed from the forward to the backward sweep as unorm16
+GRAD_ENC_ROW0 = 217       # rows 217..255 of the backward outputs of layers 4 and 0 carry d sdf / d enc[0..38]
 
 
 def surface_plan_bf16(W: int = 256, D: int = 8, skips=(4,), multires: int = 6, W_geo_feat: int = 256) -> PackPlanBF16:
@@ -374,12 +431,35 @@ def surface_plan_bf16(W: int = 256, D: int = 8, skips=(4,), multires: int = 6, W
                 return f if f < in_dim else -1
             chunks += _layer_chunks_bf16(flat, f"w{l}", out_dim, fn, 8, 0)
     ar = np.arange
+    nc_fwd = len(chunks)
+    # ---- reverse-mode program (k_sdf_grad_bf16): d sdf / d a_{l-1} = W_l^T (d sdf / d a_l * softplus'(z_l)), l = 7..0.
+    # Transposed matrices, k slots in the same unit order (the backward inputs are the previous backward step's
+    # accumulators), output rows = the layer's input features in natural order.  Layer 7 absorbs the sdf row of
+    # the last linear layer (its input units are softplus'(z_7) alone); layers 6..0 absorb 1/65535 (unorm16
+    # softplus' from the forward sweep); layer 4's 1/sqrt(2) comes with plan.scale.  Layer 0 only has the 39
+    # encoding rows: they sit at rows 217..255 like layer 4's (3 output tiles, all 8 k-steps in one 48 KiB chunk).
+    mul, scl = [None] * nc_fwd, [1.0] * nc_fwd
+    nat = ar(256)
+    for l in range(D - 1, 0, -1):
+        out_dim, in_dim = dims[l]
+
+        def kf(ks, g, e, out_dim=out_dim):
+            f = unit_feature_hidden(ks, g, e)
+            return f if f < out_dim else -1
+        for c0 in range(0, 8, CHUNK_KS):
+            chunks.append(np.concatenate([_kstep_index_T(flat, f"w{l}", ks, kf, nat) for ks in range(c0, c0 + CHUNK_KS)]))
+            mul.append(np.concatenate([_kstep_mul_index(flat, f"w{D}", 0, ks, kf) for ks in range(c0, c0 + CHUNK_KS)]) if l == D - 1 else None)
+            scl.append(1.0 if l == D - 1 else 1.0 / D_UNORM)
+    enc_rows = np.where(nat >= GRAD_ENC_ROW0, nat - GRAD_ENC_ROW0, -1)
+    chunks.append(np.concatenate([_kstep_index_T(flat, "w0", ks, unit_feature_hidden, enc_rows, tiles=(13, 14, 15)) for ks in range(8)]))
+    mul.append(None)
+    scl.append(1.0 / D_UNORM)
     aux = [flat.vec_index(f"b{l}", _pad(ar(dims[l][0]), 256)) for l in range(D)]
     aux.append(flat.mat_index(f"w{D}", np.array([0]), ar(256)).reshape(-1))
     aux.append(flat.vec_index(f"b{D}", _pad(np.array([0]), 4)))
     aux = np.concatenate(aux)
     assert len(aux) == SURF_AUX_FLOATS
-    plan = PackPlanBF16(PROG_SURFACE_BF16, flat, chunks, aux)
+    plan = PackPlanBF16(PROG_SURFACE_BF16, flat, chunks, aux, chunk_mul=mul, chunk_scale=scl, nc_main=nc_fwd)
     # cat[h, enc] / sqrt(2) (base.py:250) is applied to the skip layer's weights instead of its inputs
     plan.scale = {f"w{l}": 1.0 / float(np.sqrt(2.0)) for l in skips}
     return plan

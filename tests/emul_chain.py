@@ -397,3 +397,102 @@ def emul_radiance_bf16(blob_np, view_tiles, pts16, view16, nabla16, h7_16):
         z = _group_sum(dots[c]) + blob.aux[2048 + c]
         rgb[:, c] = (1.0 / (1.0 + np.exp(-z)))[:16]
     return rgb
+
+
+# ======================================================================================================
+# Software model of k_sdf_grad_bf16 (reverse-mode d sdf / d x): forward sweep keeping softplus'(z_l) as
+# unorm16, backward sweep through the transposed-weight chunks that follow the forward program in the blob.
+# ======================================================================================================
+D_UNORM = np.float32(65535.0)
+
+
+def _acc_layer(units, blob, init, ntiles=16, tiles_per_kstep=16):
+    """units: list of (hi, lo) [64, 8] in k-step order; init: list of [64, 4].  Chunks of 2 k-steps."""
+    acc = [a.copy() for a in init]
+    ks = 0
+    while ks < len(units):
+        w = blob.acquire()
+        for kk in range(min(2, len(units) - ks)):
+            for T in range(ntiles):
+                o = (kk * tiles_per_kstep + T) * TS_FLOATS
+                raw = np.ascontiguousarray(w[o:o + TS_FLOATS]).view(np.uint16).reshape(2, 64, 8)
+                f = (raw.astype(np.uint32) << 16).view(np.float32)
+                acc[T] = mfma_16x16x32(f[0], units[ks + kk][0], acc[T])
+                acc[T] = mfma_16x16x32(f[0], units[ks + kk][1], acc[T])
+                acc[T] = mfma_16x16x32(f[1], units[ks + kk][0], acc[T])
+        ks += 2
+    return acc
+
+
+def _units_of(Y):
+    return [split2(np.concatenate([Y[2 * U], Y[2 * U + 1]], axis=1)) for U in range(8)]
+
+
+def emul_sdf_grad_bf16(blob_np, pts16, R_bg):
+    """pts16 [16,3] -> sdf[16], nabla[16,3], h7[16,256] with the data flow of k_sdf_grad_bf16."""
+    blob = Blob(blob_np)
+    blob.nc = int(blob.hdr[6])
+    blob.offs = blob.hdr[HDR_OFFS: HDR_OFFS + blob.nc + 1]
+    p = pts16[J].astype(np.float32)
+    enc = encode_units_bf16(p, np.full(64, -1))
+    zero = [np.zeros((64, 4), np.float32) for _ in range(16)]
+    bias = lambda l: [blob.aux[l * 256:(l + 1) * 256][_tile_feat(T)].astype(np.float32) for T in range(16)]
+    z = [None] * 8
+    dq = [None] * 8
+    z[0] = _acc_layer(enc, blob, bias(0))
+    for l in range(1, 8):
+        dq[l - 1] = [np.rint(softplus100_grad(a) * D_UNORM).astype(np.float32) for a in z[l - 1]]
+        units = _units_of([softplus100(a) for a in z[l - 1]])
+        if l == 4:
+            units = units[:7] + enc
+        z[l] = _acc_layer(units, blob, bias(l))
+    a7 = [softplus100(a) for a in z[7]]
+    row = blob.aux[2048:2304]
+    dot = np.zeros(64, np.float32)
+    h7 = np.zeros((16, 256), np.float32)
+    for T in range(16):
+        dot += (a7[T] * row[_tile_feat(T)]).sum(1).astype(np.float32)
+        h7[J[:, None], _tile_feat(T)] = a7[T]
+    sdf = _group_sum(dot) + blob.aux[2304]
+    if R_bg > 0:
+        d_bg = R_bg - np.sqrt((p ** 2).sum(1))
+        sdf = np.where(d_bg < sdf, d_bg, sdf)
+    # backward: layer 7 (inputs softplus'(z7), the sdf row is inside the weights), then 6..1
+    P = _acc_layer(_units_of([softplus100_grad(a) for a in z[7]]), blob, zero)
+    ge4 = None
+    for l in range(6, 0, -1):
+        P = _acc_layer(_units_of([(P[T] * dq[l][T]).astype(np.float32) for T in range(16)]), blob, zero)
+        if l == 4:
+            ge4 = [P[13].copy(), P[14].copy(), P[15].copy()]
+    # layer 0: 3 output tiles (rows 217..255 = encoding features), all 8 k-steps in one chunk
+    units = _units_of([(P[T] * dq[0][T]).astype(np.float32) for T in range(16)])
+    w = blob.acquire()
+    E = [a.copy() for a in ge4]
+    for ks in range(8):
+        for t in range(3):
+            o = (ks * 3 + t) * TS_FLOATS
+            raw = np.ascontiguousarray(w[o:o + TS_FLOATS]).view(np.uint16).reshape(2, 64, 8)
+            f = (raw.astype(np.uint32) << 16).view(np.float32)
+            E[t] = mfma_16x16x32(f[0], units[ks][0], E[t])
+            E[t] = mfma_16x16x32(f[0], units[ks][1], E[t])
+            E[t] = mfma_16x16x32(f[1], units[ks][0], E[t])
+    # contraction with d enc / d x: lane (g, j), tile t, reg r holds d sdf / d enc[f], f = 16 t + 4 g + r - 9
+    part = np.zeros((64, 3), np.float32)
+    for t in range(3):
+        for r in range(4):
+            f = 16 * t + 4 * G + r - 9
+            for lane in range(64):
+                ff = f[lane]
+                if ff < 0 or ff >= 39:
+                    continue
+                if ff < 3:
+                    c, jac = ff, np.float32(1.0)
+                else:
+                    k, rem = divmod(ff - 3, 6)
+                    s_, c = divmod(rem, 3)
+                    fr = np.float32(1 << k)
+                    arg = np.float32(p[lane, c] * fr)
+                    jac = np.float32(np.cos(arg) * fr) if s_ == 0 else np.float32(-np.sin(arg) * fr)
+                part[lane, c] += E[t][lane, r] * jac
+    nabla = np.stack([_group_sum(part[:, c]) for c in range(3)], axis=1)
+    return sdf[:16], nabla[:16], h7

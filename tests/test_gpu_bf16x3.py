@@ -113,3 +113,28 @@ def test_full_frame_bf16x3_vs_fp32():
     print(f"  fp32 vs bf16x3 full frame: identical rounds on {same:.4f} of rays; rgb max {err.max().item():.2e}, "
           f"99.9 pct {err.flatten().kthvalue(int(0.999 * err.numel())).values.item():.2e}, PSNR {psnr:.1f} dB")
     assert same >= 0.99 and psnr >= 60.0
+
+
+@pytest.mark.parametrize("M", [1, 127, 128, 1500])
+def test_reverse_mode_nabla_bf16x3(pts, M):
+    """precision 1 = reverse-mode kernel (k_sdf_grad_bf16); precision 2 = forward-mode tangent quads on the same blob."""
+    from oracle import nets
+    from nerfart_amd import hip
+    model, _, _ = _model()
+    sd, _ = scene_state("VolSDF", 0.01)
+    surf, _ = model.packed()
+    p = pts[0][:M].contiguous()
+    pd = p.to(DEV)
+    s_ref, n_ref, feat_ref = nets.surface_forward_with_nablas(sd, p)
+    d_bg = 3.0 - p.norm(dim=-1)
+    s_ref = torch.where(d_bg < s_ref, d_bg, s_ref)
+    for rep in range(2):                              # second call reuses the library's scratch (and the L1/L2 state)
+        sdf, nab, h7 = hip.sdf_nabla_fwd(surf, pd, 3.0, precision=1)
+        close(f"reverse sdf M={M}", sdf, s_ref, 1e-4)
+        close(f"reverse nabla M={M}", nab, n_ref, 1e-3, 1e-3)
+    sdf2, nab2, h72 = hip.sdf_nabla_fwd(surf, pd, 3.0, precision=2)
+    close("reverse vs forward-mode nabla", nab, nab2.cpu(), 5e-4, 5e-4)
+    close("reverse vs forward-mode h7", h7, h72.cpu(), 1e-4, 1e-4)
+    w8 = nets.folded_weight(sd, "implicit_surface.surface_fc_layers.8")
+    b8 = sd["implicit_surface.surface_fc_layers.8.bias"]
+    close("reverse h7 -> geometry feature", h7.cpu() @ w8[1:].T + b8[1:], feat_ref, 1e-3, 1e-3)

@@ -89,11 +89,13 @@ def _blobs_bf16(fw):
 
 def test_bf16_blob_header():
     _, surf, rad, _ = _blobs_bf16("VolSDF")
-    for blob, nc in ((surf, 30), (rad, 21)):
+    for blob, nc, nc_all in ((surf, 30, 59), (rad, 21, 21)):
         hdr = blob[:512].view(np.int32)
-        assert hdr[0] == packing.MAGIC and hdr[2] == nc and hdr[3] == blob.size
-        offs = hdr[16:16 + nc + 1]
-        assert set(np.diff(offs).tolist()) <= {8192, 16384} and offs[-1] == hdr[4]      # 1 or 2 k-steps of 32 KiB
+        assert hdr[0] == packing.MAGIC and hdr[2] == nc and hdr[6] == nc_all and hdr[3] == blob.size
+        offs = hdr[16:16 + nc_all + 1]
+        # 1 or 2 k-steps of 32 KiB; the reverse-mode program ends with one 48 KiB chunk (8 k-steps x 3 tiles)
+        assert set(np.diff(offs).tolist()) <= {8192, 12288, 16384} and offs[-1] == hdr[4]
+        assert offs[-2] + 16384 <= blob.size          # the stream copies 64 KiB per chunk
 
 
 def test_emulated_bf16_sdf_only_matches_oracle():
@@ -134,3 +136,22 @@ def test_emulated_bf16_radiance_matches_oracle(fw):
                                                 h7[i:i + 16]) for i in (0, 16)])
     ref = nets.radiance_forward(sd, pts, view, nab, feat, -1, -1 if fw == "VolSDF" else 4).numpy()
     np.testing.assert_allclose(out, ref, atol=2e-4, rtol=1e-3)
+
+
+def test_emulated_bf16_reverse_mode_grad_matches_oracle():
+    """Forward program + transposed-weight backward program of the surface blob (k_sdf_grad_bf16's data flow)."""
+    sd, surf, _, _ = _blobs_bf16("VolSDF")
+    hdr = surf[:512].view(np.int32)
+    assert hdr[2] == 30 and hdr[6] == 59
+    g = torch.Generator().manual_seed(23)
+    pts = (torch.rand(16, 3, generator=g) * 4 - 2)
+    pts[:2] *= 2.0                                   # a few outside the bounding sphere (clamped sdf, nabla kept)
+    sdf, nab, h7 = em.emul_sdf_grad_bf16(surf, pts.numpy(), 3.0)
+    s_ref, n_ref, feat_ref = nets.surface_forward_with_nablas(sd, pts)
+    d_bg = 3.0 - pts.norm(dim=-1)
+    s_ref = torch.where(d_bg < s_ref, d_bg, s_ref)
+    np.testing.assert_allclose(sdf, s_ref.numpy(), atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(nab, n_ref.numpy(), atol=2e-4, rtol=5e-4)
+    w8 = nets.folded_weight(sd, "implicit_surface.surface_fc_layers.8").numpy()
+    b8 = sd["implicit_surface.surface_fc_layers.8.bias"].numpy()
+    np.testing.assert_allclose(h7 @ w8[1:].T + b8[1:], feat_ref.numpy(), atol=5e-4, rtol=1e-3)
