@@ -153,10 +153,11 @@ def volsdf_forward_surface(sd: dict, x, R: float = 3.0, multires: int = 6, skips
 
 
 def volsdf_forward(sd: dict, x, view_dirs, R: float = 3.0, multires: int = 6, skips=(4,),
-                   rad_multires: int = -1, rad_multires_view: int = -1):
+                   rad_multires: int = -1, rad_multires_view: int = -1, create_graph: bool = False):
     """(radiance, sdf, nabla) with the sphere clamp applied to sdf only, raw nabla fed to the
-    radiance net (volsdf.py:349-370)."""
-    sdf, nabla, feat = surface_forward_with_nablas(sd, x, multires, skips)
+    radiance net (volsdf.py:349-370).  create_graph=True keeps the autograd graph (through the nabla too:
+    base.py:272-279 uses create_graph=True under grad mode) - the training rows (a19)."""
+    sdf, nabla, feat = surface_forward_with_nablas(sd, x, multires, skips, create_graph=create_graph)
     d_bg = R - x.norm(dim=-1)
     sdf = torch.where(d_bg < sdf, d_bg, sdf)
     rad = radiance_forward(sd, x, view_dirs, nabla, feat, rad_multires, rad_multires_view)

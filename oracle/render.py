@@ -103,7 +103,9 @@ def volsdf_composite(d_all, sigma, radiances, nablas=None, white_bkgd=False):
 def volsdf_render(sd, rays_o, rays_d, near=0.0, far=6.0, obj_bounding_radius=3.0,
                   N_samples=128, N_importance=64, max_upsample_steps=5, max_bisection_steps=10,
                   epsilon=0.1, white_bkgd=False, speed_factor=10.0, multires=6, skips=(4,),
-                  rad_multires=-1, rad_multires_view=-1, calc_normal=True, chunk=1024):
+                  rad_multires=-1, rad_multires_view=-1, calc_normal=True, chunk=1024, differentiable=False):
+    """differentiable=True: the per-sample network queries and the compositing keep their autograd graph w.r.t.
+    the tensors of `sd` (sampling stays under no_grad, volsdf.py:479) - Trainer.forward's pass 2."""
     rays_o = rays_o.reshape(-1, 3).float()
     rays_d = F.normalize(rays_d.reshape(-1, 3).float(), dim=-1)               # volsdf.py:442
     alpha, beta = nets.volsdf_ab(sd, speed_factor)
@@ -128,7 +130,7 @@ def volsdf_render(sd, rays_o, rays_d, near=0.0, far=6.0, obj_bounding_radius=3.0
         pts = o[:, None, :] + d[:, None, :] * d_all[:, :, None]
         v = d[:, None, :].expand_as(pts)
         rad, sdf, nab = nets.volsdf_forward(sd, pts.reshape(-1, 3), v.reshape(-1, 3), R_bg, multires, skips,
-                                            rad_multires, rad_multires_view)
+                                            rad_multires, rad_multires_view, create_graph=differentiable)
         P = d_all.shape[-1]
         rad, sdf, nab = rad.reshape(n, P, 3), sdf.reshape(n, P), nab.reshape(n, P, 3)
         sigma = sdf_to_sigma(sdf, alpha, beta)

@@ -140,3 +140,27 @@ def test_G10_neus(golden, neus_state):
         close(out[k], golden[tag + k], 3e-5, 2e-4)
     rad, sdf, nab = nets.neus_forward_radiance(sd, tt(golden["G10_pts"]), tt(golden["G10_view"])), None, None
     close(rad, golden["G10_radiance"], 1e-6, 1e-5)
+
+
+def test_G11_backward_matches_reference(golden):
+    """Trainer.forward pass 2 on 4 rays: rgb.backward(gvec) + 0.1 * eikonal MSE -> gradients of all 43 parameter
+    tensors (reference autograd, double backward through the SDF net) vs the oracle's differentiable render."""
+    from oracle import render as orender
+    sd, rk = scene_state("VolSDF", 0.01)
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    o, d = orender.get_rays(tt(golden["G9_c2w"]), tt(golden["G9_K"]), int(golden["G9_H"]), int(golden["G9_W"]))
+    o, d = o.reshape(-1, 3), d.reshape(-1, 3)
+    ex = orender.volsdf_render(sd, o[:4], d[:4], near=rk["near"], far=rk["far"], obj_bounding_radius=rk["obj_bounding_radius"],
+                               N_samples=128, max_upsample_steps=rk["max_upsample_steps"], differentiable=True)
+    ex["rgb"].backward(tt(golden["G11_gvec"]), retain_graph=True)
+    nn_ = ex["implicit_nablas"].reshape(-1, 3).norm(dim=-1)
+    (0.1 * torch.nn.functional.mse_loss(nn_, torch.ones_like(nn_))).backward()
+    names = [k[len("G11_gradnorm_"):] for k in golden if k.startswith("G11_gradnorm_")]
+    assert len(names) == 43
+    for n in names:
+        g = sd[n].grad
+        assert g is not None, n
+        ref_norm = float(golden["G11_gradnorm_" + n])
+        np.testing.assert_allclose(float(g.norm()), ref_norm, rtol=2e-3, atol=1e-7, err_msg=n)
+        head = golden["G11_gradhead_" + n]
+        np.testing.assert_allclose(g.reshape(-1)[:head.size].numpy(), head, rtol=2e-2, atol=2e-3 * ref_norm / max(1.0, np.sqrt(g.numel())) + 1e-8, err_msg=n)
