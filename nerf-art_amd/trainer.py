@@ -1,0 +1,102 @@
+"""Fine-tune step (row a19): the two-pass render / back-propagation of the reference Trainer
+(models/frameworks/volsdf.py:689-783, :878-939; neus.py:455-576, :629-690).
+
+    pass 1  (no grad)  whole image through the HIP renderer                       -> rgb [1, H*W, 3]
+            style loss on the image (CLIP heads, criteria.py)                      -> d loss / d rgb
+    pass 2  patches of `pass2_rays` rays (reference: 1200): HIP sampler (no grad, as volsdf.py:479), then the
+            differentiable per-sample evaluation + compositing (autodiff.py),
+            rgb_patch.backward(d loss / d rgb[patch]); eikonal = w * MSE(|nabla|, 1) over the patch's nablas, backward.
+    caller  optimizer.step()  (train.py:247); with N ranks: dist.allreduce_gradients first.
+
+Differences from the reference, all deliberate: perturb=False in both passes (the
+reference draws different random samples in pass 1 and pass 2); NeuS keeps `radiance_net` frozen exactly like
+neus.py:455-456.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import autodiff, hip
+from .nets import NeuS, VolSDF
+
+
+class Trainer(nn.Module):
+    def __init__(self, model, w_eikonal: float = 0.1, use_eikonal: bool = True, pass2_rays: int = 1200):
+        super().__init__()
+        if not isinstance(model, (VolSDF, NeuS)):
+            raise TypeError("Trainer expects a nerfart_amd VolSDF or NeuS model")
+        self.model = model
+        self.is_neus = isinstance(model, NeuS)
+        self.w_eikonal, self.use_eikonal, self.pass2_rays = w_eikonal, use_eikonal, pass2_rays
+        if self.is_neus:                       # neus.py:455-456: only the SDF net (and ln_s) is fine-tuned
+            for p in model.radiance_net.parameters():
+                p.requires_grad_(False)
+
+    # ---- pass 1 ---------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def render_image(self, render_fn, rays_o, rays_d, **render_kwargs):
+        kw = dict(render_kwargs)
+        kw.pop("rayschunk", None)
+        rgb, depth, extras = render_fn(rays_o, rays_d, detailed_output=False, require_nablas=True, calc_normal=True, **kw)
+        return rgb
+
+    # ---- pass 2 ---------------------------------------------------------------------------------------
+    def _samples(self, o, dn, d_raw, rk):
+        """Sample depths of a patch (no grad): the HIP sampler."""
+        m = self.model
+        surf_blob, rad_blob = m.packed()
+        if self.is_neus:
+            out = hip.neus_render(surf_blob, rad_blob, m.view_tiles, o, d_raw, obj_bounding_radius=rk.get("obj_bounding_radius", 1.0),
+                                  s=float(m.forward_s().detach()), n_samples=rk.get("N_samples", 64),
+                                  n_importance=rk.get("N_importance", 64), n_upsample_iters=rk.get("N_upsample_iters", 4),
+                                  calc_normal=False, detailed=True, precision=m.precision_id)
+            return out["d_all"]
+        alpha, beta = m.forward_ab()
+        ns, ni = rk.get("N_samples", 128), rk.get("N_importance", 64)
+        near, far = rk.get("near", 0.0), rk.get("far", 6.0)
+        d_fine, _, _ = hip.volsdf_fine_sample(surf_blob, o, dn, near, far, rk.get("obj_bounding_radius", 3.0), float(alpha.detach()),
+                                              float(beta.detach()), rk.get("epsilon", 0.1), 4 * ns, 4 * ns, ni,
+                                              rk.get("max_upsample_steps", 5), rk.get("max_bisection_steps", 10),
+                                              precision=m.precision_id)
+        t = hip.lin_table(ns, o.device)
+        d_coarse = (near * (1.0 - t) + far * t)[None, :].expand(o.shape[0], ns)
+        return torch.sort(torch.cat([d_coarse, d_fine], dim=-1), dim=-1)[0]
+
+    def backward_patches(self, rays_o, rays_d, gradient, **render_kwargs):
+        """Pass 2: accumulates parameter gradients for d loss / d rgb = `gradient` [N, 3] (+ the eikonal term).
+        Returns the mean eikonal loss over the patches (what the reference prints)."""
+        o_all = rays_o.reshape(-1, 3).float().contiguous()
+        d_all_ = rays_d.reshape(-1, 3).float().contiguous()
+        g_all = gradient.reshape(-1, 3)
+        eik_sum, n = 0.0, 0
+        for i in range(0, o_all.shape[0], self.pass2_rays):
+            o, d_raw = o_all[i:i + self.pass2_rays], d_all_[i:i + self.pass2_rays]
+            dn = F.normalize(d_raw, dim=-1)
+            with torch.no_grad():
+                depths = self._samples(o, dn, d_raw, render_kwargs)
+            fn = autodiff.neus_render_samples if self.is_neus else autodiff.volsdf_render_samples
+            out = fn(self.model, o, dn, depths, white_bkgd=render_kwargs.get("white_bkgd", False))
+            out["rgb"].backward(g_all[i:i + self.pass2_rays], retain_graph=self.use_eikonal)
+            if self.use_eikonal:
+                nn_ = out["implicit_nablas"].reshape(-1, 3).norm(dim=-1)
+                eik = self.w_eikonal * F.mse_loss(nn_, torch.ones_like(nn_), reduction="mean")
+                eik.backward()
+                eik_sum += float(eik.detach())
+            n += 1
+            del out
+        return eik_sum / max(n, 1)
+
+    # ---- one fine-tune step ---------------------------------------------------------------------------
+    def finetune_step(self, render_fn, rays_o, rays_d, target_rgb, H: int, style_loss, optimizer=None, **render_kwargs):
+        """style_loss(rgb_pred [B,3,H,W], rgb_gt [B,3,H,W]) -> scalar.  Returns dict(loss, eikonal, rgb)."""
+        rgb = self.render_image(render_fn, rays_o, rays_d, **render_kwargs)
+        rgb = rgb.detach().reshape(1, -1, 3).requires_grad_(True)
+        W = rgb.shape[1] // H
+        to_img = lambda t: t.reshape(t.shape[0], H, W, 3).permute(0, 3, 1, 2)          # "B (H W) C -> B C H W"
+        loss = style_loss(to_img(rgb), to_img(target_rgb.reshape(1, -1, 3)))
+        loss.backward()
+        gradient = rgb.grad.detach()
+        if optimizer is not None:
+            optimizer.zero_grad()
+        eik = self.backward_patches(rays_o, rays_d, gradient[0], **render_kwargs)
+        return {"loss": float(loss.detach()), "eikonal": eik, "rgb": rgb.detach()}

@@ -224,6 +224,6 @@ def neus_render(sd, rays_o, rays_d, obj_bounding_radius=1.0, N_samples=64, N_imp
             nn_ = F.normalize(nab, dim=-1)
             ret["normals_volume"] = (nn_[..., :P - 1, :] * w[..., None]).sum(dim=-2)
         ret.update(implicit_nablas=nab, implicit_surface=sdf, radiance=rad, alpha=alpha, cdf=cdf,
-                   visibility_weights=w, d_final=d_mid)
+                   visibility_weights=w, d_final=d_mid, d_all=d_all)
         outs.append(ret)
     return OrderedDict((k, torch.cat([o_[k] for o_ in outs], 0)) for k in outs[0])
