@@ -27,6 +27,11 @@ def main():
     style = criteria.StyleLoss(feats, (H, W), neg_texts=[f"negative prompt {i}" for i in range(16)])
     with torch.no_grad():
         target, _, _ = render_fn(o, d, detailed_output=False, require_nablas=True, calc_normal=True, **{k: v for k, v in rk.items() if k != "rayschunk"})
+    # the "photo" the render is compared with: the render itself, low-pass perturbed (pred == gt would make the
+    # directional loss 0/0, as in the reference)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    noise = torch.nn.functional.interpolate(torch.randn(1, 3, H // 8, W // 8, generator=g), size=(H, W), mode="bicubic", align_corners=False)
+    target = (target.reshape(1, H, W, 3) + 0.1 * noise.permute(0, 2, 3, 1).to(dev)).clamp(0, 1).reshape(1, -1, 3)
     tr = Trainer(model, pass2_rays=args.pass2_rays)
     opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-5)
     times = []
