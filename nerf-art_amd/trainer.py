@@ -76,12 +76,15 @@ class Trainer(nn.Module):
                 depths = self._samples(o, dn, d_raw, render_kwargs)
             fn = autodiff.neus_render_samples if self.is_neus else autodiff.volsdf_render_samples
             out = fn(self.model, o, dn, depths, white_bkgd=render_kwargs.get("white_bkgd", False))
-            out["rgb"].backward(g_all[i:i + self.pass2_rays], retain_graph=self.use_eikonal)
             if self.use_eikonal:
+                # the reference calls rgb.backward(g, retain_graph=True) and then eikonal.backward(): the same sum of
+                # gradients from ONE traversal of the (double-backward) graph of the SDF net
                 nn_ = out["implicit_nablas"].reshape(-1, 3).norm(dim=-1)
                 eik = self.w_eikonal * F.mse_loss(nn_, torch.ones_like(nn_), reduction="mean")
-                eik.backward()
+                torch.autograd.backward([out["rgb"], eik], [g_all[i:i + self.pass2_rays], torch.ones_like(eik)])
                 eik_sum += float(eik.detach())
+            else:
+                out["rgb"].backward(g_all[i:i + self.pass2_rays])
             n += 1
             del out
         return eik_sum / max(n, 1)
