@@ -95,7 +95,28 @@ def volsdf_composite(d_all, sigma, radiances, nablas=None, white_bkgd=False):
     return out
 
 
-def volsdf_render_samples(model, rays_o, rays_dn, d_all, white_bkgd=False, calc_normal=True):
+class CompositeRGB(torch.autograd.Function):
+    """rgb = composite(d_all, sigma(sdf; alpha, beta), radiance) with the hand-written HIP forward and backward
+    kernels (nerfart_volsdf_composite / _composite_bwd): the per-ray stage of pass 2 without an autograd graph."""
+
+    @staticmethod
+    def forward(ctx, d_all, sdf, radiance, alpha, beta, white_bkgd):
+        from . import hip
+        d_all, sdf, radiance = d_all.contiguous(), sdf.contiguous(), radiance.contiguous()
+        rgb, _, _ = hip.volsdf_composite(d_all, sdf, radiance, float(alpha), float(beta), white_bkgd)
+        ctx.save_for_backward(d_all, sdf, radiance, alpha, beta)
+        ctx.white_bkgd = white_bkgd
+        return rgb
+
+    @staticmethod
+    def backward(ctx, g_rgb):
+        from . import hip
+        d_all, sdf, radiance, alpha, beta = ctx.saved_tensors
+        g_sdf, g_rad, g_ab = hip.volsdf_composite_bwd(d_all, sdf, radiance, float(alpha), float(beta), g_rgb.contiguous(), ctx.white_bkgd)
+        return None, g_sdf, g_rad, g_ab[0].reshape(alpha.shape), g_ab[1].reshape(beta.shape), None
+
+
+def volsdf_render_samples(model, rays_o, rays_dn, d_all, white_bkgd=False, calc_normal=True, native_composite=None):
     """Differentiable part of volume_render for given (non-differentiable) sample depths d_all [R, P]:
     rays_o / rays_dn [R, 3] (directions normalised).  Returns the reference's extras incl. implicit_nablas."""
     R, P = d_all.shape
@@ -104,6 +125,13 @@ def volsdf_render_samples(model, rays_o, rays_dn, d_all, white_bkgd=False, calc_
     rad, sdf, nab = volsdf_point_forward(model, pts.reshape(-1, 3), v.reshape(-1, 3))
     rad, sdf, nab = rad.reshape(R, P, 3), sdf.reshape(R, P), nab.reshape(R, P, 3)
     alpha, beta = model.forward_ab()
+    if native_composite is None:
+        native_composite = d_all.is_cuda
+    if native_composite:
+        # only rgb is produced (all the fine-tune losses need); depth / mask / normals maps come from pass 1
+        out = {"rgb": CompositeRGB.apply(d_all, sdf, rad, alpha, beta, white_bkgd)}
+        out.update(implicit_surface=sdf, implicit_nablas=nab, radiance=rad, d_vals=d_all)
+        return out
     sigma = sdf_to_sigma(sdf, alpha, beta)
     out = volsdf_composite(d_all, sigma, rad, nab if calc_normal else None, white_bkgd)
     out.update(implicit_surface=sdf, implicit_nablas=nab, radiance=rad, sigma=sigma, d_vals=d_all)

@@ -46,6 +46,7 @@ _SIGS = {
     "nerfart_volsdf_fine_sample": (_i, [_p, _i, _p, _p, _i, _p, _p, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _ll, _p]),
     "nerfart_sort_concat": (_i, [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p]),
     "nerfart_volsdf_composite": (_i, [_i, _i, _p, _p, _p, _p, _f, _f, _i] + [_p] * 8),
+    "nerfart_volsdf_composite_bwd": (_i, [_i, _i, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p]),
     "nerfart_volsdf_render_workspace_bytes": (_ll, [_i, _i, _i, _i, _i]),
     "nerfart_volsdf_render_fwd": (_i, [_p, _p, _i, _i, _p, _p, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i] + [_p] * 4 + [_p] * 13 + [_p, _ll, _p]),
     "nerfart_near_far_from_sphere": (_i, [_p, _p, _i, _f, _p, _p, _p]),
@@ -203,6 +204,32 @@ def volsdf_fine_sample(surf_blob, rays_o, rays_dn, near: float, far: float, R_bg
                                           _dev(lin_table(n_final, dev)), _dev(d_fine), _dev(beta_map), _dev(usage), ws.data_ptr(), ws.numel(),
                                           _stream()), "nerfart_volsdf_fine_sample")
     return d_fine, beta_map, usage
+
+
+def volsdf_composite(d_all, sdf, radiance, alpha: float, beta: float, white_bkgd: bool = False):
+    """rgb [R,3], depth [R], acc [R] of nerfart_volsdf_composite for d_all / sdf [R,P], radiance [R,P,3]."""
+    R, P = d_all.shape
+    dev = d_all.device
+    rgb = torch.empty(R, 3, dtype=torch.float32, device=dev)
+    depth = torch.empty(R, dtype=torch.float32, device=dev)
+    acc = torch.empty(R, dtype=torch.float32, device=dev)
+    _check(lib.nerfart_volsdf_composite(R, P, _dev(d_all), _dev(sdf), _dev(radiance), None, float(alpha), float(beta),
+                                        int(bool(white_bkgd)), _dev(rgb), _dev(depth), _dev(acc), None, None, None, None, _stream()),
+           "nerfart_volsdf_composite")
+    return rgb, depth, acc
+
+
+def volsdf_composite_bwd(d_all, sdf, radiance, alpha: float, beta: float, g_rgb, white_bkgd: bool = False):
+    """Cotangents (g_sdf [R,P], g_radiance [R,P,3], g_alpha_beta [2]) for d loss / d rgb = g_rgb [R,3]."""
+    R, P = d_all.shape
+    dev = d_all.device
+    g_sdf = torch.empty(R, P, dtype=torch.float32, device=dev)
+    g_rad = torch.empty(R, P, 3, dtype=torch.float32, device=dev)
+    g_ab = torch.zeros(2, dtype=torch.float32, device=dev)
+    _check(lib.nerfart_volsdf_composite_bwd(R, P, _dev(d_all), _dev(sdf), _dev(radiance), float(alpha), float(beta),
+                                            int(bool(white_bkgd)), _dev(g_rgb), _dev(g_sdf), _dev(g_rad), _dev(g_ab), _stream()),
+           "nerfart_volsdf_composite_bwd")
+    return g_sdf, g_rad, g_ab
 
 
 def volsdf_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, near, far, R_bg, alpha, beta, eps=0.1,

@@ -70,3 +70,29 @@ def test_neus_pass2_radiance_frozen():
             assert p.grad is None, n
         else:
             assert p.grad is not None and torch.isfinite(p.grad).all(), n
+
+
+@pytest.mark.parametrize("white", [False, True])
+def test_composite_bwd_kernel_matches_autograd(white):
+    """nerfart_volsdf_composite_bwd against autograd through the reference formulas (autodiff.volsdf_composite)."""
+    from nerfart_amd import autodiff, hip
+    g = torch.Generator().manual_seed(5)
+    R, P = 257, 192
+    d_all = torch.sort(torch.rand(R, P, generator=g) * 6, dim=-1)[0]
+    sdf = (torch.rand(R, P, generator=g) - 0.4) * 0.3
+    sdf[:, 150:] = -0.2                                            # opaque tail: p underflows, T -> 0
+    rad = torch.rand(R, P, 3, generator=g)
+    g_rgb = torch.randn(R, 3, generator=g)
+    beta = torch.tensor([0.013], dtype=torch.float32, requires_grad=True)
+    alpha = (1.0 / beta).detach().requires_grad_(True)
+    sdf_r, rad_r = sdf.clone().requires_grad_(True), rad.clone().requires_grad_(True)
+    ref = autodiff.volsdf_composite(d_all, autodiff.sdf_to_sigma(sdf_r, alpha, beta), rad_r, None, white)
+    ref["rgb"].backward(g_rgb)
+    rgb, _, _ = hip.volsdf_composite(d_all.to(DEV), sdf.to(DEV), rad.to(DEV), float(alpha), float(beta), white)
+    np.testing.assert_allclose(rgb.cpu().numpy(), ref["rgb"].detach().numpy(), atol=2e-6, rtol=1e-5)
+    g_sdf, g_rad, g_ab = hip.volsdf_composite_bwd(d_all.to(DEV), sdf.to(DEV), rad.to(DEV), float(alpha), float(beta), g_rgb.to(DEV), white)
+    np.testing.assert_allclose(g_rad.cpu().numpy(), rad_r.grad.numpy(), atol=1e-6, rtol=1e-4)
+    scale = float(sdf_r.grad.abs().max())
+    np.testing.assert_allclose(g_sdf.cpu().numpy(), sdf_r.grad.numpy(), atol=2e-5 * scale, rtol=2e-3)
+    np.testing.assert_allclose(float(g_ab[0]), float(alpha.grad), rtol=2e-3, atol=1e-6)
+    np.testing.assert_allclose(float(g_ab[1]), float(beta.grad), rtol=2e-3, atol=1e-3 * abs(float(beta.grad)) + 1e-6)
