@@ -144,8 +144,12 @@ __device__ __forceinline__ void stream_start(Stream& s) {
     stream_lookup(s, stream_next_of(s, 0));
 }
 __device__ __forceinline__ const float* stream_acquire(Stream& s) {
+#ifndef NERFART_ABLATE_VMWAIT   // timing experiments only (tools/ablate_bf16.py): results are wrong without these
     wait_glds();          // my pieces of the current chunk have landed
+#endif
+#ifndef NERFART_ABLATE_BARRIER
     __syncthreads();      // everyone's pieces landed; everyone is done reading buffer pb^1
+#endif
     const float* w = s.lds + s.pb * CHUNK_FLOATS;
     stream_target(s, s.nxt_o0, s.pb ^ 1);
     stream_lookup(s, stream_next_of(s, s.nxt));
@@ -250,7 +254,8 @@ __device__ __forceinline__ void d_load(GradCtx& gc, int idx, int buf) {
 // one epilogue slice (last 12 items of a hosting k-step).  LDS returns in order: with items it, it+1, it+2
 // outstanding (2 reads each) item it has landed at lgkmcnt(4) (cdna_hip_programming.md 5.7, form ii).
 // ---------------------------------------------------------------------------------------
-struct Ring { u32x4 h0, l0, h1, l1, h2, l2; };
+struct Ring { u32x4 h[4], l[4]; };                   // AHEAD + 1 slots in use
+struct Ring3 { u32x4 h0, l0, h1, l1, h2, l2; };     // fixed 3-slot ring of the reverse-mode tail
 
 template <int OFF>
 __device__ __forceinline__ void lds_read_pair(u32x4& fh, u32x4& fl, unsigned addr) {
@@ -271,9 +276,11 @@ __device__ __forceinline__ void lds_wait_pair(u32x4& fh, u32x4& fl) {
 // from memory).  NEXT0: the last k-step also builds unit 0 of the NEXT layer from this layer's tiles 0 and 1, with
 // epilogue MQ.  ZINIT: accumulators start at 0 instead of the bias.  PEND_IN / LOADNEXT (reverse-mode kernel): a
 // softplus' unit of the previous layer is waiting to be stored / the following layer's first unit needs its load.
-template <int MODE_, int MQ_, int NH_, int NX_, bool NEXT0_, bool ZINIT_ = false, bool PEND_IN_ = false, bool LOADNEXT_ = false>
+template <int MODE_, int MQ_, int NH_, int NX_, bool NEXT0_, bool ZINIT_ = false, bool PEND_IN_ = false, bool LOADNEXT_ = false,
+          int AHEAD_ = 2>
 struct Cfg {
     static constexpr int MODE = MODE_, MQ = MQ_, NH = NH_, NX = NX_, NXA = NX_ > 0 ? NX_ : 1, NKS = NH_ + NX_;
+    static constexpr int AHEAD = AHEAD_;      // A fragments are read this many items ahead of their MFMAs (2 or 3)
     static constexpr bool NEXT0 = NEXT0_, ZINIT = ZINIT_, PEND_IN = PEND_IN_, LOADNEXT = LOADNEXT_;
     // unit whose epilogue is hosted by k-step ks: a unit of act(P) (0..7), 100 = unit 0 of act(Q), -1 = none
     static constexpr int hosted(int ks) { return (ks + 1 < NH_) ? ks + 1 : ((NEXT0_ && ks == NH_ + NX_ - 1) ? 100 : -1); }
@@ -287,19 +294,16 @@ struct Items {
         constexpr int N = NKC * 16;
         if constexpr (IT < N) {
             constexpr int kk = IT >> 4, T = IT & 15, ks = CHUNK_KS * C + kk;
-            constexpr int S = IT % 3, S2 = (IT + 2) % 3;
-            constexpr int PENDING = (IT + 2 < N) ? 4 : ((IT + 1 < N) ? 2 : 0);
-            if constexpr (IT + 2 < N) {
-                if constexpr (S2 == 0) lds_read_pair<(IT + 2) * 2048>(r.h0, r.l0, addr);
-                else if constexpr (S2 == 1) lds_read_pair<(IT + 2) * 2048>(r.h1, r.l1, addr);
-                else lds_read_pair<(IT + 2) * 2048>(r.h2, r.l2, addr);
-            }
+            constexpr int AH = L::AHEAD, NS = AH + 1;
+            constexpr int S = IT % NS, S2 = (IT + AH) % NS;
+            constexpr int LEFT = N - 1 - IT;
+            constexpr int PENDING = 2 * (LEFT < AH ? LEFT : AH);
+            if constexpr (IT + AH < N) lds_read_pair<(IT + AH) * 2048>(r.h[S2], r.l[S2], addr);
             u32x4 bh, bl;
             if constexpr (ks < L::NH) { bh = xb[ks & 1].h; bl = xb[ks & 1].l; }
             else { bh = xs[ks - L::NH].h; bl = xs[ks - L::NH].l; }
-            if constexpr (S == 0) { lds_wait_pair<PENDING>(r.h0, r.l0); Q.t[T] = mfma3(r.h0, r.l0, bh, bl, Q.t[T]); }
-            else if constexpr (S == 1) { lds_wait_pair<PENDING>(r.h1, r.l1); Q.t[T] = mfma3(r.h1, r.l1, bh, bl, Q.t[T]); }
-            else { lds_wait_pair<PENDING>(r.h2, r.l2); Q.t[T] = mfma3(r.h2, r.l2, bh, bl, Q.t[T]); }
+            lds_wait_pair<PENDING>(r.h[S], r.l[S]);
+            Q.t[T] = mfma3(r.h[S], r.l[S], bh, bl, Q.t[T]);
             constexpr int HU = L::hosted(ks);
             constexpr int HM = L::mode_of(HU);
             if constexpr (T == 0) {
@@ -362,8 +366,9 @@ __device__ __forceinline__ void run_chunk(const Acc& P, Acc& Q, Unit (&xb)[2], c
         // waits below assume only the ring's reads are outstanding
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         Ring r;
-        lds_read_pair<0>(r.h0, r.l0, addr);
-        lds_read_pair<2048>(r.h1, r.l1, addr);
+        lds_read_pair<0>(r.h[0], r.l[0], addr);
+        lds_read_pair<2048>(r.h[1], r.l[1], addr);
+        if constexpr (L::AHEAD >= 3) lds_read_pair<4096>(r.h[2], r.l[2], addr);
         Items<L, C, NKC, 0>::run(P, Q, xb, xs, x0n, w, r, addr, s, ec, gc);
         run_chunk<L, C + 1>(P, Q, xb, xs, x0n, w, s, ec, gc);
     }
@@ -491,20 +496,22 @@ __device__ __forceinline__ float surface_chain(float px, float py, float pz, int
     none[0] = enc[0];
     x0 = enc[0];
     GradCtx gc;
-    layer<Cfg<MODE, MODE, 0, 2, true>>(B, A, x0, enc, x0n, s, aux, ec, gc);
+    // AHEAD = 3 (a deeper fragment ring) was measured 3 % SLOWER on K2: the LDS is throughput-, not latency-limited
+    constexpr int AH = 2;
+    layer<Cfg<MODE, MODE, 0, 2, true, false, false, false, AH>>(B, A, x0, enc, x0n, s, aux, ec, gc);
     x0 = x0n;
 #pragma nounroll
     for (int L = 1; L < 7; ++L) {
         if (L == 4) {
             encode_units(px, py, pz, g, dq, enc);
-            layer<Cfg<MODE, MODE, 7, 2, true>>(A, B, x0, enc, x0n, s, aux + L * 256, ec, gc);
+            layer<Cfg<MODE, MODE, 7, 2, true, false, false, false, AH>>(A, B, x0, enc, x0n, s, aux + L * 256, ec, gc);
         } else {
-            layer<Cfg<MODE, MODE, 8, 0, true>>(A, B, x0, none, x0n, s, aux + L * 256, ec, gc);
+            layer<Cfg<MODE, MODE, 8, 0, true, false, false, false, AH>>(A, B, x0, none, x0n, s, aux + L * 256, ec, gc);
         }
         A = B;
         x0 = x0n;
     }
-    layer<Cfg<MODE, MODE, 8, 0, false>>(A, B, x0, none, x0n, s, aux + 7 * 256, ec, gc);
+    layer<Cfg<MODE, MODE, 8, 0, false, false, false, false, AH>>(A, B, x0, none, x0n, s, aux + 7 * 256, ec, gc);
     float dot[1] = {0.f};
     last_epilogue<MODE, 1>(B, aux + SURF_AUX_ROW, dot, h7_lane, ec);
     return sum_over_groups(dot[0]);        // the 4 lane groups of a column hold complementary feature sets
@@ -599,7 +606,7 @@ constexpr int GRAD_WS_PER_WG = 7 * 8 * 8 * 1024;           // 7 layers x 8 units
 
 template <int IT>
 struct TailItems {     // layer-0 step: 8 k-steps x 3 output tiles from one 48 KiB chunk
-    static __device__ __forceinline__ void run(f32x4 (&E)[3], const Unit (&X)[8], Ring& r, unsigned addr, const Stream& s) {
+    static __device__ __forceinline__ void run(f32x4 (&E)[3], const Unit (&X)[8], Ring3& r, unsigned addr, const Stream& s) {
         constexpr int N = 24;
         if constexpr (IT < N) {
             constexpr int ks = IT / 3, t = IT % 3;
@@ -716,7 +723,7 @@ k_sdf_grad_bf16(const float* __restrict__ blob, PointSrc src, float R_bg, float*
             const float* wp = stream_acquire(s) + lane * 4;
             const unsigned addr = (unsigned)(size_t)wp;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            Ring r;
+            Ring3 r;
             lds_read_pair<0>(r.h0, r.l0, addr);
             lds_read_pair<2048>(r.h1, r.l1, addr);
             TailItems<0>::run(E, X, r, addr, s);
@@ -842,7 +849,7 @@ k_radiance_bf16(const float* __restrict__ blob, PointSrc src, const float* __res
             x0 = hu[0];
             // geometry feature = W8[1:] h7 + b8[1:] (no activation)
             const EpiCtx ec{-INFINITY, -INFINITY, true};
-            layer<Cfg<2, 2, 0, 8, true>>(B, A, x0, hu, x0n, s, aux, ec, gc);
+            layer<Cfg<2, 2, 0, 8, true, false, false, false, 2>>(B, A, x0, hu, x0n, s, aux, ec, gc);
         }
         x0 = x0n;
         {
@@ -850,18 +857,18 @@ k_radiance_bf16(const float* __restrict__ blob, PointSrc src, const float* __res
             Unit ex[VE];
             radiance_extras<VE>(pt, nx, ny, nz, g, ex);
             const EpiCtx ec{-INFINITY, 0.f, true};
-            layer<Cfg<2, 2, 8, VE, true>>(A, B, x0, ex, x0n, s, aux + 256, ec, gc);
+            layer<Cfg<2, 2, 8, VE, true, false, false, false, 2>>(A, B, x0, ex, x0n, s, aux + 256, ec, gc);
         }
         A = B;
         x0 = x0n;
         const EpiCtx ec{0.f, 0.f, true};
 #pragma nounroll
         for (int L = 2; L < 4; ++L) {
-            layer<Cfg<2, 2, 8, 0, true>>(A, B, x0, none, x0n, s, aux + L * 256, ec, gc);
+            layer<Cfg<2, 2, 8, 0, true, false, false, false, 2>>(A, B, x0, none, x0n, s, aux + L * 256, ec, gc);
             A = B;
             x0 = x0n;
         }
-        layer<Cfg<2, 2, 8, 0, false>>(A, B, x0, none, x0n, s, aux + 4 * 256, ec, gc);
+        layer<Cfg<2, 2, 8, 0, false, false, false, false, 2>>(A, B, x0, none, x0n, s, aux + 4 * 256, ec, gc);
         float dot[3] = {0.f, 0.f, 0.f};
         last_epilogue<2, 3>(B, aux + RAD_AUX_ROWS, dot, nullptr, ec);
         float c[3];

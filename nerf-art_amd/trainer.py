@@ -17,6 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import autodiff, hip
+from . import dist as nd
 from .nets import NeuS, VolSDF
 
 
@@ -90,9 +91,21 @@ class Trainer(nn.Module):
         return eik_sum / max(n, 1)
 
     # ---- one fine-tune step ---------------------------------------------------------------------------
-    def finetune_step(self, render_fn, rays_o, rays_d, target_rgb, H: int, style_loss, optimizer=None, **render_kwargs):
-        """style_loss(rgb_pred [B,3,H,W], rgb_gt [B,3,H,W]) -> scalar.  Returns dict(loss, eikonal, rgb)."""
-        rgb = self.render_image(render_fn, rays_o, rays_d, **render_kwargs)
+    def finetune_step(self, render_fn, rays_o, rays_d, target_rgb, H: int, style_loss, optimizer=None, tile: int = 2048,
+                      **render_kwargs):
+        """style_loss(rgb_pred [B,3,H,W], rgb_gt [B,3,H,W]) -> scalar.  Returns dict(loss, eikonal, rgb).
+
+        With torch.distributed initialised (one process per GPU) the step is ray-parallel: pass 1
+        renders this rank's tiles and all-gathers the image; every rank evaluates the (cheap, deterministic) style
+        loss on the full image and keeps its own rays' d loss / d rgb; pass 2 runs on its own rays; one flat
+        all-reduce(SUM) of the gradients before the caller's optimizer.step()."""
+        sharded = nd.world_size() > 1
+        if sharded:
+            kw = {k: v for k, v in render_kwargs.items() if k != "rayschunk"}
+            rgb = nd.render_sharded(render_fn, rays_o.reshape(1, -1, 3), rays_d.reshape(1, -1, 3), keys=("rgb",), tile=tile,
+                                    detailed_output=False, require_nablas=True, calc_normal=True, **kw)["rgb"]
+        else:
+            rgb = self.render_image(render_fn, rays_o, rays_d, **render_kwargs)
         rgb = rgb.detach().reshape(1, -1, 3).requires_grad_(True)
         W = rgb.shape[1] // H
         to_img = lambda t: t.reshape(t.shape[0], H, W, 3).permute(0, 3, 1, 2)          # "B (H W) C -> B C H W"
@@ -101,5 +114,14 @@ class Trainer(nn.Module):
         gradient = rgb.grad.detach()
         if optimizer is not None:
             optimizer.zero_grad()
-        eik = self.backward_patches(rays_o, rays_d, gradient[0], **render_kwargs)
+        if sharded:
+            idx = nd.my_ray_indices(rgb.shape[1], tile, nd.rank(), nd.world_size(), rgb.device)
+            eik = self.backward_patches(rays_o.reshape(-1, 3)[idx], rays_d.reshape(-1, 3)[idx], gradient[0][idx], **render_kwargs)
+            # ranks that own fewer parameters' gradients than others (none here: every rank touches every tensor)
+            for p in self.model.parameters():
+                if p.requires_grad and p.grad is None:
+                    p.grad = torch.zeros_like(p)
+            nd.allreduce_gradients([p for p in self.model.parameters() if p.requires_grad])
+        else:
+            eik = self.backward_patches(rays_o, rays_d, gradient[0], **render_kwargs)
         return {"loss": float(loss.detach()), "eikonal": eik, "rgb": rgb.detach()}

@@ -7,12 +7,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "nerf-art_amd", "csrc")
 VARIANTS = {"full": [], "nodma": ["-DNERFART_ABLATE_DMA"], "noepi": ["-DNERFART_ABLATE_EPI"], "nomfma": ["-DNERFART_ABLATE_MFMA"],
             "nodma_noepi": ["-DNERFART_ABLATE_DMA", "-DNERFART_ABLATE_EPI"], "noldsread": ["-DNERFART_ABLATE_LDSREAD"],
-            "mfma_only": ["-DNERFART_ABLATE_DMA", "-DNERFART_ABLATE_EPI", "-DNERFART_ABLATE_LDSREAD"]}
+            "mfma_only": ["-DNERFART_ABLATE_DMA", "-DNERFART_ABLATE_EPI", "-DNERFART_ABLATE_LDSREAD"],
+            "nobarrier": ["-DNERFART_ABLATE_BARRIER"], "nobarrier_novmwait": ["-DNERFART_ABLATE_BARRIER", "-DNERFART_ABLATE_VMWAIT"],
+            "mfma_only_nobarrier": ["-DNERFART_ABLATE_DMA", "-DNERFART_ABLATE_EPI", "-DNERFART_ABLATE_LDSREAD", "-DNERFART_ABLATE_BARRIER"]}
 OUT = os.path.join(ROOT, "gpurun_ablate")
 
 def build():
     os.makedirs(OUT, exist_ok=True)
-    srcs = ["capi_common.cpp", "mlp_chain.hip", "mlp_chain_bf16.hip", "volsdf_render.hip", "neus_render.hip", "raygen.hip"]
+    srcs = ["capi_common.cpp", "mlp_chain.hip", "mlp_chain_bf16.hip", "volsdf_render.hip", "volsdf_backward.hip", "neus_render.hip", "raygen.hip"]
     for name, flags in VARIANTS.items():
         lib = os.path.join(OUT, f"lib_{name}.so")
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip"] + flags + \
