@@ -69,6 +69,19 @@ int nerfart_radiance_fwd_rays(const float* rad_blob, int precision, int view_til
                               const int* ray_idx, const float* depth, int n_slots, int n_per_ray, int depth_stride,
                               const float* nabla, const float* h7, float* rgb_out, void* stream);
 
+/* ---- B2 "bwd", radiance half (row a19; split-bf16 blobs only).  nerfart_radiance_fwd_dump = nerfart_radiance_fwd
+ * that also writes the activations of the five layers (geometry feature, four ReLU outputs; bf16, in the kernels'
+ * unit order: [tile of 128 points][5][unit 8][wave 8][lane 64][8]) into `dump` (nerfart_radiance_dump_bytes(M) bytes).
+ * nerfart_radiance_bwd: d loss / d rgb[M,3] -> g_h7[M,256] (cotangent of the SDF net's layer-7 activation through the
+ * geometry-feature rows), g_n[M,3] (cotangent of the normal input), and bwd_dump (same layout: the deltas of
+ * R3, R2, R1, R0 and the geometry-feature cotangent) - the operands of the weight-gradient GEMMs
+ * (dW_l = delta_l^T act_{l-1}, plain library GEMMs; see nerf-art_amd/autodiff.py:RadianceNetFn). */
+long long nerfart_radiance_dump_bytes(long long M);
+int nerfart_radiance_fwd_dump(const float* rad_blob, int view_tiles, const float* pts, const float* view, long long M,
+                              const float* nabla, const float* h7, float* rgb_out, void* dump, void* stream);
+int nerfart_radiance_bwd(const float* rad_blob, long long M, const float* rgb, const float* g_rgb, void* fwd_dump, void* bwd_dump,
+                         float* g_h7_out, float* g_n_out, void* stream);
+
 /* ---- rays.  rend_util.get_rays (utils/rend_util.py:112-165) for one camera: pose/K are row-major 4x4
  * on the device; select (int64, may be NULL = all H*W pixels in row-major order) picks pixel indices. */
 int nerfart_get_rays(const float* pose_dev, const float* K_dev, int H, int W, const long long* select_dev, int n,

@@ -34,23 +34,28 @@ def softplus100(x):
     return F.softplus(x, beta=100.0, threshold=20.0)
 
 
-def surface_forward(surf, x: torch.Tensor):
-    """ImplicitSurface.forward (base.py:243-263) -> (sdf, feat)."""
+def surface_forward(surf, x: torch.Tensor, return_h: bool = False):
+    """ImplicitSurface.forward (base.py:243-263) -> (sdf, feat)  [return_h: (sdf, h7) - the geometry feature is then
+    left to the radiance kernels, which own the rows 1.. of the last linear layer]."""
     e = embed(x, surf.embed_multires)
     h = e
     for i in range(surf.D):
         if i in surf.skips:
             h = torch.cat([h, e], dim=-1) / np.sqrt(2)
         h = softplus100(wn_linear(surf.surface_fc_layers[i], h))
-    out = wn_linear(surf.surface_fc_layers[surf.D], h)
+    last = surf.surface_fc_layers[surf.D]
+    if return_h:
+        w = torch._weight_norm(last.weight_v, last.weight_g, 0)
+        return F.linear(h, w[:1], last.bias[:1])[..., 0], h
+    out = wn_linear(last, h)
     return out[..., 0], out[..., 1:]
 
 
-def surface_forward_with_nablas(surf, x: torch.Tensor):
+def surface_forward_with_nablas(surf, x: torch.Tensor, return_h: bool = False):
     """ImplicitSurface.forward_with_nablas under grad mode (base.py:265-282): nabla keeps its graph."""
     with torch.enable_grad():
         xg = x.detach().requires_grad_(True)
-        sdf, feat = surface_forward(surf, xg)
+        sdf, feat = surface_forward(surf, xg, return_h)
         nabla = torch.autograd.grad(sdf, xg, torch.ones_like(sdf), create_graph=True, retain_graph=True)[0]
     return sdf, nabla, feat
 
@@ -63,11 +68,91 @@ def radiance_forward(rad, x, view_dirs, normals, feat):
     return torch.sigmoid(wn_linear(rad.layers[rad.D], h))
 
 
-def volsdf_point_forward(model, x, view_dirs):
+# ---- radiance net on the hand-written kernels (forward with activation dumps, backward chain, GEMM operands) ----
+_RAD_DUMP_PER_TILE = 5 * 8 * 8 * 1024
+_UNIT_PERM = None
+
+
+def _unit_perm(device):
+    """column c = (unit * 4 + lane group) * 8 + e of a dumped matrix -> natural feature index."""
+    global _UNIT_PERM
+    if _UNIT_PERM is None:
+        from .packing import unit_feature_hidden
+        _UNIT_PERM = torch.tensor([unit_feature_hidden(u, g, e) for u in range(8) for g in range(4) for e in range(8)])
+    return _UNIT_PERM.to(device)
+
+
+def _dump_matrix(dump: torch.Tensor, slot: int, M: int) -> torch.Tensor:
+    """[M, 256] fp32 (columns in unit order) of one dumped activation / delta."""
+    T = dump.numel() // _RAD_DUMP_PER_TILE
+    v = dump.view(torch.bfloat16).view(T, 5, 8, 8, 4, 16, 8)[:, slot]            # tile, unit, wave, g, j, e
+    return v.permute(0, 2, 4, 1, 3, 5).reshape(T * 128, 256)[:M].float()
+
+
+class RadianceNetFn(torch.autograd.Function):
+    """rgb = RadianceNet(x, v, n, W8[1:] h7 + b8[1:]) on k_radiance_bf16 / k_radiance_bwd_bf16.  The weight inputs are the
+    FOLDED matrices (autograd carries their gradients on to weight_g / weight_v); their gradients are plain GEMMs of
+    the dumped deltas and activations."""
+
+    @staticmethod
+    def forward(ctx, model, x, v, n, h7, w8, b8, *rw_rb):
+        from . import hip
+        _, rad_blob = model.packed()
+        x, v, n, h7 = x.contiguous(), v.contiguous(), n.detach().contiguous(), h7.detach().contiguous()
+        rgb, dump = hip.radiance_fwd_dump(rad_blob, model.view_tiles, x, v, n, h7)
+        ctx.model = model
+        ctx.save_for_backward(x, v, n, h7, rgb, dump)
+        return rgb
+
+    @staticmethod
+    def backward(ctx, g_rgb):
+        from . import hip
+        model = ctx.model
+        x, v, n, h7, rgb, dump = ctx.saved_tensors
+        M = x.shape[0]
+        _, rad_blob = model.packed()
+        g_rgb = g_rgb.contiguous()
+        g_h7, g_n, bdump = hip.radiance_bwd(rad_blob, rgb, g_rgb, dump)
+        perm = _unit_perm(x.device)
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(256, device=x.device)
+        nat = lambda m: m[:, inv]                                                   # unit order -> natural feature order
+        acts = [nat(_dump_matrix(dump, s, M)) for s in range(5)]                     # f, r0, r1, r2, r3
+        deltas = [nat(_dump_matrix(bdump, s, M)) for s in range(5)]                  # d3, d2, d1, d0, g_f
+        d4 = g_rgb * rgb * (1.0 - rgb)
+        rad = model.radiance_net
+        ex = torch.cat([embed(x, rad.embed_multires), embed(v, rad.embed_multires_view), n], dim=-1)
+        gw = [None] * 5
+        gb = [None] * 5
+        gw[4], gb[4] = d4.t() @ acts[4], d4.sum(0)
+        gw[3], gb[3] = deltas[0].t() @ acts[3], deltas[0].sum(0)
+        gw[2], gb[2] = deltas[1].t() @ acts[2], deltas[1].sum(0)
+        gw[1], gb[1] = deltas[2].t() @ acts[1], deltas[2].sum(0)
+        gw[0], gb[0] = torch.cat([deltas[3].t() @ ex, deltas[3].t() @ acts[0]], dim=1), deltas[3].sum(0)
+        g_w8 = torch.cat([torch.zeros(1, 256, device=x.device), deltas[4].t() @ h7], dim=0)
+        g_b8 = torch.cat([torch.zeros(1, device=x.device), deltas[4].sum(0)])
+        out = [None, None, None, g_n, g_h7, g_w8, g_b8]
+        for l in range(5):
+            out += [gw[l], gb[l]]
+        return tuple(out)
+
+
+def radiance_forward_native(model, x, view_dirs, nabla, h7):
+    surf_last = model.implicit_surface.surface_fc_layers[model.implicit_surface.D]
+    w8 = torch._weight_norm(surf_last.weight_v, surf_last.weight_g, 0)
+    args = []
+    for lyr in model.radiance_net.layers:
+        args += [torch._weight_norm(lyr.weight_v, lyr.weight_g, 0), lyr.bias]
+    return RadianceNetFn.apply(model, x, view_dirs, nabla, h7, w8, surf_last.bias, *args)
+
+
+def volsdf_point_forward(model, x, view_dirs, native_radiance: bool = False):
     """VolSDF.forward (volsdf.py:349-370): sphere clamp on sdf only, raw nabla into the radiance net."""
-    sdf, nabla, feat = surface_forward_with_nablas(model.implicit_surface, x)
+    sdf, nabla, feat = surface_forward_with_nablas(model.implicit_surface, x, return_h=native_radiance)
     d_bg = model.obj_bounding_radius - x.norm(dim=-1)
     sdf = torch.where(d_bg < sdf, d_bg, sdf)
+    if native_radiance:
+        return radiance_forward_native(model, x, view_dirs, nabla, feat), sdf, nabla
     return radiance_forward(model.radiance_net, x, view_dirs, nabla, feat), sdf, nabla
 
 
@@ -122,11 +207,12 @@ def volsdf_render_samples(model, rays_o, rays_dn, d_all, white_bkgd=False, calc_
     R, P = d_all.shape
     pts = rays_o[:, None, :] + rays_dn[:, None, :] * d_all[:, :, None]
     v = rays_dn[:, None, :].expand_as(pts)
-    rad, sdf, nab = volsdf_point_forward(model, pts.reshape(-1, 3), v.reshape(-1, 3))
-    rad, sdf, nab = rad.reshape(R, P, 3), sdf.reshape(R, P), nab.reshape(R, P, 3)
-    alpha, beta = model.forward_ab()
     if native_composite is None:
         native_composite = d_all.is_cuda
+    native_radiance = bool(native_composite and getattr(model, "precision", "fp32") == "bf16x3")
+    rad, sdf, nab = volsdf_point_forward(model, pts.reshape(-1, 3), v.reshape(-1, 3), native_radiance)
+    rad, sdf, nab = rad.reshape(R, P, 3), sdf.reshape(R, P), nab.reshape(R, P, 3)
+    alpha, beta = model.forward_ab()
     if native_composite:
         # only rgb is produced (all the fine-tune losses need); depth / mask / normals maps come from pass 1
         out = {"rgb": CompositeRGB.apply(d_all, sdf, rad, alpha, beta, white_bkgd)}

@@ -436,6 +436,10 @@ int sdf_bf16(const float* blob, const PointSrc& s, float R_bg, float* out, int o
 int sdf_nabla_bf16(const float* blob, const PointSrc& s, float R_bg, float* sdf, float* nabla, float* h7, hipStream_t st);
 int radiance_bf16(const float* blob, int view_tiles, const PointSrc& s, const float* nabla, const float* h7, float* rgb, hipStream_t st);
 size_t sdf_grad_ws_bytes();
+size_t radiance_dump_bytes(long long M);
+int radiance_fwd_dump_bf16(const float* blob, int view_tiles, const PointSrc& s, const float* nabla, const float* h7, float* rgb, void* dump, hipStream_t st);
+int radiance_bwd_bf16(const float* blob, long long M, const float* rgb, const float* g_rgb, void* fwd_dump, void* bwd_dump, float* g_h7,
+                      float* g_n, hipStream_t st);
 int sdf_grad_bf16(const float* blob, const PointSrc& s, float R_bg, float* sdf, float* nabla, float* h7, void* ws, hipStream_t st);
 void* grad_scratch(hipStream_t st, size_t bytes);
 static int check_precision(int precision, bool allow_fwd_tangents = false) {
@@ -536,4 +540,25 @@ int nerfart_radiance_fwd_rays(const float* blob, int precision, int view_tiles, 
     return 2;
 }
 
+
+// ---- radiance net with activation dumps + its backward (row a19; split-bf16 blobs only) ----------------------
+long long nerfart_radiance_dump_bytes(long long M) { return (long long)radiance_dump_bytes(M); }
+
+int nerfart_radiance_fwd_dump(const float* rad_blob, int view_tiles, const float* pts, const float* view, long long M,
+                              const float* nabla, const float* h7, float* rgb_out, void* dump, void* stream) {
+    if (int rc = check_M(M)) return rc;
+    if (M == 0) return 0;
+    PointSrc s = make_src(pts, view, nullptr, nullptr, nullptr, nullptr, 1, 0, M);
+    if (int rc = validate_src(s)) return rc;
+    if (!dump) { set_last_error("radiance_fwd_dump: dump buffer is NULL"); return 2; }
+    return radiance_fwd_dump_bf16(rad_blob, view_tiles, s, nabla, h7, rgb_out, dump, (hipStream_t)stream);
+}
+
+int nerfart_radiance_bwd(const float* rad_blob, long long M, const float* rgb, const float* g_rgb, void* fwd_dump, void* bwd_dump,
+                         float* g_h7_out, float* g_n_out, void* stream) {
+    if (int rc = check_M(M)) return rc;
+    if (M == 0) return 0;
+    if (!fwd_dump || !bwd_dump) { set_last_error("radiance_bwd: dump buffers are NULL"); return 2; }
+    return radiance_bwd_bf16(rad_blob, M, rgb, g_rgb, fwd_dump, bwd_dump, g_h7_out, g_n_out, (hipStream_t)stream);
+}
 }  // extern "C"

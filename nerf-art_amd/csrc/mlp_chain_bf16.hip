@@ -163,7 +163,9 @@ __device__ __forceinline__ const float* stream_acquire(Stream& s) {
 //   0 softplus(beta = 100)                         3 reverse sweep: z * softplus'(z_l), softplus' from the unorm16 pair `din`
 //   1 softplus value / tangent columns (quads)     4 reverse sweep, first step: softplus'(z) itself
 //   2 max(z, floor)                                5 forward sweep of the reverse-mode kernel: softplus + `dout` =
-//                                                    softplus'(z) of the pair as packed unorm16
+//   8 = 2, the unit's bf16 hi part is dumped         softplus'(z) of the pair as packed unorm16
+//   7 radiance backward: z * [r > 0], r = the pair of bf16 activations `din` dumped by mode 8; 9: z itself
+//     (7 and 9 dump the unit's hi part: the deltas of the weight-gradient GEMMs)
 // ---------------------------------------------------------------------------------------
 // max(z, 0) in one instruction (fmaxf() first canonicalises z with a v_max_f32 z, z)
 __device__ __forceinline__ float relu1(float z) {
@@ -192,11 +194,18 @@ __device__ __forceinline__ void epi_phase(float z0, float z1, Work& w, unsigned&
             w.r0 = (float)(din & 0xffffu);          // 65535 * softplus'(z_l): the 1/65535 lives in the packed weights
             w.r1 = (float)(din >> 16);
         }
+        if constexpr (MODE == 7) {
+            w.r0 = (din & 0xffffu) ? 1.f : 0.f;     // relu mask from the dumped activation (bf16 bits)
+            w.r1 = (din >> 16) ? 1.f : 0.f;
+        }
     } else if constexpr (PH == 1) {
-        if constexpr (MODE == 2) {
+        if constexpr (MODE == 2 || MODE == 8) {
             w.y0 = fmaxf(z0, floor);
             w.y1 = fmaxf(z1, floor);
-        } else if constexpr (MODE == 3) {
+        } else if constexpr (MODE == 9) {
+            w.y0 = z0;
+            w.y1 = z1;
+        } else if constexpr (MODE == 3 || MODE == 7) {
             w.y0 = z0 * w.r0;
             w.y1 = z1 * w.r1;
         } else if constexpr (MODE == 4) {
@@ -233,7 +242,8 @@ __device__ __forceinline__ void epi_phase(float z0, float z1, Work& w, unsigned&
 // ws + ((8 l + u) * 8 + wave) * 1024 + lane * 16.
 // ---------------------------------------------------------------------------------------
 struct GradCtx {
-    char* ws;                 // scratch of this wave: workgroup base + wave * 1024 (wave uniform)
+    char* ws;                 // scratch of this wave: workgroup base + wave * 1024 (wave uniform) - loads
+    char* ws_out;             // where finished units are stored (same as ws in the reverse-mode SDF kernel)
     unsigned voff;            // lane * 16
     int layer;                // layer whose weights are being applied (wave uniform)
     u32x4 dbuf[2];            // backward sweep: softplus' units, k-step parity double buffer
@@ -285,6 +295,8 @@ struct Cfg {
     // unit whose epilogue is hosted by k-step ks: a unit of act(P) (0..7), 100 = unit 0 of act(Q), -1 = none
     static constexpr int hosted(int ks) { return (ks + 1 < NH_) ? ks + 1 : ((NEXT0_ && ks == NH_ + NX_ - 1) ? 100 : -1); }
     static constexpr int mode_of(int hu) { return hu == 100 ? MQ_ : MODE_; }
+    static constexpr bool stores(int m) { return m == 5 || m == 7 || m == 8 || m == 9; }     // unit dumped when finished
+    static constexpr bool loads(int m) { return m == 3 || m == 7; }                          // unit needs a `din` unit
 };
 
 template <class L, int C, int NKC, int IT>
@@ -309,12 +321,12 @@ struct Items {
             if constexpr (T == 0) {
                 // reverse-mode kernel, forward sweep: store the softplus' unit finished in the previous k-step
                 constexpr int HUP = (ks == 0) ? (L::PEND_IN ? 100 : -1) : L::hosted(ks - 1);
-                constexpr bool STORE = (ks == 0) ? L::PEND_IN : (HUP >= 0 && L::mode_of(HUP) == 5);
+                constexpr bool STORE = (ks == 0) ? L::PEND_IN : (HUP >= 0 && L::stores(L::mode_of(HUP)));
                 if constexpr (STORE) *reinterpret_cast<u32x4*>(gc.pend_ptr + gc.voff) = gc.dpend;
                 // backward sweep: load the softplus' unit needed by the slices of the NEXT k-step
                 if constexpr (ks + 1 < L::NKS) {
                     constexpr int HN = L::hosted(ks + 1);
-                    if constexpr (HN >= 0 && L::mode_of(HN) == 3) {
+                    if constexpr (HN >= 0 && L::loads(L::mode_of(HN))) {
                         if constexpr (HN == 100) d_load(gc, (gc.layer - 1) * 8, (ks + 1) & 1);
                         else d_load(gc, gc.layer * 8 + HN, (ks + 1) & 1);
                     }
@@ -333,7 +345,7 @@ struct Items {
                 constexpr int pr = (T - 4) / 3, ph = (T - 4) % 3;
                 constexpr int tile = (HU == 100 ? 0 : 2 * HU) + (pr >> 1), r0 = 2 * (pr & 1);
                 unsigned hi = 0, lo = 0, dout = 0;
-                const unsigned din = (HM == 3) ? gc.dbuf[ks & 1][pr] : 0u;
+                const unsigned din = L::loads(HM) ? gc.dbuf[ks & 1][pr] : 0u;
                 if constexpr (HU == 100) {
                     epi_phase<HM, ph>(Q.t[tile][r0], Q.t[tile][r0 + 1], w, hi, lo, ec.floor_q, ec.is_val, din, dout);
                     if constexpr (ph == 2) { x0n.h[pr] = hi; x0n.l[pr] = lo; }
@@ -341,11 +353,16 @@ struct Items {
                     epi_phase<HM, ph>(P.t[tile][r0], P.t[tile][r0 + 1], w, hi, lo, ec.floor_p, ec.is_val, din, dout);
                     if constexpr (ph == 2) { xb[HU & 1].h[pr] = hi; xb[HU & 1].l[pr] = lo; }
                 }
-                if constexpr (HM == 5) {
-                    if constexpr (ph == 1) gc.dacc[pr] = dout;
+                if constexpr (L::stores(HM)) {
+                    if constexpr (HM == 5) { if constexpr (ph == 1) gc.dacc[pr] = dout; }
+                    else { if constexpr (ph == 2) gc.dacc[pr] = hi; }
                     if constexpr (T == 15) {
                         gc.dpend = gc.dacc;
-                        gc.pend_ptr = gc.ws + (size_t)((HU == 100 ? gc.layer * 8 : (gc.layer - 1) * 8 + HU)) * 8192;
+                        // forward sweeps (5, 8): slot = the layer that PRODUCED the activation; radiance backward (7, 9):
+                        // slot 4 - layer (deltas of R3, R2, R1, R0, then the geometry-feature cotangent)
+                        const int idx = (HM == 5 || HM == 8) ? (HU == 100 ? gc.layer * 8 : (gc.layer - 1) * 8 + HU)
+                                                             : (HU == 100 ? (5 - gc.layer) * 8 : (4 - gc.layer) * 8 + HU);
+                        gc.pend_ptr = gc.ws_out + (size_t)idx * 8192;
                     }
                 }
             }
@@ -400,8 +417,10 @@ __device__ __forceinline__ void layer(const Acc& P, Acc& Q, const Unit& x0, cons
 
 // Epilogue of the last hidden layer: dot products of act(Q) with NROWS rows (+ the fp32 activations h7).
 template <int MODE, int NROWS>
-__device__ __forceinline__ void last_epilogue(const Acc& Q, const float* rows, float (&dot)[NROWS], float* h7, const EpiCtx& ec) {
+__device__ __forceinline__ void last_epilogue(const Acc& Q, const float* rows, float (&dot)[NROWS], float* h7, const EpiCtx& ec,
+                                              char* dump = nullptr) {
     const int g = lane_id() >> 4;
+    u32x4 du;
 #pragma unroll
     for (int T = 0; T < 16; ++T) {
         f32x4 y;
@@ -427,6 +446,12 @@ __device__ __forceinline__ void last_epilogue(const Acc& Q, const float* rows, f
         }
         if constexpr (MODE != 2) {
             if (h7 != nullptr && ec.is_val) *reinterpret_cast<f32x4*>(h7 + 16 * T + 4 * g) = y;
+        } else {
+            if (dump != nullptr) {          // unit T/2 = (tile T regs 0..3 | tile T+1 regs 0..3), bf16 hi parts
+                du[2 * (T & 1)] = pack_bf16(y[0], y[1]);
+                du[2 * (T & 1) + 1] = pack_bf16(y[2], y[3]);
+                if (T & 1) *reinterpret_cast<u32x4*>(dump + (size_t)(T >> 1) * 8192 + (lane_id() * 16)) = du;
+            }
         }
     }
 }
@@ -642,6 +667,7 @@ k_sdf_grad_bf16(const float* __restrict__ blob, PointSrc src, float R_bg, float*
     stream_start(s);
     GradCtx gc;
     gc.ws = ws + (size_t)blockIdx.x * GRAD_WS_PER_WG + wv * 1024;
+    gc.ws_out = gc.ws;
     gc.voff = lane * 16;
     gc.pend_ptr = gc.ws;
     const EpiCtx ec{0.f, 0.f, true};
@@ -802,10 +828,13 @@ __device__ __forceinline__ void radiance_extras(const Pt& pt, float nx, float ny
     }
 }
 
-template <int VE>
+constexpr int RAD_DUMP_PER_TILE = 5 * 8 * 8 * 1024;      // 5 activations x 8 units x 8 waves x 1 KiB (bf16, unit order)
+
+template <int VE, bool DUMP>
 __global__ void __launch_bounds__(WG_THREADS, 2)
 k_radiance_bf16(const float* __restrict__ blob, PointSrc src, const float* __restrict__ nabla_in,
-                const float* __restrict__ h7_in, float* __restrict__ rgb_out) {
+                const float* __restrict__ h7_in, float* __restrict__ rgb_out, char* __restrict__ dump) {
+    constexpr int M = DUMP ? 8 : 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int* hdr = reinterpret_cast<const int*>(blob);
     float* aux = smem + 2 * CHUNK_FLOATS;
@@ -826,6 +855,8 @@ k_radiance_bf16(const float* __restrict__ blob, PointSrc src, const float* __res
         Acc A, B;
         Unit x0, x0n, none[1];
         GradCtx gc;
+        gc.voff = lane * 16;
+        gc.ws = gc.ws_out = gc.pend_ptr = DUMP ? dump + (size_t)tile * RAD_DUMP_PER_TILE + wv * 1024 : nullptr;
         {
             // h7 -> units: unit u slot e < 4: feature 32u + 4g + e; e >= 4: 32u + 16 + 4g + (e - 4)
             Unit hu[8];
@@ -849,7 +880,8 @@ k_radiance_bf16(const float* __restrict__ blob, PointSrc src, const float* __res
             x0 = hu[0];
             // geometry feature = W8[1:] h7 + b8[1:] (no activation)
             const EpiCtx ec{-INFINITY, -INFINITY, true};
-            layer<Cfg<2, 2, 0, 8, true, false, false, false, 2>>(B, A, x0, hu, x0n, s, aux, ec, gc);
+            gc.layer = 0;
+            layer<Cfg<M, M, 0, 8, true, false, false>>(B, A, x0, hu, x0n, s, aux, ec, gc);
         }
         x0 = x0n;
         {
@@ -857,24 +889,168 @@ k_radiance_bf16(const float* __restrict__ blob, PointSrc src, const float* __res
             Unit ex[VE];
             radiance_extras<VE>(pt, nx, ny, nz, g, ex);
             const EpiCtx ec{-INFINITY, 0.f, true};
-            layer<Cfg<2, 2, 8, VE, true, false, false, false, 2>>(A, B, x0, ex, x0n, s, aux + 256, ec, gc);
+            gc.layer = 1;
+            layer<Cfg<M, M, 8, VE, true, false, DUMP>>(A, B, x0, ex, x0n, s, aux + 256, ec, gc);
         }
         A = B;
         x0 = x0n;
         const EpiCtx ec{0.f, 0.f, true};
 #pragma nounroll
         for (int L = 2; L < 4; ++L) {
-            layer<Cfg<2, 2, 8, 0, true, false, false, false, 2>>(A, B, x0, none, x0n, s, aux + L * 256, ec, gc);
+            gc.layer = L;
+            layer<Cfg<M, M, 8, 0, true, false, DUMP>>(A, B, x0, none, x0n, s, aux + L * 256, ec, gc);
             A = B;
             x0 = x0n;
         }
-        layer<Cfg<2, 2, 8, 0, false, false, false, false, 2>>(A, B, x0, none, x0n, s, aux + 4 * 256, ec, gc);
+        gc.layer = 4;
+        layer<Cfg<M, M, 8, 0, false, false, DUMP>>(A, B, x0, none, x0n, s, aux + 4 * 256, ec, gc);
         float dot[3] = {0.f, 0.f, 0.f};
-        last_epilogue<2, 3>(B, aux + RAD_AUX_ROWS, dot, nullptr, ec);
+        last_epilogue<2, 3>(B, aux + RAD_AUX_ROWS, dot, nullptr, ec, DUMP ? gc.ws_out + (size_t)(4 * 8) * 8192 : nullptr);
         float c[3];
 #pragma unroll
         for (int n = 0; n < 3; ++n) c[n] = sigmoidf_(sum_over_groups(dot[n]) + aux[RAD_AUX_BF + n]);
         if (valid && g < 3) rgb_out[(size_t)m * 3 + g] = (g == 0) ? c[0] : ((g == 1) ? c[1] : c[2]);
+    }
+}
+
+// =======================================================================================
+// Radiance net, backward (row a19): cotangents of the layer-7 activation h7 and of the normal input, and the
+// per-layer deltas for the weight-gradient GEMMs, from d loss / d rgb.  Consumes the activations the forward
+// kernel dumped (k_radiance_bf16<VE, true>: f = geometry feature, r0..r3 = relu outputs, bf16 hi parts in unit
+// order) - only their signs here - and streams the transposed-weight chunks that follow the forward program in the
+// blob (packing.radiance_plan_bf16): R3^T, R2^T, R1^T, the normal rows of R0^T, the feature rows of R0^T, W8[1:]^T.
+// Dumps (bf16, unit order, same [tile][slot][unit][wave][lane] layout): delta3, delta2, delta1, delta0, g_f.
+// =======================================================================================
+template <int IT>
+struct NrmItems {      // the 3 normal rows of R0^T: 8 k-steps x 1 output tile from one 16 KiB chunk
+    static __device__ __forceinline__ void run(f32x4& E, const Unit (&X)[8], Ring3& r, unsigned addr, const Stream& s) {
+        constexpr int N = 8;
+        if constexpr (IT < N) {
+            constexpr int S = IT % 3, S2 = (IT + 2) % 3;
+            constexpr int PENDING = (IT + 2 < N) ? 4 : ((IT + 1 < N) ? 2 : 0);
+            if constexpr (IT + 2 < N) {
+                if constexpr (S2 == 0) lds_read_pair<(IT + 2) * 2048>(r.h0, r.l0, addr);
+                else if constexpr (S2 == 1) lds_read_pair<(IT + 2) * 2048>(r.h1, r.l1, addr);
+                else lds_read_pair<(IT + 2) * 2048>(r.h2, r.l2, addr);
+            }
+            if constexpr (S == 0) { lds_wait_pair<PENDING>(r.h0, r.l0); E = mfma3(r.h0, r.l0, X[IT].h, X[IT].l, E); }
+            else if constexpr (S == 1) { lds_wait_pair<PENDING>(r.h1, r.l1); E = mfma3(r.h1, r.l1, X[IT].h, X[IT].l, E); }
+            else { lds_wait_pair<PENDING>(r.h2, r.l2); E = mfma3(r.h2, r.l2, X[IT].h, X[IT].l, E); }
+            stream_piece<IT>(s);
+            __builtin_amdgcn_sched_barrier(0);
+            NrmItems<IT + 1>::run(E, X, r, addr, s);
+        }
+    }
+};
+
+// unit u of (P * [mask != 0]) as a B operand
+__device__ __forceinline__ Unit masked_unit(const Acc& P, int u, const u32x4 mk) {
+    Unit X;
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {
+        const int r0 = 2 * (pr & 1);
+        const f32x4 t = (pr >> 1) ? P.t[2 * u + 1] : P.t[2 * u];
+        const float y0 = (mk[pr] & 0xffffu) ? t[r0] : 0.f;
+        const float y1 = (mk[pr] >> 16) ? t[r0 + 1] : 0.f;
+        unsigned hi, lo;
+        split2(y0, y1, hi, lo);
+        X.h[pr] = hi; X.l[pr] = lo;
+    }
+    return X;
+}
+
+__global__ void __launch_bounds__(WG_THREADS, 2)
+k_radiance_bwd_bf16(const float* __restrict__ blob, unsigned M, const float* __restrict__ rgb, const float* __restrict__ g_rgb,
+                    char* __restrict__ fwd_dump, char* __restrict__ bwd_dump, float* __restrict__ g_h7_out,
+                    float* __restrict__ g_n_out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int* hdr = reinterpret_cast<const int*>(blob);
+    float* aux = smem + 2 * CHUNK_FLOATS;
+    const int lane = lane_id(), g = lane >> 4, j = lane & 15, wv = wave_id();
+    load_aux(aux, blob, hdr, RAD_AUX_FLOATS);
+    const unsigned ntiles = (M + 127u) / 128u;
+    if (blockIdx.x >= ntiles) return;
+    Stream s = make_stream(blob, aux, smem, hdr[6] - hdr[2]);          // the reverse chunks only
+    s.tab += hdr[2];
+    s.wrap = (blockIdx.x + gridDim.x) < ntiles;
+    stream_start(s);
+    const EpiCtx ec{0.f, 0.f, true};
+    const float* rows = aux + RAD_AUX_ROWS;
+    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        s.wrap = (tile + gridDim.x) < ntiles;
+        const unsigned m = tile * 128u + wv * 16 + j;
+        const bool valid = m < M;
+        GradCtx gc;
+        gc.voff = lane * 16;
+        gc.ws = fwd_dump + (size_t)tile * RAD_DUMP_PER_TILE + wv * 1024;
+        gc.ws_out = gc.pend_ptr = bwd_dump + (size_t)tile * RAD_DUMP_PER_TILE + wv * 1024;
+        // delta4 = g_rgb * rgb (1 - rgb); g_r3 = R4^T delta4 (3 rows: plain FMAs)
+        float d4[3] = {0.f, 0.f, 0.f};
+        if (valid) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float o = rgb[(size_t)m * 3 + c];
+                d4[c] = g_rgb[(size_t)m * 3 + c] * o * (1.f - o);
+            }
+        }
+        Acc A, B;
+#pragma unroll
+        for (int T = 0; T < 16; ++T) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(rows + 16 * T + 4 * g);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(rows + 256 + 16 * T + 4 * g);
+            const f32x4 w2 = *reinterpret_cast<const f32x4*>(rows + 512 + 16 * T + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A.t[T][r] = fmaf(d4[2], w2[r], fmaf(d4[1], w1[r], d4[0] * w0[r]));
+        }
+        Unit x0, x0n, none[1];
+        {   // unit 0 of delta3 (mask = r3, slot 4); it is also the first dumped unit (delta slot 0)
+            const u32x4 mk = *reinterpret_cast<const u32x4*>(gc.ws + (size_t)(4 * 8) * 8192 + gc.voff);
+            x0 = masked_unit(A, 0, mk);
+            *reinterpret_cast<u32x4*>(gc.ws_out + gc.voff) = x0.h;
+        }
+        none[0] = x0;
+        d_load(gc, 4 * 8 + 1, 0);
+        gc.layer = 4;
+        layer<Cfg<7, 7, 8, 0, true, true, false, true>>(A, B, x0, none, x0n, s, aux, ec, gc);       // R3^T
+        A = B;
+        x0 = x0n;
+#pragma nounroll
+        for (int L = 3; L > 1; --L) {
+            gc.layer = L;
+            layer<Cfg<7, 7, 8, 0, true, true, true, true>>(A, B, x0, none, x0n, s, aux, ec, gc);     // R2^T, R1^T
+            A = B;
+            x0 = x0n;
+        }
+        // A = g_r0.  Normal rows of R0^T (d loss / d n) need all 8 units of delta0 at once.
+        {
+            Unit X[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const u32x4 mk = *reinterpret_cast<const u32x4*>(gc.ws + (size_t)(1 * 8 + u) * 8192 + gc.voff);
+                X[u] = masked_unit(A, u, mk);
+            }
+            const float* wp = stream_acquire(s) + lane * 4;
+            const unsigned addr = (unsigned)(size_t)wp;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            Ring3 r;
+            f32x4 E = {0.f, 0.f, 0.f, 0.f};
+            lds_read_pair<0>(r.h0, r.l0, addr);
+            lds_read_pair<2048>(r.h1, r.l1, addr);
+            NrmItems<0>::run(E, X, r, addr, s);
+            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+            if (valid && g == 0) { g_n_out[(size_t)m * 3] = E[0]; g_n_out[(size_t)m * 3 + 1] = E[1]; g_n_out[(size_t)m * 3 + 2] = E[2]; }
+        }
+        gc.layer = 1;
+        layer<Cfg<7, 9, 8, 0, true, true, true, false>>(A, B, x0, none, x0n, s, aux, ec, gc);        // feature rows of R0^T
+        A = B;
+        x0 = x0n;
+        gc.layer = 0;
+        layer<Cfg<9, 9, 8, 0, false, true, true, false>>(A, B, x0, none, x0n, s, aux, ec, gc);       // W8[1:]^T
+        if (valid) {
+            float* o = g_h7_out + (size_t)m * 256;
+#pragma unroll
+            for (int T = 0; T < 16; ++T) *reinterpret_cast<f32x4*>(o + 16 * T + 4 * g) = B.t[T];
+        }
     }
 }
 
@@ -904,14 +1080,27 @@ int sdf_bf16(const float* blob, const PointSrc& s, float R_bg, float* out, int o
 int sdf_nabla_bf16(const float* blob, const PointSrc& s, float R_bg, float* sdf, float* nabla, float* h7, hipStream_t st) {
     return b16::launch_chain(1, (long long)s.M, b16::k_sdf_nabla_bf16, (s.M + 31u) / 32u, st, blob, s, R_bg, sdf, nabla, h7);
 }
+size_t radiance_dump_bytes(long long M) { return (size_t)((M + 127) / 128) * b16::RAD_DUMP_PER_TILE; }
+int radiance_fwd_dump_bf16(const float* blob, int view_tiles, const PointSrc& s, const float* nabla, const float* h7, float* rgb, void* dump, hipStream_t st) {
+    const unsigned nt = (s.M + 127u) / 128u;
+    if (view_tiles == 1) return b16::launch_chain(2, (long long)s.M, b16::k_radiance_bf16<1, true>, nt, st, blob, s, nabla, h7, rgb, (char*)dump);
+    if (view_tiles == 3) return b16::launch_chain(2, (long long)s.M, b16::k_radiance_bf16<2, true>, nt, st, blob, s, nabla, h7, rgb, (char*)dump);
+    set_last_error("radiance_fwd_dump: view_tiles must be 1 or 3");
+    return 2;
+}
+int radiance_bwd_bf16(const float* blob, long long M, const float* rgb, const float* g_rgb, void* fwd_dump, void* bwd_dump, float* g_h7,
+                      float* g_n, hipStream_t st) {
+    return b16::launch_chain(-1, M, b16::k_radiance_bwd_bf16, (unsigned)((M + 127) / 128), st, blob, (unsigned)M, rgb, g_rgb, (char*)fwd_dump,
+                             (char*)bwd_dump, g_h7, g_n);
+}
 size_t sdf_grad_ws_bytes() { return (size_t)num_cus() * b16::GRAD_WS_PER_WG; }
 int sdf_grad_bf16(const float* blob, const PointSrc& s, float R_bg, float* sdf, float* nabla, float* h7, void* ws, hipStream_t st) {
     return b16::launch_chain(1, (long long)s.M, b16::k_sdf_grad_bf16, (s.M + 127u) / 128u, st, blob, s, R_bg, sdf, nabla, h7, (char*)ws);
 }
 int radiance_bf16(const float* blob, int view_tiles, const PointSrc& s, const float* nabla, const float* h7, float* rgb, hipStream_t st) {
     const unsigned nt = (s.M + 127u) / 128u;
-    if (view_tiles == 1) return b16::launch_chain(2, (long long)s.M, b16::k_radiance_bf16<1>, nt, st, blob, s, nabla, h7, rgb);
-    if (view_tiles == 3) return b16::launch_chain(2, (long long)s.M, b16::k_radiance_bf16<2>, nt, st, blob, s, nabla, h7, rgb);
+    if (view_tiles == 1) return b16::launch_chain(2, (long long)s.M, b16::k_radiance_bf16<1, false>, nt, st, blob, s, nabla, h7, rgb, (char*)nullptr);
+    if (view_tiles == 3) return b16::launch_chain(2, (long long)s.M, b16::k_radiance_bf16<2, false>, nt, st, blob, s, nabla, h7, rgb, (char*)nullptr);
     set_last_error("radiance_fwd: view_tiles must be 1 (raw view dirs) or 3 (multires_view = 4)");
     return 2;
 }

@@ -47,6 +47,9 @@ _SIGS = {
     "nerfart_sort_concat": (_i, [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p]),
     "nerfart_volsdf_composite": (_i, [_i, _i, _p, _p, _p, _p, _f, _f, _i] + [_p] * 8),
     "nerfart_volsdf_composite_bwd": (_i, [_i, _i, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p]),
+    "nerfart_radiance_dump_bytes": (_ll, [_ll]),
+    "nerfart_radiance_fwd_dump": (_i, [_p, _i, _p, _p, _ll, _p, _p, _p, _p, _p]),
+    "nerfart_radiance_bwd": (_i, [_p, _ll, _p, _p, _p, _p, _p, _p, _p]),
     "nerfart_volsdf_render_workspace_bytes": (_ll, [_i, _i, _i, _i, _i]),
     "nerfart_volsdf_render_fwd": (_i, [_p, _p, _i, _i, _p, _p, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i] + [_p] * 4 + [_p] * 13 + [_p, _ll, _p]),
     "nerfart_near_far_from_sphere": (_i, [_p, _p, _i, _f, _p, _p, _p]),
@@ -204,6 +207,29 @@ def volsdf_fine_sample(surf_blob, rays_o, rays_dn, near: float, far: float, R_bg
                                           _dev(lin_table(n_final, dev)), _dev(d_fine), _dev(beta_map), _dev(usage), ws.data_ptr(), ws.numel(),
                                           _stream()), "nerfart_volsdf_fine_sample")
     return d_fine, beta_map, usage
+
+
+def radiance_fwd_dump(rad_blob, view_tiles: int, pts, view, nabla, h7):
+    """Radiance net forward (split-bf16 blob) that also dumps the layer activations (bf16, unit order) for
+    radiance_bwd / the weight-gradient GEMMs.  Returns (rgb [M,3], dump uint8)."""
+    M = pts.shape[0]
+    rgb = torch.empty(M, 3, dtype=torch.float32, device=pts.device)
+    dump = torch.empty(int(lib.nerfart_radiance_dump_bytes(M)), dtype=torch.uint8, device=pts.device)
+    _check(lib.nerfart_radiance_fwd_dump(_dev(rad_blob), int(view_tiles), _dev(pts, name="pts"), _dev(view, name="view"), M,
+                                         _dev(nabla, name="nabla"), _dev(h7, name="h7"), _dev(rgb), dump.data_ptr(), _stream()),
+           "nerfart_radiance_fwd_dump")
+    return rgb, dump
+
+
+def radiance_bwd(rad_blob, rgb, g_rgb, fwd_dump):
+    """(g_h7 [M,256], g_n [M,3], delta dump uint8) for d loss / d rgb = g_rgb [M,3]."""
+    M = rgb.shape[0]
+    g_h7 = torch.empty(M, 256, dtype=torch.float32, device=rgb.device)
+    g_n = torch.empty(M, 3, dtype=torch.float32, device=rgb.device)
+    bwd_dump = torch.empty_like(fwd_dump)
+    _check(lib.nerfart_radiance_bwd(_dev(rad_blob), M, _dev(rgb), _dev(g_rgb), fwd_dump.data_ptr(), bwd_dump.data_ptr(), _dev(g_h7),
+                                    _dev(g_n), _stream()), "nerfart_radiance_bwd")
+    return g_h7, g_n, bwd_dump
 
 
 def volsdf_composite(d_all, sdf, radiance, alpha: float, beta: float, white_bkgd: bool = False):

@@ -362,7 +362,7 @@ class PackPlanBF16(PackPlan):
         return torch.cat([hdr, body, src[ai], torch.zeros(self.pad, dtype=torch.float32, device=dev)]).contiguous()
 
 
-def _kstep_index_T(flat, name, ks, kfeat_fn, row_feature, tiles=range(16)):
+def _kstep_index_T(flat, name, ks, kfeat_fn, row_feature, tiles=range(16), row0=0):
     """Transposed gather for the reverse-mode chain: index array [T in tiles][lane=64][e=8] of one k-step with
     A[row][k] = W[kfeat][rowfeat]: W's ROW index comes from the k slot (kfeat_fn(ks, g, e), -1 = zero), W's COLUMN
     index from the output row 16T + i (row_feature[16T + i], -1 = zero)."""
@@ -376,9 +376,9 @@ def _kstep_index_T(flat, name, ks, kfeat_fn, row_feature, tiles=range(16)):
         for g in range(4):
             for e in range(8):
                 kf = kfeat_fn(ks, g, e)
-                if kf < 0 or kf >= R:
+                if kf < 0 or kf + row0 >= R:
                     continue
-                idx[n, (16 * g + i)[ok], e] = flat.base[name] + kf * C + rf[ok]
+                idx[n, (16 * g + i)[ok], e] = flat.base[name] + (kf + row0) * C + rf[ok]
     return idx.reshape(-1)
 
 
@@ -494,7 +494,21 @@ def radiance_plan_bf16(view_tiles: int, W: int = 256, D: int = 4, W_geo_feat: in
     aux.append(flat.vec_index(f"rb{D}", _pad(ar(3), 4)))
     aux = np.concatenate(aux)
     assert len(aux) == RAD_AUX_FLOATS
-    return PackPlanBF16(PROG_RADIANCE_BF16, flat, chunks, aux)
+    # ---- reverse program (k_radiance_bwd_bf16): g_r{l-1} = R_l^T (g_r{l} * [r_l > 0]) for l = 3..1, the normal rows of
+    # R0^T (one output tile, all 8 k-steps in one 16 KiB chunk), the feature rows of R0^T, then W8[1:]^T.
+    nc_fwd = len(chunks)
+    nat = ar(256)
+    for name in ("r3", "r2", "r1"):
+        for c0 in range(0, 8, CHUNK_KS):
+            chunks.append(np.concatenate([_kstep_index_T(flat, name, ks, unit_feature_hidden, nat) for ks in range(c0, c0 + CHUNK_KS)]))
+    nrm_rows = np.full(256, -1, dtype=np.int64)
+    nrm_rows[:3] = n_extra - 3 + ar(3)
+    chunks.append(np.concatenate([_kstep_index_T(flat, "r0", ks, unit_feature_hidden, nrm_rows, tiles=(0,)) for ks in range(8)]))
+    for c0 in range(0, 8, CHUNK_KS):
+        chunks.append(np.concatenate([_kstep_index_T(flat, "r0", ks, unit_feature_hidden, n_extra + nat) for ks in range(c0, c0 + CHUNK_KS)]))
+    for c0 in range(0, 8, CHUNK_KS):
+        chunks.append(np.concatenate([_kstep_index_T(flat, "w8", ks, unit_feature_hidden, nat, row0=1) for ks in range(c0, c0 + CHUNK_KS)]))
+    return PackPlanBF16(PROG_RADIANCE_BF16, flat, chunks, aux, nc_main=nc_fwd)
 
 
 def fold_weight_norm(weight_g: torch.Tensor, weight_v: torch.Tensor) -> torch.Tensor:

@@ -496,3 +496,55 @@ def emul_sdf_grad_bf16(blob_np, pts16, R_bg):
                 part[lane, c] += E[t][lane, r] * jac
     nabla = np.stack([_group_sum(part[:, c]) for c in range(3)], axis=1)
     return sdf[:16], nabla[:16], h7
+
+
+# ======================================================================================================
+# Software model of k_radiance_bwd_bf16: the transposed-weight chunks that follow the forward radiance program.
+# Inputs are the forward activations as the forward kernel dumps them (relu outputs r0..r3) - only their sign is
+# used (masks) - plus d loss / d rgb and rgb.  Returns g_h7 [16,256], g_n [16,3] and the deltas of every layer.
+# ======================================================================================================
+def emul_radiance_bwd_bf16(blob_np, rgb16, g_rgb16, r_acts):
+    """r_acts: dict l -> [16, 256] relu outputs (natural feature order), l = 0..3."""
+    blob = Blob(blob_np)
+    nc_fwd, nc_all = int(blob.hdr[2]), int(blob.hdr[6])
+    blob.nc = nc_all
+    blob.offs = blob.hdr[HDR_OFFS: HDR_OFFS + nc_all + 1]
+    blob.c = nc_fwd
+    rows = blob.aux[1280:1280 + 768].reshape(3, 256)
+    d4 = (g_rgb16 * rgb16 * (1.0 - rgb16)).astype(np.float32)[J]                   # [64, 3]
+    P = [(d4[:, 0:1] * rows[0][_tile_feat(T)] + d4[:, 1:2] * rows[1][_tile_feat(T)] + d4[:, 2:3] * rows[2][_tile_feat(T)]).astype(np.float32)
+         for T in range(16)]
+    zero = [np.zeros((64, 4), np.float32) for _ in range(16)]
+    mask = lambda l: [(r_acts[l][J[:, None], _tile_feat(T)] > 0).astype(np.float32) for T in range(16)]
+    deltas = {}
+    for l in (3, 2, 1):
+        m = mask(l)
+        dl = [(P[T] * m[T]).astype(np.float32) for T in range(16)]
+        deltas[l] = dl
+        P = _acc_layer(_units_of(dl), blob, zero)
+    m = mask(0)
+    d0 = [(P[T] * m[T]).astype(np.float32) for T in range(16)]
+    deltas[0] = d0
+    units = _units_of(d0)
+    w = blob.acquire()                                   # normal rows of R0^T: 8 k-steps x 1 tile
+    E = np.zeros((64, 4), np.float32)
+    for ks in range(8):
+        raw = np.ascontiguousarray(w[ks * TS_FLOATS:(ks + 1) * TS_FLOATS]).view(np.uint16).reshape(2, 64, 8)
+        f = (raw.astype(np.uint32) << 16).view(np.float32)
+        E = mfma_16x16x32(f[0], units[ks][0], E)
+        E = mfma_16x16x32(f[0], units[ks][1], E)
+        E = mfma_16x16x32(f[1], units[ks][0], E)
+    g_n = E[:16, :3].copy()                              # lanes g = 0: rows 0..2
+    P = _acc_layer(units, blob, zero)                    # g_feat
+    deltas["f"] = P
+    P = _acc_layer(_units_of(P), blob, zero)             # g_h7 = W8[1:]^T g_feat
+    g_h7 = np.zeros((16, 256), np.float32)
+    nat = lambda tiles: np.stack([np.concatenate([tiles[T][16 * g + j] for T in range(16) for g in [gg]]) for j in range(16) for gg in [0]]) if False else None
+    for T in range(16):
+        g_h7[J[:, None], _tile_feat(T)] = P[T]
+    def to_nat(tiles):
+        out = np.zeros((16, 256), np.float32)
+        for T in range(16):
+            out[J[:, None], _tile_feat(T)] = tiles[T]
+        return out
+    return g_h7, g_n, {k: to_nat(v) for k, v in deltas.items()}

@@ -89,12 +89,12 @@ def _blobs_bf16(fw):
 
 def test_bf16_blob_header():
     _, surf, rad, _ = _blobs_bf16("VolSDF")
-    for blob, nc, nc_all in ((surf, 30, 59), (rad, 21, 21)):
+    for blob, nc, nc_all in ((surf, 30, 59), (rad, 21, 42)):
         hdr = blob[:512].view(np.int32)
         assert hdr[0] == packing.MAGIC and hdr[2] == nc and hdr[6] == nc_all and hdr[3] == blob.size
         offs = hdr[16:16 + nc_all + 1]
-        # 1 or 2 k-steps of 32 KiB; the reverse-mode program ends with one 48 KiB chunk (8 k-steps x 3 tiles)
-        assert set(np.diff(offs).tolist()) <= {8192, 12288, 16384} and offs[-1] == hdr[4]
+        # 1 or 2 k-steps of 32 KiB; the reverse programs hold one 48 KiB (8 k-steps x 3 tiles) / 16 KiB (x 1 tile) chunk
+        assert set(np.diff(offs).tolist()) <= {4096, 8192, 12288, 16384} and offs[-1] == hdr[4]
         assert offs[-2] + 16384 <= blob.size          # the stream copies 64 KiB per chunk
 
 
@@ -155,3 +155,37 @@ def test_emulated_bf16_reverse_mode_grad_matches_oracle():
     w8 = nets.folded_weight(sd, "implicit_surface.surface_fc_layers.8").numpy()
     b8 = sd["implicit_surface.surface_fc_layers.8.bias"].numpy()
     np.testing.assert_allclose(h7 @ w8[1:].T + b8[1:], feat_ref.numpy(), atol=5e-4, rtol=1e-3)
+
+
+@pytest.mark.parametrize("fw", ["VolSDF", "NeuS"])
+def test_emulated_bf16_radiance_backward_matches_autograd(fw):
+    """Transposed-weight program of the radiance blob (k_radiance_bwd_bf16's data flow) against torch autograd."""
+    sd, surf, rad, vt = _blobs_bf16(fw)
+    hdr = rad[:512].view(np.int32)
+    assert hdr[2] == 21 and hdr[6] == 42
+    g = torch.Generator().manual_seed(29)
+    pts = (torch.rand(16, 3, generator=g) * 2 - 1)
+    view = torch.nn.functional.normalize(torch.randn(16, 3, generator=g), dim=-1)
+    _, nab, _ = nets.surface_forward_with_nablas(sd, pts)
+    h7 = torch.rand(16, 256, generator=g) * 0.2
+    W8 = nets.folded_weight(sd, "implicit_surface.surface_fc_layers.8")
+    b8 = sd["implicit_surface.surface_fc_layers.8.bias"]
+    mv = -1 if fw == "VolSDF" else 4
+    h7g, nabg = h7.clone().requires_grad_(True), nab.clone().requires_grad_(True)
+    feat = h7g @ W8[1:].T + b8[1:]
+    # layer-by-layer forward to get the relu outputs
+    from oracle.nets import embed, folded_weight
+    x = torch.cat([pts, embed(view, mv), nabg, feat], dim=-1)
+    acts = {}
+    hcur = x
+    for l in range(4):
+        hcur = torch.relu(torch.nn.functional.linear(hcur, folded_weight(sd, f"radiance_net.layers.{l}"), sd[f"radiance_net.layers.{l}.bias"]))
+        acts[l] = hcur
+    rgb = torch.sigmoid(torch.nn.functional.linear(hcur, folded_weight(sd, "radiance_net.layers.4"), sd["radiance_net.layers.4.bias"]))
+    np.testing.assert_allclose(rgb.detach().numpy(), nets.radiance_forward(sd, pts, view, nab, feat.detach(), -1, mv).numpy(), atol=1e-6)
+    g_rgb = torch.randn(16, 3, generator=g)
+    rgb.backward(g_rgb)
+    g_h7, g_n, deltas = em.emul_radiance_bwd_bf16(rad, rgb.detach().numpy(), g_rgb.numpy(), {l: a.detach().numpy() for l, a in acts.items()})
+    sc = float(h7g.grad.abs().max())
+    np.testing.assert_allclose(g_h7, h7g.grad.numpy(), atol=2e-4 * sc, rtol=2e-3)
+    np.testing.assert_allclose(g_n, nabg.grad.numpy(), atol=2e-4 * float(nabg.grad.abs().max()), rtol=2e-3)
