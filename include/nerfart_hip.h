@@ -82,6 +82,20 @@ int nerfart_radiance_fwd_dump(const float* rad_blob, int view_tiles, const float
 int nerfart_radiance_bwd(const float* rad_blob, long long M, const float* rgb, const float* g_rgb, void* fwd_dump, void* bwd_dump,
                          float* g_h7_out, float* g_n_out, void* stream);
 
+/* ---- B2 "bwd", SDF half (row a19; split-bf16 surface blob).  Parameter gradients of
+ *        sbar * sdf + hbar7 . h7 + nbar . grad_x sdf        (what rgb.backward + eikonal.backward ask of the SDF net,
+ * volsdf.py:766-770, through ImplicitSurface.forward_with_nablas' create_graph=True, base.py:272-279) need, per layer,
+ * the operands of  dW_l = sum_p zbar_l (x) a_{l-1} + (t_l d_l) (x) adot_{l-1}  (see csrc/mlp_chain_bf16.hip):
+ *   nerfart_sdf_fwd2: pts[M,3], dir[M,3] = nbar -> f2_dump: (a_l | adot_l) bf16 and softplus'(z_l) unorm16, l = 0..7
+ *   nerfart_sdf_bwd2: gbar_h7[M,256], gbar_sdf[M], f2_dump -> r2_dump: 65535 * (t_l d_l | zbar_l) bf16, l = 0..7
+ * (unit order, [tile of 64 points][slot][unit 8][wave 8][lane 64][8]; even lanes = first, odd lanes = second column).
+ * The GEMMs and the weight_norm chain rule are host side (nerf-art_amd/autodiff.py: surface_weight_grads). */
+long long nerfart_sdf_fwd2_dump_bytes(long long M);
+long long nerfart_sdf_bwd2_dump_bytes(long long M);
+int nerfart_sdf_fwd2(const float* surf_blob, const float* pts, const float* dir, long long M, void* f2_dump, void* stream);
+int nerfart_sdf_bwd2(const float* surf_blob, long long M, const float* gbar_h7, const float* gbar_sdf, void* f2_dump, void* r2_dump,
+                     void* stream);
+
 /* ---- rays.  rend_util.get_rays (utils/rend_util.py:112-165) for one camera: pose/K are row-major 4x4
  * on the device; select (int64, may be NULL = all H*W pixels in row-major order) picks pixel indices. */
 int nerfart_get_rays(const float* pose_dev, const float* K_dev, int H, int W, const long long* select_dev, int n,

@@ -83,10 +83,155 @@ def _unit_perm(device):
 
 
 def _dump_matrix(dump: torch.Tensor, slot: int, M: int) -> torch.Tensor:
-    """[M, 256] fp32 (columns in unit order) of one dumped activation / delta."""
+    """[M, 256] bf16 (columns in unit order) of one dumped activation / delta."""
     T = dump.numel() // _RAD_DUMP_PER_TILE
     v = dump.view(torch.bfloat16).view(T, 5, 8, 8, 4, 16, 8)[:, slot]            # tile, unit, wave, g, j, e
-    return v.permute(0, 2, 4, 1, 3, 5).reshape(T * 128, 256)[:M].float()
+    return v.permute(0, 2, 4, 1, 3, 5).reshape(T * 128, 256)[:M]
+
+
+def _mmT(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a^T b with bf16 operands and an fp32 result: the weight-gradient GEMMs (plain library GEMMs, hipBLASLt)."""
+    a = a if a.dtype == torch.bfloat16 else a.to(torch.bfloat16)
+    b = b if b.dtype == torch.bfloat16 else b.to(torch.bfloat16)
+    return torch.mm(a.t(), b, out_dtype=torch.float32)
+
+
+def _colsum(a: torch.Tensor) -> torch.Tensor:
+    return a.float().sum(0)          # (a GEMM against a ones column takes the N = 1 GEMV path: 70x slower)
+
+
+def _inv_perm(device):
+    perm = _unit_perm(device)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(256, device=device)
+    return inv
+
+
+def radiance_weight_grads(model, x, v, n, h7, rgb, g_rgb, dump, bdump):
+    """Gradients of the FOLDED radiance weights / biases and of rows 1.. of the last SDF layer: plain GEMMs of the deltas
+    (k_radiance_bwd_bf16's dump) with the activations (k_radiance_bf16<dump>'s)."""
+    M = x.shape[0]
+    inv = _inv_perm(x.device)
+    nat = lambda m: m[:, inv]                                                   # unit order -> natural feature order
+    acts = [nat(_dump_matrix(dump, s, M)) for s in range(5)]                     # f, r0, r1, r2, r3
+    deltas = [nat(_dump_matrix(bdump, s, M)) for s in range(5)]                  # d3, d2, d1, d0, g_f
+    d4 = g_rgb * rgb * (1.0 - rgb)
+    rad = model.radiance_net
+    ex = torch.cat([embed(x, rad.embed_multires), embed(v, rad.embed_multires_view), n], dim=-1)
+    gw, gb = [None] * 5, [None] * 5
+    gw[4], gb[4] = _mmT(d4, acts[4]), d4.sum(0)
+    gw[3], gb[3] = _mmT(deltas[0], acts[3]), _colsum(deltas[0])
+    gw[2], gb[2] = _mmT(deltas[1], acts[2]), _colsum(deltas[1])
+    gw[1], gb[1] = _mmT(deltas[2], acts[1]), _colsum(deltas[2])
+    gw[0], gb[0] = torch.cat([_mmT(deltas[3], ex), _mmT(deltas[3], acts[0])], dim=1), _colsum(deltas[3])
+    g_w8 = torch.cat([torch.zeros(1, 256, device=x.device), _mmT(deltas[4], h7)], dim=0)
+    g_b8 = torch.cat([torch.zeros(1, device=x.device), _colsum(deltas[4])])
+    return gw, gb, g_w8, g_b8
+
+
+_F2_SLOTS, _R2_SLOTS = 16, 8
+
+
+def _pair_matrix(dump: torch.Tensor, slots: int, slot: int, M: int) -> torch.Tensor:
+    """[2, M, 256] bf16 of one dumped slot of the column-pair kernels: [0] = even-lane column, [1] = odd-lane column
+    (features in unit order)."""
+    T = dump.numel() // (slots * 8 * 8 * 1024)
+    v = dump.view(torch.bfloat16).view(T, slots, 8, 8, 4, 8, 2, 8)[:, slot]      # tile, unit, wave, g, point, column, e
+    return v.permute(5, 0, 2, 4, 1, 3, 6).reshape(2, T * 64, 256)[:, :M]
+
+
+def embed_tangent(x, direction, multires: int):
+    """d embed(x) / d x . direction."""
+    out = [direction]
+    for k in range(multires):
+        f = 2.0 ** k
+        out += [torch.cos(x * f) * f * direction, -torch.sin(x * f) * f * direction]
+    return torch.cat(out, dim=-1)
+
+
+def surface_weight_grads(model, pts, sbar, hbar7, nbar):
+    """Gradients of the FOLDED SDF-net weights / biases for the cotangents (sbar of sdf [M], hbar7 of the layer-7
+    activation [M,256], nbar of grad_x sdf [M,3]) on k_sdf_fwd2_bf16 / k_sdf_bwd2_bf16 + GEMMs.  Returns (dW[0..8], db[0..8]);
+    layer 8 holds the sdf row only (rows 1.. belong to radiance_weight_grads)."""
+    from . import hip
+    surf = model.implicit_surface
+    surf_blob, _ = model.packed()
+    M = pts.shape[0]
+    pts, nbar = pts.contiguous(), nbar.contiguous()
+    f2 = hip.sdf_fwd2(surf_blob, pts, nbar)
+    r2 = hip.sdf_bwd2(surf_blob, hbar7.contiguous(), sbar.contiguous(), f2)
+    inv = _inv_perm(pts.device)
+    FA = [_pair_matrix(f2, _F2_SLOTS, l, M)[:, :, inv] for l in range(8)]           # [0] = a_l, [1] = adot_l  (bf16)
+    RZ = [_pair_matrix(r2, _R2_SLOTS, l, M)[:, :, inv] for l in range(8)]           # 65535 * ([0] = t_l d_l, [1] = zbar_l)
+    bf = torch.bfloat16
+    e = embed(pts, surf.embed_multires).to(bf)
+    ed = embed_tangent(pts, nbar, surf.embed_multires).to(bf)
+    rs2 = 1.0 / np.sqrt(2.0)
+    sc = 1.0 / 65535.0
+    dW, db = [None] * 9, [None] * 9
+    for l in range(8):
+        gz, zb = RZ[l][0], RZ[l][1]
+        out_dim = surf.surface_fc_layers[l].out_features
+        if l == 0:
+            w = _mmT(zb, e) + _mmT(gz, ed)
+        elif l in surf.skips:
+            hw = surf.W - e.shape[1]
+            w = torch.cat([_mmT(zb, FA[l - 1][0][:, :hw]) + _mmT(gz, FA[l - 1][1][:, :hw]), _mmT(zb, e) + _mmT(gz, ed)], dim=1) * rs2
+        else:
+            w = _mmT(zb, FA[l - 1][0]) + _mmT(gz, FA[l - 1][1])
+        dW[l] = (w * sc)[:out_dim]
+        db[l] = (_colsum(zb) * sc)[:out_dim]
+    w8 = torch.zeros(surf.surface_fc_layers[8].out_features, 256, device=pts.device)
+    w8[0] = _mmT(FA[7][0], sbar[:, None])[:, 0] + _colsum(FA[7][1])
+    b8 = torch.zeros(w8.shape[0], device=pts.device)
+    b8[0] = sbar.sum()
+    dW[8], db[8] = w8, b8
+    return dW, db
+
+
+def accumulate_folded_grads(layers, dW, db):
+    """p.grad += for weight_g / weight_v / bias of weight-normed layers, given gradients of the folded weights."""
+    folded = [torch._weight_norm(l.weight_v, l.weight_g, 0) for l in layers]
+    torch.autograd.backward(folded, [g.to(f.dtype) for g, f in zip(dW, folded)])
+    for l, g in zip(layers, db):
+        if l.bias.requires_grad:
+            l.bias.grad = g.clone() if l.bias.grad is None else l.bias.grad + g
+
+
+def volsdf_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikonal=0.1, use_eikonal=True, white_bkgd=False):
+    """Pass 2 of the fine-tune step for one patch, entirely on the hand-written kernels + GEMMs: accumulates into .grad what
+    rgb.backward(g_rgb) and (w_eikonal * MSE(|nabla|, 1)).backward() accumulate (volsdf.py:759-770).  Returns the eikonal loss."""
+    from . import hip
+    R, P = d_all.shape
+    pts = (rays_o[:, None, :] + rays_dn[:, None, :] * d_all[:, :, None]).reshape(-1, 3).contiguous()
+    v = rays_dn[:, None, :].expand(R, P, 3).reshape(-1, 3).contiguous()
+    surf_blob, rad_blob = model.packed()
+    Rbg = model.obj_bounding_radius
+    with torch.no_grad():
+        sdf, nab, h7 = hip.sdf_nabla_fwd(surf_blob, pts, Rbg, precision=model.precision_id)
+        rgb_pt, dump = hip.radiance_fwd_dump(rad_blob, model.view_tiles, pts, v, nab, h7)
+        alpha, beta = model.forward_ab()
+        g_sdf, g_rad, g_ab = hip.volsdf_composite_bwd(d_all.contiguous(), sdf.reshape(R, P), rgb_pt.reshape(R, P, 3), float(alpha),
+                                                      float(beta), g_rgb.contiguous(), white_bkgd)
+        clamped = sdf >= (Rbg - pts.norm(dim=-1)) - 1e-6            # sdf = min(net, R - |x|): no gradient to the net where clamped
+        sbar = torch.where(clamped, torch.zeros_like(sdf), g_sdf.reshape(-1))
+        g_h7, g_n, bdump = hip.radiance_bwd(rad_blob, rgb_pt, g_rad.reshape(-1, 3), dump)
+        nbar = g_n
+        eik = torch.zeros((), device=pts.device)
+        if use_eikonal:
+            nn_ = nab.norm(dim=-1)
+            eik = w_eikonal * ((nn_ - 1.0) ** 2).mean()
+            nbar = nbar + (w_eikonal * 2.0 / nn_.numel()) * ((nn_ - 1.0) / nn_)[:, None] * nab
+        gw, gb, g_w8, g_b8 = radiance_weight_grads(model, pts, v, nab, h7, rgb_pt, g_rad.reshape(-1, 3), dump, bdump)
+        dW, db = surface_weight_grads(model, pts, sbar, g_h7, nbar)
+        dW[8] = dW[8] + g_w8
+        db[8] = db[8] + g_b8
+    accumulate_folded_grads(list(model.implicit_surface.surface_fc_layers), dW, db)
+    if any(p.requires_grad for p in model.radiance_net.parameters()):
+        accumulate_folded_grads(list(model.radiance_net.layers), gw, gb)
+    a, b = model.forward_ab()
+    torch.autograd.backward([a, b], [g_ab[0:1].reshape(a.shape), g_ab[1:2].reshape(b.shape)])
+    return float(eik)
 
 
 class RadianceNetFn(torch.autograd.Function):
@@ -109,28 +254,10 @@ class RadianceNetFn(torch.autograd.Function):
         from . import hip
         model = ctx.model
         x, v, n, h7, rgb, dump = ctx.saved_tensors
-        M = x.shape[0]
         _, rad_blob = model.packed()
         g_rgb = g_rgb.contiguous()
         g_h7, g_n, bdump = hip.radiance_bwd(rad_blob, rgb, g_rgb, dump)
-        perm = _unit_perm(x.device)
-        inv = torch.empty_like(perm)
-        inv[perm] = torch.arange(256, device=x.device)
-        nat = lambda m: m[:, inv]                                                   # unit order -> natural feature order
-        acts = [nat(_dump_matrix(dump, s, M)) for s in range(5)]                     # f, r0, r1, r2, r3
-        deltas = [nat(_dump_matrix(bdump, s, M)) for s in range(5)]                  # d3, d2, d1, d0, g_f
-        d4 = g_rgb * rgb * (1.0 - rgb)
-        rad = model.radiance_net
-        ex = torch.cat([embed(x, rad.embed_multires), embed(v, rad.embed_multires_view), n], dim=-1)
-        gw = [None] * 5
-        gb = [None] * 5
-        gw[4], gb[4] = d4.t() @ acts[4], d4.sum(0)
-        gw[3], gb[3] = deltas[0].t() @ acts[3], deltas[0].sum(0)
-        gw[2], gb[2] = deltas[1].t() @ acts[2], deltas[1].sum(0)
-        gw[1], gb[1] = deltas[2].t() @ acts[1], deltas[2].sum(0)
-        gw[0], gb[0] = torch.cat([deltas[3].t() @ ex, deltas[3].t() @ acts[0]], dim=1), deltas[3].sum(0)
-        g_w8 = torch.cat([torch.zeros(1, 256, device=x.device), deltas[4].t() @ h7], dim=0)
-        g_b8 = torch.cat([torch.zeros(1, device=x.device), deltas[4].sum(0)])
+        gw, gb, g_w8, g_b8 = radiance_weight_grads(model, x, v, n, h7, rgb, g_rgb, dump, bdump)
         out = [None, None, None, g_n, g_h7, g_w8, g_b8]
         for l in range(5):
             out += [gw[l], gb[l]]

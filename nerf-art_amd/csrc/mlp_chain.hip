@@ -437,6 +437,10 @@ int sdf_nabla_bf16(const float* blob, const PointSrc& s, float R_bg, float* sdf,
 int radiance_bf16(const float* blob, int view_tiles, const PointSrc& s, const float* nabla, const float* h7, float* rgb, hipStream_t st);
 size_t sdf_grad_ws_bytes();
 size_t radiance_dump_bytes(long long M);
+size_t sdf_fwd2_dump_bytes(long long M);
+size_t sdf_bwd2_dump_bytes(long long M);
+int sdf_fwd2_bf16(const float* blob, long long M, const float* pts, const float* dirv, void* dump, hipStream_t st);
+int sdf_bwd2_bf16(const float* blob, long long M, const float* gbar_h7, const float* gbar_sdf, void* f2_dump, void* r2_dump, hipStream_t st);
 int radiance_fwd_dump_bf16(const float* blob, int view_tiles, const PointSrc& s, const float* nabla, const float* h7, float* rgb, void* dump, hipStream_t st);
 int radiance_bwd_bf16(const float* blob, long long M, const float* rgb, const float* g_rgb, void* fwd_dump, void* bwd_dump, float* g_h7,
                       float* g_n, hipStream_t st);
@@ -560,5 +564,24 @@ int nerfart_radiance_bwd(const float* rad_blob, long long M, const float* rgb, c
     if (M == 0) return 0;
     if (!fwd_dump || !bwd_dump) { set_last_error("radiance_bwd: dump buffers are NULL"); return 2; }
     return radiance_bwd_bf16(rad_blob, M, rgb, g_rgb, fwd_dump, bwd_dump, g_h7_out, g_n_out, (hipStream_t)stream);
+}
+
+// ---- second-order backward of the SDF net (row a19; split-bf16 surface blob) -------------------------------------
+long long nerfart_sdf_fwd2_dump_bytes(long long M) { return (long long)sdf_fwd2_dump_bytes(M); }
+long long nerfart_sdf_bwd2_dump_bytes(long long M) { return (long long)sdf_bwd2_dump_bytes(M); }
+
+int nerfart_sdf_fwd2(const float* surf_blob, const float* pts, const float* dir, long long M, void* f2_dump, void* stream) {
+    if (int rc = check_M(M)) return rc;
+    if (M == 0) return 0;
+    if (!pts || !dir || !f2_dump) { set_last_error("sdf_fwd2: NULL argument"); return 2; }
+    return sdf_fwd2_bf16(surf_blob, M, pts, dir, f2_dump, (hipStream_t)stream);
+}
+
+int nerfart_sdf_bwd2(const float* surf_blob, long long M, const float* gbar_h7, const float* gbar_sdf, void* f2_dump, void* r2_dump,
+                     void* stream) {
+    if (int rc = check_M(M)) return rc;
+    if (M == 0) return 0;
+    if (!gbar_h7 || !gbar_sdf || !f2_dump || !r2_dump) { set_last_error("sdf_bwd2: NULL argument"); return 2; }
+    return sdf_bwd2_bf16(surf_blob, M, gbar_h7, gbar_sdf, f2_dump, r2_dump, (hipStream_t)stream);
 }
 }  // extern "C"

@@ -166,6 +166,10 @@ __device__ __forceinline__ const float* stream_acquire(Stream& s) {
 //   8 = 2, the unit's bf16 hi part is dumped         softplus'(z) of the pair as packed unorm16
 //   7 radiance backward: z * [r > 0], r = the pair of bf16 activations `din` dumped by mode 8; 9: z itself
 //     (7 and 9 dump the unit's hi part: the deltas of the weight-gradient GEMMs)
+//  10 second-order SDF backward, forward sweep: column PAIRS (value, tangent along a given direction): like 1 with
+//     the softplus' taken from the pair's even lane; dumps the unit's hi part and softplus' (unorm16)
+//  11 second-order SDF backward, reverse sweep: column pairs (t = d sdf/d a, abar = d loss/d a):
+//     even lanes z D, odd lanes z D + 100 t tangent (65535 - D), D = 65535 softplus' (`din`), tangent = `din2` (bf16)
 // ---------------------------------------------------------------------------------------
 // max(z, 0) in one instruction (fmaxf() first canonicalises z with a v_max_f32 z, z)
 __device__ __forceinline__ float relu1(float z) {
@@ -174,19 +178,30 @@ __device__ __forceinline__ float relu1(float z) {
     return y;
 }
 
+// lane 2i of every pair (2i, 2i+1) to both: one VALU op with DPP quad_perm [0,0,2,2]
+__device__ __forceinline__ float pair_bcast0(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xA0, 0xF, 0xF, false));
+}
+
 template <int MODE, int PH>
 __device__ __forceinline__ void epi_phase(float z0, float z1, Work& w, unsigned& hi, unsigned& lo, float floor, bool is_val,
-                                          unsigned din, unsigned& dout) {
+                                          unsigned din, unsigned& dout, unsigned din2 = 0u) {
 #ifdef NERFART_ABLATE_EPI       // timing experiments only: no activation arithmetic
     if (PH == 2) { hi = __float_as_uint(z0); lo = __float_as_uint(z1); }
     return;
 #endif
     if constexpr (PH == 0) {
-        if constexpr (MODE == 0 || MODE == 1 || MODE == 4 || MODE == 5) {
+        if constexpr (MODE == 0 || MODE == 1 || MODE == 4 || MODE == 5 || MODE == 10) {
             w.e0 = __builtin_amdgcn_exp2f(fabsf(z0) * -144.269504088896340736f);     // exp(-|100 z|)
             w.e1 = __builtin_amdgcn_exp2f(fabsf(z1) * -144.269504088896340736f);
         }
-        if constexpr (MODE == 1 || MODE == 4 || MODE == 5) {
+        if constexpr (MODE == 11) {
+            w.r0 = (float)(din & 0xffffu);
+            w.r1 = (float)(din >> 16);
+            w.e0 = __uint_as_float(din2 << 16);     // tangent of the activation (bf16 hi part from the forward sweep)
+            w.e1 = __uint_as_float(din2 & 0xffff0000u);
+        }
+        if constexpr (MODE == 1 || MODE == 4 || MODE == 5 || MODE == 10) {
             w.r0 = __builtin_amdgcn_rcpf(1.0f + w.e0);
             w.r1 = __builtin_amdgcn_rcpf(1.0f + w.e1);
         }
@@ -211,6 +226,20 @@ __device__ __forceinline__ void epi_phase(float z0, float z1, Work& w, unsigned&
         } else if constexpr (MODE == 4) {
             w.y0 = (z0 >= 0.f) ? w.r0 : w.e0 * w.r0;
             w.y1 = (z1 >= 0.f) ? w.r1 : w.e1 * w.r1;
+        } else if constexpr (MODE == 11) {
+            const float t0 = pair_bcast0(z0), t1 = pair_bcast0(z1);                  // the pair's even lane: d sdf / d a
+            const float s0 = z0 * w.r0, s1 = z1 * w.r1;
+            w.y0 = is_val ? s0 : fmaf(100.0f * t0 * w.e0, 65535.0f - w.r0, s0);
+            w.y1 = is_val ? s1 : fmaf(100.0f * t1 * w.e1, 65535.0f - w.r1, s1);
+        } else if constexpr (MODE == 10) {
+            const float v0 = relu1(z0) + __builtin_amdgcn_logf(1.0f + w.e0) * (0.69314718055994530942f / 100.0f);
+            const float v1 = relu1(z1) + __builtin_amdgcn_logf(1.0f + w.e1) * (0.69314718055994530942f / 100.0f);
+            const float d0 = pair_bcast0((z0 >= 0.f) ? w.r0 : w.e0 * w.r0);
+            const float d1 = pair_bcast0((z1 >= 0.f) ? w.r1 : w.e1 * w.r1);
+            w.y0 = is_val ? v0 : d0 * z0;
+            w.y1 = is_val ? v1 : d1 * z1;
+            typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+            dout = __builtin_bit_cast(unsigned, (u16x2)__builtin_amdgcn_cvt_pknorm_u16(d0, d1));
         } else {
             const float v0 = relu1(z0) + __builtin_amdgcn_logf(1.0f + w.e0) * (0.69314718055994530942f / 100.0f);
             const float v1 = relu1(z1) + __builtin_amdgcn_logf(1.0f + w.e1) * (0.69314718055994530942f / 100.0f);
@@ -247,10 +276,17 @@ struct GradCtx {
     unsigned voff;            // lane * 16
     int layer;                // layer whose weights are being applied (wave uniform)
     u32x4 dbuf[2];            // backward sweep: softplus' units, k-step parity double buffer
+    u32x4 abuf[2];            // second-order reverse sweep: tangent units (bf16 hi parts)
+    u32x4 dacc2, dpend2;      // second-order forward sweep: the softplus' unit stored next to the hi unit (slot + 8)
     u32x4 dacc;               // forward sweep: unit being packed
     u32x4 dpend;              // forward sweep: finished unit, stored at the first triple of the next k-step
     char* pend_ptr;
 };
+// (l, unit) of the second-order kernels: softplus' at slot 8 + l, tangent / activation hi parts at slot l
+__device__ __forceinline__ void d_load2(GradCtx& gc, int idx, int buf) {
+    gc.dbuf[buf] = *reinterpret_cast<const u32x4*>(gc.ws + (size_t)(64 + idx) * 8192 + gc.voff);
+    gc.abuf[buf] = *reinterpret_cast<const u32x4*>(gc.ws + (size_t)idx * 8192 + gc.voff);
+}
 // Plain (compiler-visible) loads: hipcc then keeps its own vmcnt bookkeeping for them - with the LDS-DMA pieces it
 // cannot see this can only make its wait stricter.  (Hand-counted asm loads gave wrong gradients on random waves.)
 __device__ __forceinline__ void d_load(GradCtx& gc, int idx, int buf) {
@@ -295,8 +331,8 @@ struct Cfg {
     // unit whose epilogue is hosted by k-step ks: a unit of act(P) (0..7), 100 = unit 0 of act(Q), -1 = none
     static constexpr int hosted(int ks) { return (ks + 1 < NH_) ? ks + 1 : ((NEXT0_ && ks == NH_ + NX_ - 1) ? 100 : -1); }
     static constexpr int mode_of(int hu) { return hu == 100 ? MQ_ : MODE_; }
-    static constexpr bool stores(int m) { return m == 5 || m == 7 || m == 8 || m == 9; }     // unit dumped when finished
-    static constexpr bool loads(int m) { return m == 3 || m == 7; }                          // unit needs a `din` unit
+    static constexpr bool stores(int m) { return m == 5 || m == 7 || m == 8 || m == 9 || m == 10 || m == 11; }   // unit dumped when finished
+    static constexpr bool loads(int m) { return m == 3 || m == 7 || m == 11; }               // unit needs a `din` unit
 };
 
 template <class L, int C, int NKC, int IT>
@@ -322,16 +358,26 @@ struct Items {
                 // reverse-mode kernel, forward sweep: store the softplus' unit finished in the previous k-step
                 constexpr int HUP = (ks == 0) ? (L::PEND_IN ? 100 : -1) : L::hosted(ks - 1);
                 constexpr bool STORE = (ks == 0) ? L::PEND_IN : (HUP >= 0 && L::stores(L::mode_of(HUP)));
-                if constexpr (STORE) *reinterpret_cast<u32x4*>(gc.pend_ptr + gc.voff) = gc.dpend;
+                if constexpr (STORE) {
+                    *reinterpret_cast<u32x4*>(gc.pend_ptr + gc.voff) = gc.dpend;
+                    constexpr int PM = (ks == 0) ? L::MODE : L::mode_of(HUP);        // (mode 10 layers use 10 for both kinds)
+                    if constexpr (PM == 10) *reinterpret_cast<u32x4*>(gc.pend_ptr + (size_t)64 * 8192 + gc.voff) = gc.dpend2;
+                }
                 // backward sweep: load the softplus' unit needed by the slices of the NEXT k-step
                 if constexpr (ks + 1 < L::NKS) {
                     constexpr int HN = L::hosted(ks + 1);
                     if constexpr (HN >= 0 && L::loads(L::mode_of(HN))) {
-                        if constexpr (HN == 100) d_load(gc, (gc.layer - 1) * 8, (ks + 1) & 1);
-                        else d_load(gc, gc.layer * 8 + HN, (ks + 1) & 1);
+                        if constexpr (L::mode_of(HN) == 11) {
+                            if constexpr (HN == 100) d_load2(gc, (gc.layer - 1) * 8, (ks + 1) & 1);
+                            else d_load2(gc, gc.layer * 8 + HN, (ks + 1) & 1);
+                        } else {
+                            if constexpr (HN == 100) d_load(gc, (gc.layer - 1) * 8, (ks + 1) & 1);
+                            else d_load(gc, gc.layer * 8 + HN, (ks + 1) & 1);
+                        }
                     }
                 } else if constexpr (L::LOADNEXT) {
-                    d_load(gc, (gc.layer - 1) * 8 + 1, (ks + 1) & 1);
+                    if constexpr (L::MODE == 11) d_load2(gc, (gc.layer - 1) * 8 + 1, (ks + 1) & 1);
+                    else d_load(gc, (gc.layer - 1) * 8 + 1, (ks + 1) & 1);
                 }
             }
             // LDS-DMA: the 8 pieces per wave of the next chunk go out during items 5..8 of each k-step (after the
@@ -346,22 +392,26 @@ struct Items {
                 constexpr int tile = (HU == 100 ? 0 : 2 * HU) + (pr >> 1), r0 = 2 * (pr & 1);
                 unsigned hi = 0, lo = 0, dout = 0;
                 const unsigned din = L::loads(HM) ? gc.dbuf[ks & 1][pr] : 0u;
+                const unsigned din2 = (HM == 11) ? gc.abuf[ks & 1][pr] : 0u;
                 if constexpr (HU == 100) {
-                    epi_phase<HM, ph>(Q.t[tile][r0], Q.t[tile][r0 + 1], w, hi, lo, ec.floor_q, ec.is_val, din, dout);
+                    epi_phase<HM, ph>(Q.t[tile][r0], Q.t[tile][r0 + 1], w, hi, lo, ec.floor_q, ec.is_val, din, dout, din2);
                     if constexpr (ph == 2) { x0n.h[pr] = hi; x0n.l[pr] = lo; }
                 } else {
-                    epi_phase<HM, ph>(P.t[tile][r0], P.t[tile][r0 + 1], w, hi, lo, ec.floor_p, ec.is_val, din, dout);
+                    epi_phase<HM, ph>(P.t[tile][r0], P.t[tile][r0 + 1], w, hi, lo, ec.floor_p, ec.is_val, din, dout, din2);
                     if constexpr (ph == 2) { xb[HU & 1].h[pr] = hi; xb[HU & 1].l[pr] = lo; }
                 }
                 if constexpr (L::stores(HM)) {
                     if constexpr (HM == 5) { if constexpr (ph == 1) gc.dacc[pr] = dout; }
                     else { if constexpr (ph == 2) gc.dacc[pr] = hi; }
+                    if constexpr (HM == 10) { if constexpr (ph == 1) gc.dacc2[pr] = dout; }
                     if constexpr (T == 15) {
                         gc.dpend = gc.dacc;
+                        if constexpr (HM == 10) gc.dpend2 = gc.dacc2;
                         // forward sweeps (5, 8): slot = the layer that PRODUCED the activation; radiance backward (7, 9):
                         // slot 4 - layer (deltas of R3, R2, R1, R0, then the geometry-feature cotangent)
-                        const int idx = (HM == 5 || HM == 8) ? (HU == 100 ? gc.layer * 8 : (gc.layer - 1) * 8 + HU)
-                                                             : (HU == 100 ? (5 - gc.layer) * 8 : (4 - gc.layer) * 8 + HU);
+                        const int idx = (HM == 5 || HM == 8 || HM == 10) ? (HU == 100 ? gc.layer * 8 : (gc.layer - 1) * 8 + HU)
+                                        : (HM == 11)                     ? (HU == 100 ? (gc.layer - 1) * 8 : gc.layer * 8 + HU)
+                                                                         : (HU == 100 ? (5 - gc.layer) * 8 : (4 - gc.layer) * 8 + HU);
                         gc.pend_ptr = gc.ws_out + (size_t)idx * 8192;
                     }
                 }
@@ -914,6 +964,220 @@ k_radiance_bf16(const float* __restrict__ blob, PointSrc src, const float* __res
 }
 
 // =======================================================================================
+// Second-order backward of the SDF net (row a19): parameter gradients of
+//     Phi = sbar * sdf + hbar7 . a_7 + nbar . grad_x sdf            (sbar, hbar7, nbar: cotangents, per point)
+// nbar . grad_x sdf is the directional derivative of sdf along nbar, i.e. w8 . adot_7 with adot the forward-mode
+// tangent; reverse mode over the (value, tangent) recursion gives, per layer,
+//     t_{l-1} = W_l^T (t_l * d_l)                                    (t_7 = w8: the reverse sweep of k_sdf_grad_bf16)
+//     abar_{l-1} = W_l^T zbar_l,  zbar_l = abar_l * d_l + 100 t_l adot_l (1 - d_l)      (softplus'' = 100 d (1 - d))
+//     dW_l = sum_points zbar_l (x) a_{l-1} + (t_l d_l) (x) adot_{l-1},   db_l = sum zbar_l
+// Two kernels with COLUMN PAIRS (8 points per wave), both dumping bf16 GEMM operands in unit order
+// ([tile of 64 points][slot][unit 8][wave 8][lane 64][8]):
+//   k_sdf_fwd2_bf16: columns (value, tangent along nbar): slots 0..7 = (a_l | adot_l), slots 8..15 = softplus'(z_l) unorm16
+//   k_sdf_bwd2_bf16: columns (t, abar): consumes those, slots 0..7 = 65535 * (t_l d_l | zbar_l)
+// The weight-gradient GEMMs and the weight_norm chain rule are host side (autodiff.SurfaceBackward).
+// =======================================================================================
+constexpr int F2_DUMP_PER_TILE = 16 * 8 * 8 * 1024;
+constexpr int R2_DUMP_PER_TILE = 8 * 8 * 8 * 1024;
+
+// encoding units for the (value, tangent) pairs: value lanes as encode_units, tangent lanes d enc / d x . dir
+__device__ __forceinline__ void encode_units_pair(float x, float y, float z, float dx, float dy, float dz, int g, bool is_val, Unit (&X)[2]) {
+    const float cg = (g == 0) ? x : ((g == 1) ? y : z);
+    const float wg = (g == 0) ? dx : ((g == 1) ? dy : dz);
+    const bool live = g < 3;
+    float m[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) m[k] = 0.f;
+    m[0] = is_val ? cg : wg;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const float f = (float)(1 << k);
+        float sn, cs;
+        sincosf(cg * f, &sn, &cs);
+        m[1 + 2 * k] = is_val ? sn : cs * f * wg;
+        m[2 + 2 * k] = is_val ? cs : -(sn * f) * wg;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        u32x4 hi, lo;
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+            const float a = live ? m[8 * q + 2 * pr] : 0.f, b = live ? m[8 * q + 2 * pr + 1] : 0.f;
+            unsigned sh, sl;
+            split2(a, b, sh, sl);
+            hi[pr] = sh; lo[pr] = sl;
+        }
+        X[q].h = hi;
+        X[q].l = lo;
+    }
+}
+
+__global__ void __launch_bounds__(WG_THREADS, 2)
+k_sdf_fwd2_bf16(const float* __restrict__ blob, unsigned M, const float* __restrict__ pts, const float* __restrict__ dirv,
+                char* __restrict__ dump) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int* hdr = reinterpret_cast<const int*>(blob);
+    float* aux = smem + 2 * CHUNK_FLOATS;
+    const int lane = lane_id(), g = lane >> 4, j = lane & 15, wv = wave_id();
+    const bool is_val = (j & 1) == 0;
+    load_aux(aux, blob, hdr, SURF_AUX_FLOATS);
+    const unsigned ntiles = (M + 63u) / 64u;
+    if (blockIdx.x >= ntiles) return;
+    Stream s = make_stream(blob, aux, smem, hdr[2]);
+    s.wrap = (blockIdx.x + gridDim.x) < ntiles;
+    stream_start(s);
+    const EpiCtx ec{0.f, 0.f, is_val};
+    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        s.wrap = (tile + gridDim.x) < ntiles;
+        const unsigned m = tile * 64u + wv * 8 + (j >> 1);
+        float px = 0.f, py = 0.f, pz = 0.f, vx = 0.f, vy = 0.f, vz = 0.f;
+        if (m < M) {
+            px = pts[3 * (size_t)m]; py = pts[3 * (size_t)m + 1]; pz = pts[3 * (size_t)m + 2];
+            vx = dirv[3 * (size_t)m]; vy = dirv[3 * (size_t)m + 1]; vz = dirv[3 * (size_t)m + 2];
+        }
+        GradCtx gc;
+        gc.voff = lane * 16;
+        gc.ws = gc.ws_out = gc.pend_ptr = dump + (size_t)tile * F2_DUMP_PER_TILE + wv * 1024;
+        // unit 7 of layer 3 (features 224..255 of a 217-wide layer) is never built: the reverse sweep still reads it (against
+        // zero weights) - it must not hold a NaN
+        *reinterpret_cast<u32x4*>(gc.ws_out + (size_t)(3 * 8 + 7) * 8192 + gc.voff) = u32x4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(gc.ws_out + (size_t)(64 + 3 * 8 + 7) * 8192 + gc.voff) = u32x4{0u, 0u, 0u, 0u};
+        Acc A, B;
+        Unit x0, x0n, enc[2], none[1];
+        encode_units_pair(px, py, pz, vx, vy, vz, g, is_val, enc);
+        none[0] = enc[0];
+        x0 = enc[0];
+        gc.layer = 0;
+        layer<Cfg<10, 10, 0, 2, true, false, false>>(B, A, x0, enc, x0n, s, aux, ec, gc);
+        x0 = x0n;
+#pragma nounroll
+        for (int L = 1; L < 7; ++L) {
+            gc.layer = L;
+            if (L == 4) {
+                encode_units_pair(px, py, pz, vx, vy, vz, g, is_val, enc);
+                layer<Cfg<10, 10, 7, 2, true, false, true>>(A, B, x0, enc, x0n, s, aux + L * 256, ec, gc);
+            } else {
+                layer<Cfg<10, 10, 8, 0, true, false, true>>(A, B, x0, none, x0n, s, aux + L * 256, ec, gc);
+            }
+            A = B;
+            x0 = x0n;
+        }
+        gc.layer = 7;
+        layer<Cfg<10, 10, 8, 0, false, false, true>>(A, B, x0, none, x0n, s, aux + 7 * 256, ec, gc);
+        // layer 7's own activations / tangents / softplus' (no later layer hosts them)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            u32x4 hi, dd;
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr) {
+                const int r0 = 2 * (pr & 1);
+                const f32x4 t = (pr >> 1) ? B.t[2 * u + 1] : B.t[2 * u];
+                Work w = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                unsigned h = 0, l = 0, dout = 0;
+                epi_phase<10, 0>(t[r0], t[r0 + 1], w, h, l, 0.f, is_val, 0u, dout);
+                epi_phase<10, 1>(t[r0], t[r0 + 1], w, h, l, 0.f, is_val, 0u, dout);
+                epi_phase<10, 2>(t[r0], t[r0 + 1], w, h, l, 0.f, is_val, 0u, dout);
+                hi[pr] = h; dd[pr] = dout;
+            }
+            *reinterpret_cast<u32x4*>(gc.ws_out + (size_t)(7 * 8 + u) * 8192 + gc.voff) = hi;
+            *reinterpret_cast<u32x4*>(gc.ws_out + (size_t)(64 + 7 * 8 + u) * 8192 + gc.voff) = dd;
+        }
+    }
+}
+
+// unit u of the reverse sweep's input, outside the hosted pipeline (first unit of layer 7, all units of layer 0)
+__device__ __forceinline__ Unit pair_unit(const Acc& P, int u, const u32x4 dd, const u32x4 aa, bool is_val, u32x4& hi_out) {
+    Unit X;
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {
+        const int r0 = 2 * (pr & 1);
+        const f32x4 t = (pr >> 1) ? P.t[2 * u + 1] : P.t[2 * u];
+        Work w = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        unsigned h = 0, l = 0, dout = 0;
+        epi_phase<11, 0>(t[r0], t[r0 + 1], w, h, l, 0.f, is_val, dd[pr], dout, aa[pr]);
+        epi_phase<11, 1>(t[r0], t[r0 + 1], w, h, l, 0.f, is_val, dd[pr], dout, aa[pr]);
+        epi_phase<11, 2>(t[r0], t[r0 + 1], w, h, l, 0.f, is_val, dd[pr], dout, aa[pr]);
+        X.h[pr] = h; X.l[pr] = l;
+    }
+    hi_out = X.h;
+    return X;
+}
+
+__global__ void __launch_bounds__(WG_THREADS, 2)
+k_sdf_bwd2_bf16(const float* __restrict__ blob, unsigned M, const float* __restrict__ gbar_h7, const float* __restrict__ gbar_sdf,
+                char* __restrict__ f2_dump, char* __restrict__ r2_dump) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int* hdr = reinterpret_cast<const int*>(blob);
+    float* aux = smem + 2 * CHUNK_FLOATS;
+    const int lane = lane_id(), g = lane >> 4, j = lane & 15, wv = wave_id();
+    const bool is_val = (j & 1) == 0;                       // even lanes: t = d sdf / d a; odd lanes: abar
+    {   // aux + the chunk table of this program (header words 128..)
+        const float* src = blob + hdr[4];
+        for (int i = threadIdx.x; i < SURF_AUX_FLOATS; i += WG_THREADS) aux[i] = src[i];
+        int* tab = reinterpret_cast<int*>(aux + AUX_FLOATS_MAX);
+        if (threadIdx.x < TAB_INTS) tab[threadIdx.x] = hdr[128 + threadIdx.x];
+        __syncthreads();
+    }
+    const unsigned ntiles = (M + 63u) / 64u;
+    if (blockIdx.x >= ntiles) return;
+    Stream s = make_stream(blob, aux, smem, hdr[7]);
+    s.wrap = (blockIdx.x + gridDim.x) < ntiles;
+    stream_start(s);
+    const EpiCtx ec{0.f, 0.f, is_val};
+    const float* row = aux + SURF_AUX_ROW;
+    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        s.wrap = (tile + gridDim.x) < ntiles;
+        const unsigned m = tile * 64u + wv * 8 + (j >> 1);
+        const bool valid = m < M;
+        GradCtx gc;
+        gc.voff = lane * 16;
+        gc.ws = f2_dump + (size_t)tile * F2_DUMP_PER_TILE + wv * 1024;
+        gc.ws_out = gc.pend_ptr = r2_dump + (size_t)tile * R2_DUMP_PER_TILE + wv * 1024;
+        const float sb = valid ? gbar_sdf[m] : 0.f;
+        Acc A, B;
+#pragma unroll
+        for (int T = 0; T < 16; ++T) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(row + 16 * T + 4 * g);
+            f32x4 hb = {0.f, 0.f, 0.f, 0.f};
+            if (valid && !is_val) hb = *reinterpret_cast<const f32x4*>(gbar_h7 + (size_t)m * 256 + 16 * T + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A.t[T][r] = is_val ? w0[r] : fmaf(sb, w0[r], hb[r]);
+        }
+        Unit x0, x0n, none[1];
+        {
+            const u32x4 dd = *reinterpret_cast<const u32x4*>(gc.ws + (size_t)(64 + 7 * 8) * 8192 + gc.voff);
+            const u32x4 aa = *reinterpret_cast<const u32x4*>(gc.ws + (size_t)(7 * 8) * 8192 + gc.voff);
+            u32x4 hi;
+            x0 = pair_unit(A, 0, dd, aa, is_val, hi);
+            *reinterpret_cast<u32x4*>(gc.ws_out + (size_t)(7 * 8) * 8192 + gc.voff) = hi;
+        }
+        none[0] = x0;
+        d_load2(gc, 7 * 8 + 1, 0);
+        gc.layer = 7;
+        layer<Cfg<11, 11, 8, 0, true, true, false, true>>(A, B, x0, none, x0n, s, aux, ec, gc);
+        A = B;
+        x0 = x0n;
+#pragma nounroll
+        for (int L = 6; L > 0; --L) {
+            gc.layer = L;
+            layer<Cfg<11, 11, 8, 0, true, true, true, true>>(A, B, x0, none, x0n, s, aux, ec, gc);
+            A = B;
+            x0 = x0n;
+        }
+        // A = (t_0 | abar_0): the deltas of layer 0 (unit 0 was built by the last step and is still pending)
+        *reinterpret_cast<u32x4*>(gc.pend_ptr + gc.voff) = gc.dpend;
+#pragma unroll
+        for (int u = 1; u < 8; ++u) {
+            const u32x4 dd = *reinterpret_cast<const u32x4*>(gc.ws + (size_t)(64 + u) * 8192 + gc.voff);
+            const u32x4 aa = *reinterpret_cast<const u32x4*>(gc.ws + (size_t)u * 8192 + gc.voff);
+            u32x4 hi;
+            (void)pair_unit(A, u, dd, aa, is_val, hi);
+            *reinterpret_cast<u32x4*>(gc.ws_out + (size_t)u * 8192 + gc.voff) = hi;
+        }
+    }
+}
+
+// =======================================================================================
 // Radiance net, backward (row a19): cotangents of the layer-7 activation h7 and of the normal input, and the
 // per-layer deltas for the weight-gradient GEMMs, from d loss / d rgb.  Consumes the activations the forward
 // kernel dumped (k_radiance_bf16<VE, true>: f = geometry feature, r0..r3 = relu outputs, bf16 hi parts in unit
@@ -1079,6 +1343,15 @@ int sdf_bf16(const float* blob, const PointSrc& s, float R_bg, float* out, int o
 }
 int sdf_nabla_bf16(const float* blob, const PointSrc& s, float R_bg, float* sdf, float* nabla, float* h7, hipStream_t st) {
     return b16::launch_chain(1, (long long)s.M, b16::k_sdf_nabla_bf16, (s.M + 31u) / 32u, st, blob, s, R_bg, sdf, nabla, h7);
+}
+size_t sdf_fwd2_dump_bytes(long long M) { return (size_t)((M + 63) / 64) * b16::F2_DUMP_PER_TILE; }
+size_t sdf_bwd2_dump_bytes(long long M) { return (size_t)((M + 63) / 64) * b16::R2_DUMP_PER_TILE; }
+int sdf_fwd2_bf16(const float* blob, long long M, const float* pts, const float* dirv, void* dump, hipStream_t st) {
+    return b16::launch_chain(-1, M, b16::k_sdf_fwd2_bf16, (unsigned)((M + 63) / 64), st, blob, (unsigned)M, pts, dirv, (char*)dump);
+}
+int sdf_bwd2_bf16(const float* blob, long long M, const float* gbar_h7, const float* gbar_sdf, void* f2_dump, void* r2_dump, hipStream_t st) {
+    return b16::launch_chain(-1, M, b16::k_sdf_bwd2_bf16, (unsigned)((M + 63) / 64), st, blob, (unsigned)M, gbar_h7, gbar_sdf, (char*)f2_dump,
+                             (char*)r2_dump);
 }
 size_t radiance_dump_bytes(long long M) { return (size_t)((M + 127) / 128) * b16::RAD_DUMP_PER_TILE; }
 int radiance_fwd_dump_bf16(const float* blob, int view_tiles, const PointSrc& s, const float* nabla, const float* h7, float* rgb, void* dump, hipStream_t st) {

@@ -47,6 +47,10 @@ _SIGS = {
     "nerfart_sort_concat": (_i, [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p]),
     "nerfart_volsdf_composite": (_i, [_i, _i, _p, _p, _p, _p, _f, _f, _i] + [_p] * 8),
     "nerfart_volsdf_composite_bwd": (_i, [_i, _i, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p]),
+    "nerfart_sdf_fwd2_dump_bytes": (_ll, [_ll]),
+    "nerfart_sdf_bwd2_dump_bytes": (_ll, [_ll]),
+    "nerfart_sdf_fwd2": (_i, [_p, _p, _p, _ll, _p, _p]),
+    "nerfart_sdf_bwd2": (_i, [_p, _ll, _p, _p, _p, _p, _p]),
     "nerfart_radiance_dump_bytes": (_ll, [_ll]),
     "nerfart_radiance_fwd_dump": (_i, [_p, _i, _p, _p, _ll, _p, _p, _p, _p, _p]),
     "nerfart_radiance_bwd": (_i, [_p, _ll, _p, _p, _p, _p, _p, _p, _p]),
@@ -207,6 +211,25 @@ def volsdf_fine_sample(surf_blob, rays_o, rays_dn, near: float, far: float, R_bg
                                           _dev(lin_table(n_final, dev)), _dev(d_fine), _dev(beta_map), _dev(usage), ws.data_ptr(), ws.numel(),
                                           _stream()), "nerfart_volsdf_fine_sample")
     return d_fine, beta_map, usage
+
+
+def sdf_fwd2(surf_blob, pts, direction):
+    """Forward sweep of the second-order SDF backward: (value, tangent along `direction`) column pairs; returns the dump
+    (uint8) with the activations / tangents (bf16) and softplus' (unorm16) of all 8 layers."""
+    M = pts.shape[0]
+    dump = torch.empty(int(lib.nerfart_sdf_fwd2_dump_bytes(M)), dtype=torch.uint8, device=pts.device)
+    _check(lib.nerfart_sdf_fwd2(_dev(surf_blob), _dev(pts, name="pts"), _dev(direction, name="direction"), M, dump.data_ptr(), _stream()),
+           "nerfart_sdf_fwd2")
+    return dump
+
+
+def sdf_bwd2(surf_blob, gbar_h7, gbar_sdf, f2_dump):
+    """Reverse sweep: cotangents of h7 [M,256] and sdf [M] -> dump (uint8) of 65535 * (t_l d_l | zbar_l), bf16."""
+    M = gbar_sdf.shape[0]
+    dump = torch.empty(int(lib.nerfart_sdf_bwd2_dump_bytes(M)), dtype=torch.uint8, device=gbar_sdf.device)
+    _check(lib.nerfart_sdf_bwd2(_dev(surf_blob), M, _dev(gbar_h7, name="gbar_h7"), _dev(gbar_sdf, name="gbar_sdf"), f2_dump.data_ptr(),
+                                dump.data_ptr(), _stream()), "nerfart_sdf_bwd2")
+    return dump
 
 
 def radiance_fwd_dump(rad_blob, view_tiles: int, pts, view, nabla, h7):

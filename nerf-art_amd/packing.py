@@ -305,14 +305,14 @@ class PackPlanBF16(PackPlan):
     first (used to fold a row vector into a transposed matrix); chunk_scale: optional per-chunk constant.
     nc_main: number of leading chunks that form the forward program (header word 2); header word 6 = all chunks."""
 
-    def __init__(self, prog, flat, chunk_indices, aux, chunk_mul=None, chunk_scale=None, nc_main=None):
+    def __init__(self, prog, flat, chunk_indices, aux, chunk_mul=None, chunk_scale=None, nc_main=None, nc_cycle=None, table2=None):
         self.prog, self.flat = prog, flat
         offs = [HDR_INTS]
         for c in chunk_indices:
             offs.append(offs[-1] + (len(c) // 512) * TS_FLOATS)
-        self.nc_all = len(chunk_indices)
+        self.nc_all = len(chunk_indices) if nc_cycle is None else nc_cycle      # header word 6: chunks of the second program
         self.nc = self.nc_all if nc_main is None else nc_main
-        assert self.nc_all + 1 <= 128
+        assert len(chunk_indices) + 1 <= 112
         self.aux_off = offs[-1]
         self.cindex = np.concatenate(chunk_indices)
         self.cmul = None
@@ -330,7 +330,12 @@ class PackPlanBF16(PackPlan):
         self.pad = self.total - (self.aux_off + len(aux))
         hdr = np.zeros(HDR_INTS, dtype=np.int32)
         hdr[0], hdr[1], hdr[2], hdr[3], hdr[4], hdr[5], hdr[6] = MAGIC, prog, self.nc, self.total, self.aux_off, len(aux), self.nc_all
-        hdr[HDR_OFFS: HDR_OFFS + self.nc_all + 1] = offs
+        hdr[HDR_OFFS: HDR_OFFS + len(offs)] = offs
+        # optional third program: an explicit list of chunk indices (header word 7 = its length, offsets at words 128..)
+        if table2 is not None:
+            assert len(table2) <= 120
+            hdr[7] = len(table2)
+            hdr[128: 128 + len(table2)] = [offs[c] for c in table2]
         self.header = hdr
         self._index_t = {}
 
@@ -459,7 +464,19 @@ def surface_plan_bf16(W: int = 256, D: int = 8, skips=(4,), multires: int = 6, W
     aux.append(flat.vec_index(f"b{D}", _pad(np.array([0]), 4)))
     aux = np.concatenate(aux)
     assert len(aux) == SURF_AUX_FLOATS
-    plan = PackPlanBF16(PROG_SURFACE_BF16, flat, chunks, aux, chunk_mul=mul, chunk_scale=scl, nc_main=nc_fwd)
+    # ---- second-order program (k_sdf_bwd2_bf16, the fine-tune step's SDF backward): the same transposed layers, but
+    # layer 7 WITHOUT the folded sdf row (its cotangent is an input) and with the 1/65535 of the others
+    nc_grad = len(chunks)
+
+    def kf7(ks, g, e):
+        return unit_feature_hidden(ks, g, e)
+    for c0 in range(0, 8, CHUNK_KS):
+        chunks.append(np.concatenate([_kstep_index_T(flat, f"w{D - 1}", ks, kf7, nat) for ks in range(c0, c0 + CHUNK_KS)]))
+        mul.append(None)
+        scl.append(1.0 / D_UNORM)
+    table2 = list(range(nc_grad, nc_grad + 4)) + list(range(nc_fwd + 4, nc_fwd + 4 + 24))      # B7', then B6..B1
+    plan = PackPlanBF16(PROG_SURFACE_BF16, flat, chunks, aux, chunk_mul=mul, chunk_scale=scl, nc_main=nc_fwd, nc_cycle=nc_grad,
+                        table2=table2)
     # cat[h, enc] / sqrt(2) (base.py:250) is applied to the skip layer's weights instead of its inputs
     plan.scale = {f"w{l}": 1.0 / float(np.sqrt(2.0)) for l in skips}
     return plan

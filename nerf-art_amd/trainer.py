@@ -22,13 +22,16 @@ from .nets import NeuS, VolSDF
 
 
 class Trainer(nn.Module):
-    def __init__(self, model, w_eikonal: float = 0.1, use_eikonal: bool = True, pass2_rays: int = 1200):
+    def __init__(self, model, w_eikonal: float = 0.1, use_eikonal: bool = True, pass2_rays: int = 1200, native: bool = None):
         super().__init__()
         if not isinstance(model, (VolSDF, NeuS)):
             raise TypeError("Trainer expects a nerfart_amd VolSDF or NeuS model")
         self.model = model
         self.is_neus = isinstance(model, NeuS)
         self.w_eikonal, self.use_eikonal, self.pass2_rays = w_eikonal, use_eikonal, pass2_rays
+        # native: pass 2 entirely on the hand-written kernels + GEMMs (VolSDF, split-bf16 blobs); otherwise autograd over
+        # the per-sample networks with the native compositing / radiance kernels where available
+        self.native = (not self.is_neus and model.precision == "bf16x3") if native is None else native
         if self.is_neus:                       # neus.py:455-456: only the SDF net (and ln_s) is fine-tuned
             for p in model.radiance_net.parameters():
                 p.requires_grad_(False)
@@ -75,6 +78,11 @@ class Trainer(nn.Module):
             dn = F.normalize(d_raw, dim=-1)
             with torch.no_grad():
                 depths = self._samples(o, dn, d_raw, render_kwargs)
+            if self.native:
+                eik_sum += autodiff.volsdf_backward_samples_native(self.model, o, dn, depths, g_all[i:i + self.pass2_rays], self.w_eikonal,
+                                                                   self.use_eikonal, render_kwargs.get("white_bkgd", False))
+                n += 1
+                continue
             fn = autodiff.neus_render_samples if self.is_neus else autodiff.volsdf_render_samples
             out = fn(self.model, o, dn, depths, white_bkgd=render_kwargs.get("white_bkgd", False))
             if self.use_eikonal:

@@ -89,10 +89,10 @@ def _blobs_bf16(fw):
 
 def test_bf16_blob_header():
     _, surf, rad, _ = _blobs_bf16("VolSDF")
-    for blob, nc, nc_all in ((surf, 30, 59), (rad, 21, 42)):
+    for blob, nc, nc_all, n_chunks in ((surf, 30, 59, 63), (rad, 21, 42, 42)):
         hdr = blob[:512].view(np.int32)
         assert hdr[0] == packing.MAGIC and hdr[2] == nc and hdr[6] == nc_all and hdr[3] == blob.size
-        offs = hdr[16:16 + nc_all + 1]
+        offs = hdr[16:16 + n_chunks + 1]
         # 1 or 2 k-steps of 32 KiB; the reverse programs hold one 48 KiB (8 k-steps x 3 tiles) / 16 KiB (x 1 tile) chunk
         assert set(np.diff(offs).tolist()) <= {4096, 8192, 12288, 16384} and offs[-1] == hdr[4]
         assert offs[-2] + 16384 <= blob.size          # the stream copies 64 KiB per chunk
