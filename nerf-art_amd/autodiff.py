@@ -70,16 +70,23 @@ def radiance_forward(rad, x, view_dirs, normals, feat):
 
 # ---- radiance net on the hand-written kernels (forward with activation dumps, backward chain, GEMM operands) ----
 _RAD_DUMP_PER_TILE = 5 * 8 * 8 * 1024
-_UNIT_PERM = None
+_PERMS = {}        # device -> (perm, inv) on that device: a host -> device copy per call would synchronise the stream
 
 
 def _unit_perm(device):
     """column c = (unit * 4 + lane group) * 8 + e of a dumped matrix -> natural feature index."""
-    global _UNIT_PERM
-    if _UNIT_PERM is None:
+    return _perms(device)[0]
+
+
+def _perms(device):
+    key = str(device)
+    if key not in _PERMS:
         from .packing import unit_feature_hidden
-        _UNIT_PERM = torch.tensor([unit_feature_hidden(u, g, e) for u in range(8) for g in range(4) for e in range(8)])
-    return _UNIT_PERM.to(device)
+        perm = torch.tensor([unit_feature_hidden(u, g, e) for u in range(8) for g in range(4) for e in range(8)])
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(256)
+        _PERMS[key] = (perm.to(device), inv.to(device))
+    return _PERMS[key]
 
 
 def _dump_matrix(dump: torch.Tensor, slot: int, M: int) -> torch.Tensor:
@@ -90,10 +97,30 @@ def _dump_matrix(dump: torch.Tensor, slot: int, M: int) -> torch.Tensor:
 
 
 def _mmT(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """a^T b with bf16 operands and an fp32 result: the weight-gradient GEMMs (plain library GEMMs, hipBLASLt)."""
+    """a^T b with bf16 operands and an fp32 result: the weight-gradient GEMMs (plain library GEMMs, hipBLASLt).
+    The reduction runs over ~10^5..10^6 rows into a <= 256 x 256 result - 16 output tiles would occupy 16 of 256 CUs - so
+    the rows are split into up to 64 batches (split-K as a batched GEMM) and the partial results summed in fp32."""
     a = a if a.dtype == torch.bfloat16 else a.to(torch.bfloat16)
     b = b if b.dtype == torch.bfloat16 else b.to(torch.bfloat16)
-    return torch.mm(a.t(), b, out_dtype=torch.float32)
+    n = a.shape[0]
+    s = 64
+    while s > 1 and (n % s or n // s < 1024):
+        s //= 2
+    if s == 1 or not (a.is_contiguous() and b.is_contiguous()):
+        return torch.mm(a.t(), b, out_dtype=torch.float32)
+    return torch.bmm(a.view(s, n // s, a.shape[1]).transpose(1, 2), b.view(s, n // s, b.shape[1]), out_dtype=torch.float32).sum(0)
+
+
+def _bmmT(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """[L, n, p]^T [L, n, q] -> [L, p, q] fp32 (bf16 operands), the row reduction split into up to 64 batches per matrix:
+    all same-shaped layers of a network in ONE library call (each call costs ~0.8 ms of host time in hipBLASLt)."""
+    L, n, p_ = a.shape
+    q = b.shape[2]
+    s = 64
+    while s > 1 and (n % s or n // s < 1024):
+        s //= 2
+    out = torch.bmm(a.reshape(L * s, n // s, p_).transpose(1, 2), b.reshape(L * s, n // s, q), out_dtype=torch.float32)
+    return out.view(L, s, p_, q).sum(1)
 
 
 def _colsum(a: torch.Tensor) -> torch.Tensor:
@@ -101,43 +128,80 @@ def _colsum(a: torch.Tensor) -> torch.Tensor:
 
 
 def _inv_perm(device):
-    perm = _unit_perm(device)
-    inv = torch.empty_like(perm)
-    inv[perm] = torch.arange(256, device=device)
-    return inv
+    return _perms(device)[1]
+
+
+def _unperm(w: torch.Tensor, inv: torch.Tensor, rows: bool = True, cols: bool = True) -> torch.Tensor:
+    """A small GEMM result indexed by unit-order features -> natural feature order."""
+    if rows:
+        w = w[inv]
+    if cols:
+        w = w[:, inv]
+    return w
 
 
 def radiance_weight_grads(model, x, v, n, h7, rgb, g_rgb, dump, bdump):
     """Gradients of the FOLDED radiance weights / biases and of rows 1.. of the last SDF layer: plain GEMMs of the deltas
-    (k_radiance_bwd_bf16's dump) with the activations (k_radiance_bf16<dump>'s)."""
+    (k_radiance_bwd_bf16's dump) with the activations (k_radiance_bf16<dump>'s).  The big operands stay in the kernels'
+    unit order; the 256 x 256 results are re-indexed."""
     M = x.shape[0]
     inv = _inv_perm(x.device)
-    nat = lambda m: m[:, inv]                                                   # unit order -> natural feature order
-    acts = [nat(_dump_matrix(dump, s, M)) for s in range(5)]                     # f, r0, r1, r2, r3
-    deltas = [nat(_dump_matrix(bdump, s, M)) for s in range(5)]                  # d3, d2, d1, d0, g_f
+    acts = _dump_all(dump, M)                                               # f, r0, r1, r2, r3   [5, M_pad, 256]
+    deltas = _dump_all(bdump, M)                                            # d3, d2, d1, d0, g_f (0 for the padded points)
+    Mp = acts.shape[1]
+    pad = lambda t: t if Mp == M else torch.cat([t, torch.zeros(Mp - M, t.shape[1], device=t.device, dtype=t.dtype)], dim=0)
     d4 = g_rgb * rgb * (1.0 - rgb)
     rad = model.radiance_net
     ex = torch.cat([embed(x, rad.embed_multires), embed(v, rad.embed_multires_view), n], dim=-1)
+    ww = _bmmT(deltas[0:4], acts[0:4].flip(0))                               # (d3, r2), (d2, r1), (d1, r0), (d0, f)
+    cs = deltas.float().sum(1)                                              # [5, 256] column sums
     gw, gb = [None] * 5, [None] * 5
-    gw[4], gb[4] = _mmT(d4, acts[4]), d4.sum(0)
-    gw[3], gb[3] = _mmT(deltas[0], acts[3]), _colsum(deltas[0])
-    gw[2], gb[2] = _mmT(deltas[1], acts[2]), _colsum(deltas[1])
-    gw[1], gb[1] = _mmT(deltas[2], acts[1]), _colsum(deltas[2])
-    gw[0], gb[0] = torch.cat([_mmT(deltas[3], ex), _mmT(deltas[3], acts[0])], dim=1), _colsum(deltas[3])
-    g_w8 = torch.cat([torch.zeros(1, 256, device=x.device), _mmT(deltas[4], h7)], dim=0)
-    g_b8 = torch.cat([torch.zeros(1, device=x.device), _colsum(deltas[4])])
+    gw[4], gb[4] = _unperm(_mmT(pad(d4), acts[4]), inv, rows=False), d4.sum(0)
+    for k, l in enumerate((3, 2, 1)):
+        gw[l], gb[l] = _unperm(ww[k], inv), cs[k][inv]
+    gw[0] = torch.cat([_unperm(_mmT(deltas[3], pad(ex)), inv, cols=False), _unperm(ww[3], inv)], dim=1)
+    gb[0] = cs[3][inv]
+    g_w8 = torch.cat([torch.zeros(1, 256, device=x.device), _unperm(_mmT(deltas[4], pad(h7)), inv, cols=False)], dim=0)
+    g_b8 = torch.cat([torch.zeros(1, device=x.device), cs[4][inv]])
     return gw, gb, g_w8, g_b8
 
 
 _F2_SLOTS, _R2_SLOTS = 16, 8
 
 
-def _pair_matrix(dump: torch.Tensor, slots: int, slot: int, M: int) -> torch.Tensor:
+def _pair_all(dump: torch.Tensor, slots: int, nslots: int, M: int, flip: bool = False) -> torch.Tensor:
+    """[nslots, 2 M, 256] bf16: for every one of the first `nslots` dumped slots of a column-pair kernel the even-lane column
+    stacked on the odd-lane column (flip: odd on even); features in unit order.  Two copy kernels in total."""
+    T = dump.numel() // (slots * 8 * 8 * 1024)
+    if M != T * 64:
+        raise ValueError("the GEMM glue expects a multiple of 64 points per patch")
+    v = dump.view(torch.bfloat16).view(T, slots, 8, 8, 4, 8, 2, 8)[:, :nslots]   # tile, slot, unit, wave, g, point, column, e
+    v = v.permute(6, 1, 0, 3, 5, 2, 4, 7)                                        # column, slot, tile, wave, point, unit, g, e
+    out = torch.empty(nslots, 2, M, 256, dtype=torch.bfloat16, device=dump.device)
+    o = out.view(nslots, 2, T, 8, 8, 8, 4, 8)
+    o[:, 0].copy_(v[1 if flip else 0])
+    o[:, 1].copy_(v[0 if flip else 1])
+    return out.view(nslots, 2 * M, 256)
+
+
+def _dump_all(dump: torch.Tensor, M: int) -> torch.Tensor:
+    """[5, M_pad, 256] bf16 of the radiance kernels' dumps (unit order), one copy kernel."""
+    T = dump.numel() // _RAD_DUMP_PER_TILE
+    v = dump.view(torch.bfloat16).view(T, 5, 8, 8, 4, 16, 8).permute(1, 0, 3, 5, 2, 4, 6)   # slot, tile, wave, j, unit, g, e
+    return v.reshape(5, T * 128, 256)
+
+
+def _pair_matrix(dump: torch.Tensor, slots: int, slot: int, M: int, flip: bool = False) -> torch.Tensor:
     """[2, M, 256] bf16 of one dumped slot of the column-pair kernels: [0] = even-lane column, [1] = odd-lane column
-    (features in unit order)."""
+    (flip: the other way round); features in unit order."""
     T = dump.numel() // (slots * 8 * 8 * 1024)
     v = dump.view(torch.bfloat16).view(T, slots, 8, 8, 4, 8, 2, 8)[:, slot]      # tile, unit, wave, g, point, column, e
-    return v.permute(5, 0, 2, 4, 1, 3, 6).reshape(2, T * 64, 256)[:, :M]
+    v = v.permute(5, 0, 2, 4, 1, 3, 6)                                           # column, tile, wave, point, unit, g, e
+    out = torch.empty(2, T * 64, 256, dtype=torch.bfloat16, device=dump.device)
+    o = out.view(2, T, 8, 8, 8, 4, 8)
+    o[0].copy_(v[1 if flip else 0])
+    o[1].copy_(v[0 if flip else 1])
+    return out[:, :M]
 
 
 def embed_tangent(x, direction, multires: int):
@@ -152,7 +216,10 @@ def embed_tangent(x, direction, multires: int):
 def surface_weight_grads(model, pts, sbar, hbar7, nbar):
     """Gradients of the FOLDED SDF-net weights / biases for the cotangents (sbar of sdf [M], hbar7 of the layer-7
     activation [M,256], nbar of grad_x sdf [M,3]) on k_sdf_fwd2_bf16 / k_sdf_bwd2_bf16 + GEMMs.  Returns (dW[0..8], db[0..8]);
-    layer 8 holds the sdf row only (rows 1.. belong to radiance_weight_grads)."""
+    layer 8 holds the sdf row only (rows 1.. belong to radiance_weight_grads).
+
+    dW_l = zbar_l^T a_{l-1} + (t_l d_l)^T adot_{l-1} is ONE GEMM over the 2 M stacked rows of the two dumps (the reverse
+    sweep's columns flipped); the big operands stay in unit order."""
     from . import hip
     surf = model.implicit_surface
     surf_blob, _ = model.packed()
@@ -161,28 +228,30 @@ def surface_weight_grads(model, pts, sbar, hbar7, nbar):
     f2 = hip.sdf_fwd2(surf_blob, pts, nbar)
     r2 = hip.sdf_bwd2(surf_blob, hbar7.contiguous(), sbar.contiguous(), f2)
     inv = _inv_perm(pts.device)
-    FA = [_pair_matrix(f2, _F2_SLOTS, l, M)[:, :, inv] for l in range(8)]           # [0] = a_l, [1] = adot_l  (bf16)
-    RZ = [_pair_matrix(r2, _R2_SLOTS, l, M)[:, :, inv] for l in range(8)]           # 65535 * ([0] = t_l d_l, [1] = zbar_l)
     bf = torch.bfloat16
-    e = embed(pts, surf.embed_multires).to(bf)
-    ed = embed_tangent(pts, nbar, surf.embed_multires).to(bf)
+    e2 = torch.cat([embed(pts, surf.embed_multires), embed_tangent(pts, nbar, surf.embed_multires)], dim=0).to(bf)    # [e; edot]
     rs2 = 1.0 / np.sqrt(2.0)
     sc = 1.0 / 65535.0
+    RZ = _pair_all(r2, _R2_SLOTS, 8, M, flip=True)                      # [8, 2M, 256]: 65535 * [zbar_l; t_l d_l]
+    FA = _pair_all(f2, _F2_SLOTS, 8, M)                                 # [8, 2M, 256]: [a_l; adot_l]
+    ww = _bmmT(RZ[1:8], FA[0:7])                                        # layers 1..7 against the previous layer's (a | adot)
+    we = _bmmT(torch.stack([RZ[0], RZ[4]]), e2[None].expand(2, -1, -1))    # layers 0 and 4 against the encoding
+    cs = RZ[:, :M].float().sum(1)                                       # [8, 256]: sum_p zbar_l
     dW, db = [None] * 9, [None] * 9
     for l in range(8):
-        gz, zb = RZ[l][0], RZ[l][1]
         out_dim = surf.surface_fc_layers[l].out_features
         if l == 0:
-            w = _mmT(zb, e) + _mmT(gz, ed)
+            w = _unperm(we[0], inv, cols=False)
         elif l in surf.skips:
-            hw = surf.W - e.shape[1]
-            w = torch.cat([_mmT(zb, FA[l - 1][0][:, :hw]) + _mmT(gz, FA[l - 1][1][:, :hw]), _mmT(zb, e) + _mmT(gz, ed)], dim=1) * rs2
+            hw = surf.W - e2.shape[1]
+            w = torch.cat([_unperm(ww[l - 1], inv)[:, :hw], _unperm(we[1], inv, cols=False)], dim=1) * rs2
         else:
-            w = _mmT(zb, FA[l - 1][0]) + _mmT(gz, FA[l - 1][1])
+            w = _unperm(ww[l - 1], inv)
         dW[l] = (w * sc)[:out_dim]
-        db[l] = (_colsum(zb) * sc)[:out_dim]
+        db[l] = (cs[l][inv] * sc)[:out_dim]
+    a7, ad7 = FA[7][:M], FA[7][M:]
     w8 = torch.zeros(surf.surface_fc_layers[8].out_features, 256, device=pts.device)
-    w8[0] = _mmT(FA[7][0], sbar[:, None])[:, 0] + _colsum(FA[7][1])
+    w8[0] = (_mmT(a7, sbar[:, None])[:, 0] + _colsum(ad7))[inv]
     b8 = torch.zeros(w8.shape[0], device=pts.device)
     b8[0] = sbar.sum()
     dW[8], db[8] = w8, b8
@@ -198,9 +267,10 @@ def accumulate_folded_grads(layers, dW, db):
             l.bias.grad = g.clone() if l.bias.grad is None else l.bias.grad + g
 
 
-def volsdf_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikonal=0.1, use_eikonal=True, white_bkgd=False):
+def volsdf_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikonal=0.1, use_eikonal=True, white_bkgd=False, ab=None):
     """Pass 2 of the fine-tune step for one patch, entirely on the hand-written kernels + GEMMs: accumulates into .grad what
-    rgb.backward(g_rgb) and (w_eikonal * MSE(|nabla|, 1)).backward() accumulate (volsdf.py:759-770).  Returns the eikonal loss."""
+    rgb.backward(g_rgb) and (w_eikonal * MSE(|nabla|, 1)).backward() accumulate (volsdf.py:759-770).  Returns the eikonal loss
+    (a 0-d tensor: no host synchronisation in here; `ab` = (alpha, beta) as Python floats if the caller already has them)."""
     from . import hip
     R, P = d_all.shape
     pts = (rays_o[:, None, :] + rays_dn[:, None, :] * d_all[:, :, None]).reshape(-1, 3).contiguous()
@@ -210,9 +280,11 @@ def volsdf_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikon
     with torch.no_grad():
         sdf, nab, h7 = hip.sdf_nabla_fwd(surf_blob, pts, Rbg, precision=model.precision_id)
         rgb_pt, dump = hip.radiance_fwd_dump(rad_blob, model.view_tiles, pts, v, nab, h7)
-        alpha, beta = model.forward_ab()
-        g_sdf, g_rad, g_ab = hip.volsdf_composite_bwd(d_all.contiguous(), sdf.reshape(R, P), rgb_pt.reshape(R, P, 3), float(alpha),
-                                                      float(beta), g_rgb.contiguous(), white_bkgd)
+        if ab is None:
+            alpha, beta = model.forward_ab()
+            ab = (float(alpha), float(beta))
+        g_sdf, g_rad, g_ab = hip.volsdf_composite_bwd(d_all.contiguous(), sdf.reshape(R, P), rgb_pt.reshape(R, P, 3), ab[0], ab[1],
+                                                      g_rgb.contiguous(), white_bkgd)
         clamped = sdf >= (Rbg - pts.norm(dim=-1)) - 1e-6            # sdf = min(net, R - |x|): no gradient to the net where clamped
         sbar = torch.where(clamped, torch.zeros_like(sdf), g_sdf.reshape(-1))
         g_h7, g_n, bdump = hip.radiance_bwd(rad_blob, rgb_pt, g_rad.reshape(-1, 3), dump)
@@ -231,7 +303,7 @@ def volsdf_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikon
         accumulate_folded_grads(list(model.radiance_net.layers), gw, gb)
     a, b = model.forward_ab()
     torch.autograd.backward([a, b], [g_ab[0:1].reshape(a.shape), g_ab[1:2].reshape(b.shape)])
-    return float(eik)
+    return eik
 
 
 class RadianceNetFn(torch.autograd.Function):

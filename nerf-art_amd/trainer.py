@@ -73,14 +73,19 @@ class Trainer(nn.Module):
         d_all_ = rays_d.reshape(-1, 3).float().contiguous()
         g_all = gradient.reshape(-1, 3)
         eik_sum, n = 0.0, 0
+        ab = None
+        if self.native:
+            alpha, beta = self.model.forward_ab()
+            ab = (float(alpha.detach()), float(beta.detach()))
         for i in range(0, o_all.shape[0], self.pass2_rays):
             o, d_raw = o_all[i:i + self.pass2_rays], d_all_[i:i + self.pass2_rays]
             dn = F.normalize(d_raw, dim=-1)
             with torch.no_grad():
                 depths = self._samples(o, dn, d_raw, render_kwargs)
             if self.native:
-                eik_sum += autodiff.volsdf_backward_samples_native(self.model, o, dn, depths, g_all[i:i + self.pass2_rays], self.w_eikonal,
-                                                                   self.use_eikonal, render_kwargs.get("white_bkgd", False))
+                eik_sum = eik_sum + autodiff.volsdf_backward_samples_native(self.model, o, dn, depths, g_all[i:i + self.pass2_rays],
+                                                                            self.w_eikonal, self.use_eikonal,
+                                                                            render_kwargs.get("white_bkgd", False), ab=ab)
                 n += 1
                 continue
             fn = autodiff.neus_render_samples if self.is_neus else autodiff.volsdf_render_samples
@@ -96,7 +101,7 @@ class Trainer(nn.Module):
                 out["rgb"].backward(g_all[i:i + self.pass2_rays])
             n += 1
             del out
-        return eik_sum / max(n, 1)
+        return float(eik_sum) / max(n, 1)
 
     # ---- one fine-tune step ---------------------------------------------------------------------------
     def finetune_step(self, render_fn, rays_o, rays_d, target_rgb, H: int, style_loss, optimizer=None, tile: int = 2048,
