@@ -170,11 +170,12 @@ _F2_SLOTS, _R2_SLOTS = 16, 8
 
 
 def _pair_all(dump: torch.Tensor, slots: int, nslots: int, M: int, flip: bool = False) -> torch.Tensor:
-    """[nslots, 2 M, 256] bf16: for every one of the first `nslots` dumped slots of a column-pair kernel the even-lane column
-    stacked on the odd-lane column (flip: odd on even); features in unit order.  Two copy kernels in total."""
+    """[nslots, 2 Mp, 256] bf16 (Mp = M rounded up to the kernels' 64-point tiles; the padded points carry zero tangents
+    and zero cotangents, so their rows add nothing to any GEMM): for every one of the first `nslots` dumped slots of a
+    column-pair kernel the even-lane column stacked on the odd-lane column (flip: odd on even); features in unit order.
+    Two copy kernels in total."""
     T = dump.numel() // (slots * 8 * 8 * 1024)
-    if M != T * 64:
-        raise ValueError("the GEMM glue expects a multiple of 64 points per patch")
+    M = T * 64
     v = dump.view(torch.bfloat16).view(T, slots, 8, 8, 4, 8, 2, 8)[:, :nslots]   # tile, slot, unit, wave, g, point, column, e
     v = v.permute(6, 1, 0, 3, 5, 2, 4, 7)                                        # column, slot, tile, wave, point, unit, g, e
     out = torch.empty(nslots, 2, M, 256, dtype=torch.bfloat16, device=dump.device)
@@ -229,11 +230,15 @@ def surface_weight_grads(model, pts, sbar, hbar7, nbar):
     r2 = hip.sdf_bwd2(surf_blob, hbar7.contiguous(), sbar.contiguous(), f2)
     inv = _inv_perm(pts.device)
     bf = torch.bfloat16
-    e2 = torch.cat([embed(pts, surf.embed_multires), embed_tangent(pts, nbar, surf.embed_multires)], dim=0).to(bf)    # [e; edot]
+    Mp = (M + 63) // 64 * 64                                            # the kernels' tiles; padded rows are zero where it matters
+    padr = lambda t: t if Mp == M else torch.cat([t, torch.zeros(Mp - M, *t.shape[1:], device=t.device, dtype=t.dtype)], dim=0)
+    e2 = torch.cat([padr(embed(pts, surf.embed_multires)), padr(embed_tangent(pts, nbar, surf.embed_multires))], dim=0).to(bf)    # [e; edot]
     rs2 = 1.0 / np.sqrt(2.0)
     sc = 1.0 / 65535.0
-    RZ = _pair_all(r2, _R2_SLOTS, 8, M, flip=True)                      # [8, 2M, 256]: 65535 * [zbar_l; t_l d_l]
-    FA = _pair_all(f2, _F2_SLOTS, 8, M)                                 # [8, 2M, 256]: [a_l; adot_l]
+    RZ = _pair_all(r2, _R2_SLOTS, 8, M, flip=True)                      # [8, 2 Mp, 256]: 65535 * [zbar_l; t_l d_l]
+    FA = _pair_all(f2, _F2_SLOTS, 8, M)                                 # [8, 2 Mp, 256]: [a_l; adot_l]
+    sbar = padr(sbar)
+    M = Mp
     ww = _bmmT(RZ[1:8], FA[0:7])                                        # layers 1..7 against the previous layer's (a | adot)
     we = _bmmT(torch.stack([RZ[0], RZ[4]]), e2[None].expand(2, -1, -1))    # layers 0 and 4 against the encoding
     cs = RZ[:, :M].float().sum(1)                                       # [8, 256]: sum_p zbar_l

@@ -182,3 +182,23 @@ def test_native_pass2_matches_autograd_and_G11(golden):
     for name, ref in res[False].items():
         rel = float((res[True][name] - ref).norm() / (ref.norm() + 1e-12))
         assert rel < 3e-2, (name, rel)
+
+
+def test_native_pass2_ragged_patch_sizes():
+    """Patch sizes that are not multiples of the kernels' 64- / 128-point tiles (13 rays x 96 points)."""
+    from nerfart_amd import scene, rend_util
+    from nerfart_amd.trainer import Trainer
+    model, rk, render_fn = scene.build_model("VolSDF", seed=0, beta=0.01, device=DEV, precision="bf16x3")
+    H, W = 7, 5
+    c2w, K = scene.camera(H, W)
+    o, d, _ = rend_util.get_rays(c2w[None].to(DEV), K[None].to(DEV), H, W)
+    g = torch.rand(H * W, 3, generator=torch.Generator().manual_seed(3)).to(DEV) * 1e-2
+    kw = dict(rk); kw["N_samples"] = 32                         # 32 + 64 = 96 points per ray: 13 rays = 19.5 tiles of 64
+    res = {}
+    for native in (False, True):
+        model.zero_grad()
+        Trainer(model, pass2_rays=13, native=native).backward_patches(o[0], d[0], g, **kw)
+        res[native] = {n: p.grad.clone() for n, p in model.named_parameters()}
+    for name, ref in res[False].items():
+        rel = float((res[True][name] - ref).norm() / (ref.norm() + 1e-12))
+        assert rel < 3e-2, (name, rel)
