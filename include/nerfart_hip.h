@@ -150,6 +150,11 @@ int nerfart_volsdf_composite_bwd(int n_rays, int P, const float* d_all, const fl
                                  float beta, int white_bkgd, const float* g_rgb, float* g_sdf, float* g_rad,
                                  float* g_alpha_beta, void* stream);
 
+/* The same for NeuS (neus.py:29-78, :373-395): sdf [R,P] at the samples, radiance [R,P-1,3] at the mid-points, s =
+ * exp(ln_s * speed_factor) -> g_sdf [R,P], g_rad_mid [R,P-1,3], g_s[0] += d loss / d s. */
+int nerfart_neus_composite_bwd(int n_rays, int P, const float* sdf, const float* rad_mid, float s, int white_bkgd, const float* g_rgb,
+                               float* g_sdf, float* g_rad_mid, float* g_s, void* stream);
+
 /* ---- B1: VolSDF volume_render (volsdf.py:389-615) for one chunk of rays (rays_d un-normalised). */
 long long nerfart_volsdf_render_workspace_bytes(int n_rays, int n_samples, int n_importance, int max_upsample_steps,
                                                 int k3_rays_chunk);

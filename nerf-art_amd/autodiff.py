@@ -311,6 +311,48 @@ def volsdf_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikon
     return eik
 
 
+def neus_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikonal=0.1, use_eikonal=True, white_bkgd=False, s_val=None):
+    """Pass 2 for one NeuS patch on the hand-written kernels + GEMMs (neus.py:310-395, :520-576): SDF + nablas at the P
+    samples (alpha, eikonal), SDF + nablas + radiance at the P-1 mid-points; the radiance net is frozen (neus.py:455-456).
+    Returns the eikonal loss (0-d tensor)."""
+    from . import hip
+    R, P = d_all.shape
+    pts = (rays_o[:, None, :] + rays_dn[:, None, :] * d_all[:, :, None]).reshape(-1, 3).contiguous()
+    d_mid = 0.5 * (d_all[..., 1:] + d_all[..., :-1])
+    pts_m = (rays_o[:, None, :] + rays_dn[:, None, :] * d_mid[:, :, None]).reshape(-1, 3).contiguous()
+    v_m = rays_dn[:, None, :].expand(R, P - 1, 3).reshape(-1, 3).contiguous()
+    surf_blob, rad_blob = model.packed()
+    with torch.no_grad():
+        if s_val is None:
+            s_val = float(model.forward_s())
+        sdf, nab, _ = hip.sdf_nabla_fwd(surf_blob, pts, 0.0, want_h7=False, precision=model.precision_id)
+        _, nab_m, h7_m = hip.sdf_nabla_fwd(surf_blob, pts_m, 0.0, precision=model.precision_id)
+        rgb_m, dump = hip.radiance_fwd_dump(rad_blob, model.view_tiles, pts_m, v_m, nab_m, h7_m)
+        g_sdf, g_rad, g_s = hip.neus_composite_bwd(sdf.reshape(R, P), rgb_m.reshape(R, P - 1, 3), s_val, g_rgb.contiguous(), white_bkgd)
+        g_h7, g_n, bdump = hip.radiance_bwd(rad_blob, rgb_m, g_rad.reshape(-1, 3), dump)
+        nbar = torch.zeros_like(nab)
+        eik = torch.zeros((), device=pts.device)
+        if use_eikonal:
+            nn_ = nab.norm(dim=-1)
+            eik = w_eikonal * ((nn_ - 1.0) ** 2).mean()
+            nbar = (w_eikonal * 2.0 / nn_.numel()) * ((nn_ - 1.0) / nn_)[:, None] * nab
+        # samples: cotangents of sdf (alpha) and of the nablas (eikonal); mid-points: of h7 and of the normal (radiance)
+        dW, db = surface_weight_grads(model, pts, g_sdf.reshape(-1), torch.zeros(pts.shape[0], 256, device=pts.device), nbar)
+        dW2, db2 = surface_weight_grads(model, pts_m, torch.zeros(pts_m.shape[0], device=pts.device), g_h7, g_n)
+        dW = [a + b for a, b in zip(dW, dW2)]
+        db = [a + b for a, b in zip(db, db2)]
+        trainable_rad = any(p.requires_grad for p in model.radiance_net.parameters())
+        gw, gb, g_w8, g_b8 = radiance_weight_grads(model, pts_m, v_m, nab_m, h7_m, rgb_m, g_rad.reshape(-1, 3), dump, bdump)
+        dW[8] = dW[8] + g_w8                                      # the geometry-feature rows of the last SDF layer are trainable
+        db[8] = db[8] + g_b8
+    accumulate_folded_grads(list(model.implicit_surface.surface_fc_layers), dW, db)
+    if trainable_rad:
+        accumulate_folded_grads(list(model.radiance_net.layers), gw, gb)
+    s_t = model.forward_s()
+    torch.autograd.backward([s_t], [g_s.reshape(s_t.shape)])
+    return eik
+
+
 class RadianceNetFn(torch.autograd.Function):
     """rgb = RadianceNet(x, v, n, W8[1:] h7 + b8[1:]) on k_radiance_bf16 / k_radiance_bwd_bf16.  The weight inputs are the
     FOLDED matrices (autograd carries their gradients on to weight_g / weight_v); their gradients are plain GEMMs of

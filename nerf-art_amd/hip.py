@@ -47,6 +47,7 @@ _SIGS = {
     "nerfart_sort_concat": (_i, [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p]),
     "nerfart_volsdf_composite": (_i, [_i, _i, _p, _p, _p, _p, _f, _f, _i] + [_p] * 8),
     "nerfart_volsdf_composite_bwd": (_i, [_i, _i, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p]),
+    "nerfart_neus_composite_bwd": (_i, [_i, _i, _p, _p, _f, _i, _p, _p, _p, _p, _p]),
     "nerfart_sdf_fwd2_dump_bytes": (_ll, [_ll]),
     "nerfart_sdf_bwd2_dump_bytes": (_ll, [_ll]),
     "nerfart_sdf_fwd2": (_i, [_p, _p, _p, _ll, _p, _p]),
@@ -279,6 +280,18 @@ def volsdf_composite_bwd(d_all, sdf, radiance, alpha: float, beta: float, g_rgb,
                                             int(bool(white_bkgd)), _dev(g_rgb), _dev(g_sdf), _dev(g_rad), _dev(g_ab), _stream()),
            "nerfart_volsdf_composite_bwd")
     return g_sdf, g_rad, g_ab
+
+
+def neus_composite_bwd(sdf, rad_mid, s: float, g_rgb, white_bkgd: bool = False):
+    """(g_sdf [R,P], g_rad_mid [R,P-1,3], g_s [1]) for d loss / d rgb = g_rgb [R,3]."""
+    R, P = sdf.shape
+    dev = sdf.device
+    g_sdf = torch.empty(R, P, dtype=torch.float32, device=dev)
+    g_rad = torch.empty(R, P - 1, 3, dtype=torch.float32, device=dev)
+    g_s = torch.zeros(1, dtype=torch.float32, device=dev)
+    _check(lib.nerfart_neus_composite_bwd(R, P, _dev(sdf), _dev(rad_mid), float(s), int(bool(white_bkgd)), _dev(g_rgb), _dev(g_sdf),
+                                          _dev(g_rad), _dev(g_s), _stream()), "nerfart_neus_composite_bwd")
+    return g_sdf, g_rad, g_s
 
 
 def volsdf_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, near, far, R_bg, alpha, beta, eps=0.1,

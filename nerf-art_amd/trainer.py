@@ -31,7 +31,7 @@ class Trainer(nn.Module):
         self.w_eikonal, self.use_eikonal, self.pass2_rays = w_eikonal, use_eikonal, pass2_rays
         # native: pass 2 entirely on the hand-written kernels + GEMMs (VolSDF, split-bf16 blobs); otherwise autograd over
         # the per-sample networks with the native compositing / radiance kernels where available
-        self.native = (not self.is_neus and model.precision == "bf16x3") if native is None else native
+        self.native = (model.precision == "bf16x3") if native is None else native
         if self.is_neus:                       # neus.py:455-456: only the SDF net (and ln_s) is fine-tuned
             for p in model.radiance_net.parameters():
                 p.requires_grad_(False)
@@ -73,8 +73,10 @@ class Trainer(nn.Module):
         d_all_ = rays_d.reshape(-1, 3).float().contiguous()
         g_all = gradient.reshape(-1, 3)
         eik_sum, n = 0.0, 0
-        ab = None
-        if self.native:
+        ab = s_val = None
+        if self.native and self.is_neus:
+            s_val = float(self.model.forward_s().detach())
+        elif self.native:
             alpha, beta = self.model.forward_ab()
             ab = (float(alpha.detach()), float(beta.detach()))
         for i in range(0, o_all.shape[0], self.pass2_rays):
@@ -82,6 +84,11 @@ class Trainer(nn.Module):
             dn = F.normalize(d_raw, dim=-1)
             with torch.no_grad():
                 depths = self._samples(o, dn, d_raw, render_kwargs)
+            if self.native and self.is_neus:
+                eik_sum = eik_sum + autodiff.neus_backward_samples_native(self.model, o, dn, depths, g_all[i:i + self.pass2_rays], self.w_eikonal,
+                                                                          self.use_eikonal, render_kwargs.get("white_bkgd", False), s_val=s_val)
+                n += 1
+                continue
             if self.native:
                 eik_sum = eik_sum + autodiff.volsdf_backward_samples_native(self.model, o, dn, depths, g_all[i:i + self.pass2_rays],
                                                                             self.w_eikonal, self.use_eikonal,

@@ -202,3 +202,51 @@ def test_native_pass2_ragged_patch_sizes():
     for name, ref in res[False].items():
         rel = float((res[True][name] - ref).norm() / (ref.norm() + 1e-12))
         assert rel < 3e-2, (name, rel)
+
+
+@pytest.mark.parametrize("white", [False, True])
+def test_neus_composite_bwd_kernel_matches_autograd(white):
+    from nerfart_amd import autodiff, hip
+    g = torch.Generator().manual_seed(6)
+    R, P = 130, 128
+    sdf = torch.sort(torch.rand(R, P, generator=g) * 0.6 - 0.3, dim=-1, descending=True)[0] + (torch.rand(R, P, generator=g) - 0.5) * 0.02
+    rad = torch.rand(R, P - 1, 3, generator=g)
+    g_rgb = torch.randn(R, 3, generator=g)
+    s = torch.tensor([35.0], requires_grad=True)
+    sdf_r, rad_r = sdf.clone().requires_grad_(True), rad.clone().requires_grad_(True)
+    cdf, alpha = autodiff.sdf_to_alpha(sdf_r, s)
+    w = autodiff.alpha_to_w(alpha)
+    rgb = (w[..., None] * rad_r).sum(-2)
+    if white:
+        rgb = rgb + (1.0 - w.sum(-1, keepdim=True))
+    rgb.backward(g_rgb)
+    g_sdf, g_rad, g_s = hip.neus_composite_bwd(sdf.to(DEV), rad.to(DEV), 35.0, g_rgb.to(DEV), white)
+    np.testing.assert_allclose(g_rad.cpu().numpy(), rad_r.grad.numpy(), atol=1e-6, rtol=1e-4)
+    scale = float(sdf_r.grad.abs().max())
+    # clamp(alpha, 0) sits on its kink where two neighbouring cdf values are (nearly) equal: a handful of intervals may fall
+    # on the other side with a different sigmoid rounding
+    bad = ((g_sdf.cpu() - sdf_r.grad).abs() > 3e-5 * scale + 2e-3 * sdf_r.grad.abs()).float().mean().item()
+    assert bad < 1e-3, bad
+    np.testing.assert_allclose(float(g_s), float(s.grad), rtol=5e-3, atol=1e-5)
+
+
+def test_neus_native_pass2_matches_autograd():
+    from nerfart_amd import scene, rend_util
+    from nerfart_amd.trainer import Trainer
+    model, rk, render_fn = scene.build_model("NeuS", seed=0, beta=None, device=DEV, precision="bf16x3")
+    H, W = 8, 8
+    c2w, K = scene.camera(H, W)
+    o, d, _ = rend_util.get_rays(c2w[None].to(DEV), K[None].to(DEV), H, W)
+    g = torch.rand(H * W, 3, generator=torch.Generator().manual_seed(4)).to(DEV) * 1e-2
+    res = {}
+    for native in (False, True):
+        model.zero_grad()
+        Trainer(model, pass2_rays=64, native=native).backward_patches(o[0], d[0], g, **rk)
+        res[native] = {n: (None if p.grad is None else p.grad.clone()) for n, p in model.named_parameters()}
+    for name, ref in res[False].items():
+        got = res[True][name]
+        if ref is None:
+            assert got is None, name
+            continue
+        rel = float((got - ref).norm() / (ref.norm() + 1e-12))
+        assert rel < 3e-2, (name, rel)
