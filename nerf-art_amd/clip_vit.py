@@ -91,8 +91,12 @@ class VisionTransformer(nn.Module):
         self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
 
     def forward(self, x):
-        x = self.conv1(x)                                            # [B, width, 7, 7]
-        x = x.flatten(2).transpose(1, 2)                             # [B, 49, width]
+        # the stride-32 / kernel-32 convolution is a GEMM over non-overlapping patches (no MIOpen: its first use of a new
+        # convolution shape compiles kernels for minutes on a fresh box)
+        B, C, H, W = x.shape
+        ps = self.conv1.kernel_size[0]
+        x = x.reshape(B, C, H // ps, ps, W // ps, ps).permute(0, 2, 4, 1, 3, 5).reshape(B, (H // ps) * (W // ps), C * ps * ps)
+        x = x @ self.conv1.weight.reshape(self.conv1.out_channels, -1).t()             # [B, 49, width]
         cls = self.class_embedding.to(x.dtype).expand(x.shape[0], 1, -1)
         x = torch.cat([cls, x], dim=1) + self.positional_embedding.to(x.dtype)
         x = self.transformer(self.ln_pre(x))

@@ -46,7 +46,7 @@ def volume_render(rays_o, rays_d, model: NeuS, obj_bounding_radius=1.0, batched=
             detailed=detailed_output, k3_rays_chunk=k3_rays_chunk, precision=model.precision_id))
     ret = OrderedDict()
     for k in ["rgb", "depth_volume", "mask_volume", "normals_volume", "implicit_nablas", "implicit_surface", "radiance",
-              "alpha", "cdf", "visibility_weights", "d_final"]:
+              "alpha", "cdf", "visibility_weights", "d_final", "d_all"]:      # d_all: the P sample depths (an extra key)
         if k in parts[0]:
             v = torch.cat([p[k] for p in parts], 0) if len(parts) > 1 else parts[0][k]
             ret[k] = v.reshape(*lead, *v.shape[1:])

@@ -38,10 +38,15 @@ class Trainer(nn.Module):
 
     # ---- pass 1 ---------------------------------------------------------------------------------------
     @torch.no_grad()
-    def render_image(self, render_fn, rays_o, rays_d, **render_kwargs):
+    def render_image(self, render_fn, rays_o, rays_d, want_depths: bool = False, **render_kwargs):
+        """Pass 1.  want_depths: also return the sample depths [N, P] of every ray (with perturb=False and unchanged
+        weights pass 2 would re-derive exactly these - it can reuse them)."""
         kw = dict(render_kwargs)
         kw.pop("rayschunk", None)
-        rgb, depth, extras = render_fn(rays_o, rays_d, detailed_output=False, require_nablas=True, calc_normal=True, **kw)
+        rgb, depth, extras = render_fn(rays_o, rays_d, detailed_output=want_depths, require_nablas=True, calc_normal=True, **kw)
+        if want_depths:
+            d = extras["d_all" if self.is_neus else "d_vals"]
+            return rgb, d.reshape(-1, d.shape[-1])
         return rgb
 
     # ---- pass 2 ---------------------------------------------------------------------------------------
@@ -66,9 +71,10 @@ class Trainer(nn.Module):
         d_coarse = (near * (1.0 - t) + far * t)[None, :].expand(o.shape[0], ns)
         return torch.sort(torch.cat([d_coarse, d_fine], dim=-1), dim=-1)[0]
 
-    def backward_patches(self, rays_o, rays_d, gradient, **render_kwargs):
+    def backward_patches(self, rays_o, rays_d, gradient, depths_all=None, **render_kwargs):
         """Pass 2: accumulates parameter gradients for d loss / d rgb = `gradient` [N, 3] (+ the eikonal term).
-        Returns the mean eikonal loss over the patches (what the reference prints)."""
+        depths_all [N, P]: sample depths from pass 1 (skips the re-sampling).  Returns the mean eikonal loss over the
+        patches (what the reference prints)."""
         o_all = rays_o.reshape(-1, 3).float().contiguous()
         d_all_ = rays_d.reshape(-1, 3).float().contiguous()
         g_all = gradient.reshape(-1, 3)
@@ -83,7 +89,7 @@ class Trainer(nn.Module):
             o, d_raw = o_all[i:i + self.pass2_rays], d_all_[i:i + self.pass2_rays]
             dn = F.normalize(d_raw, dim=-1)
             with torch.no_grad():
-                depths = self._samples(o, dn, d_raw, render_kwargs)
+                depths = self._samples(o, dn, d_raw, render_kwargs) if depths_all is None else depths_all[i:i + self.pass2_rays].contiguous()
             if self.native and self.is_neus:
                 eik_sum = eik_sum + autodiff.neus_backward_samples_native(self.model, o, dn, depths, g_all[i:i + self.pass2_rays], self.w_eikonal,
                                                                           self.use_eikonal, render_kwargs.get("white_bkgd", False), s_val=s_val)
@@ -124,8 +130,9 @@ class Trainer(nn.Module):
             kw = {k: v for k, v in render_kwargs.items() if k != "rayschunk"}
             rgb = nd.render_sharded(render_fn, rays_o.reshape(1, -1, 3), rays_d.reshape(1, -1, 3), keys=("rgb",), tile=tile,
                                     detailed_output=False, require_nablas=True, calc_normal=True, **kw)["rgb"]
+            depths_all = None
         else:
-            rgb = self.render_image(render_fn, rays_o, rays_d, **render_kwargs)
+            rgb, depths_all = self.render_image(render_fn, rays_o, rays_d, want_depths=True, **render_kwargs)
         rgb = rgb.detach().reshape(1, -1, 3).requires_grad_(True)
         W = rgb.shape[1] // H
         to_img = lambda t: t.reshape(t.shape[0], H, W, 3).permute(0, 3, 1, 2)          # "B (H W) C -> B C H W"
@@ -143,5 +150,5 @@ class Trainer(nn.Module):
                     p.grad = torch.zeros_like(p)
             nd.allreduce_gradients([p for p in self.model.parameters() if p.requires_grad])
         else:
-            eik = self.backward_patches(rays_o, rays_d, gradient[0], **render_kwargs)
+            eik = self.backward_patches(rays_o, rays_d, gradient[0], depths_all=depths_all, **render_kwargs)
         return {"loss": float(loss.detach()), "eikonal": eik, "rgb": rgb.detach()}

@@ -37,7 +37,7 @@ def main():
     times = []
     for it in range(args.steps + 1):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        rgb = tr.render_image(render_fn, o, d, **rk)
+        rgb, depths_all = tr.render_image(render_fn, o, d, want_depths=True, **rk)
         torch.cuda.synchronize(); t1 = time.perf_counter()
         rgb = rgb.detach().reshape(1, -1, 3).requires_grad_(True)
         to_img = lambda t: t.reshape(1, H, W, 3).permute(0, 3, 1, 2)
@@ -45,7 +45,7 @@ def main():
         loss.backward()
         torch.cuda.synchronize(); t2 = time.perf_counter()
         opt.zero_grad()
-        eik = tr.backward_patches(o, d, rgb.grad.detach()[0], **rk)
+        eik = tr.backward_patches(o, d, rgb.grad.detach()[0], depths_all=depths_all, **rk)
         torch.cuda.synchronize(); t3 = time.perf_counter()
         opt.step()
         torch.cuda.synchronize(); t4 = time.perf_counter()
