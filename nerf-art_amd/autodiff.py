@@ -89,13 +89,6 @@ def _perms(device):
     return _PERMS[key]
 
 
-def _dump_matrix(dump: torch.Tensor, slot: int, M: int) -> torch.Tensor:
-    """[M, 256] bf16 (columns in unit order) of one dumped activation / delta."""
-    T = dump.numel() // _RAD_DUMP_PER_TILE
-    v = dump.view(torch.bfloat16).view(T, 5, 8, 8, 4, 16, 8)[:, slot]            # tile, unit, wave, g, j, e
-    return v.permute(0, 2, 4, 1, 3, 5).reshape(T * 128, 256)[:M]
-
-
 def _mmT(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """a^T b with bf16 operands and an fp32 result: the weight-gradient GEMMs (plain library GEMMs, hipBLASLt).
     The reduction runs over ~10^5..10^6 rows into a <= 256 x 256 result - 16 output tiles would occupy 16 of 256 CUs - so
@@ -190,19 +183,6 @@ def _dump_all(dump: torch.Tensor, M: int) -> torch.Tensor:
     T = dump.numel() // _RAD_DUMP_PER_TILE
     v = dump.view(torch.bfloat16).view(T, 5, 8, 8, 4, 16, 8).permute(1, 0, 3, 5, 2, 4, 6)   # slot, tile, wave, j, unit, g, e
     return v.reshape(5, T * 128, 256)
-
-
-def _pair_matrix(dump: torch.Tensor, slots: int, slot: int, M: int, flip: bool = False) -> torch.Tensor:
-    """[2, M, 256] bf16 of one dumped slot of the column-pair kernels: [0] = even-lane column, [1] = odd-lane column
-    (flip: the other way round); features in unit order."""
-    T = dump.numel() // (slots * 8 * 8 * 1024)
-    v = dump.view(torch.bfloat16).view(T, slots, 8, 8, 4, 8, 2, 8)[:, slot]      # tile, unit, wave, g, point, column, e
-    v = v.permute(5, 0, 2, 4, 1, 3, 6)                                           # column, tile, wave, point, unit, g, e
-    out = torch.empty(2, T * 64, 256, dtype=torch.bfloat16, device=dump.device)
-    o = out.view(2, T, 8, 8, 8, 4, 8)
-    o[0].copy_(v[1 if flip else 0])
-    o[1].copy_(v[0 if flip else 1])
-    return out[:, :M]
 
 
 def embed_tangent(x, direction, multires: int):

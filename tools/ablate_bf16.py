@@ -14,7 +14,7 @@ OUT = os.path.join(ROOT, "gpurun_ablate")
 
 def build():
     os.makedirs(OUT, exist_ok=True)
-    srcs = ["capi_common.cpp", "mlp_chain.hip", "mlp_chain_bf16.hip", "volsdf_render.hip", "volsdf_backward.hip", "neus_render.hip", "raygen.hip"]
+    srcs = ["capi_common.cpp", "mlp_chain.hip", "mlp_chain_bf16.hip", "mlp_grad_bf16.hip", "mlp_backward_bf16.hip", "volsdf_render.hip", "volsdf_backward.hip", "neus_render.hip", "raygen.hip"]
     for name, flags in VARIANTS.items():
         lib = os.path.join(OUT, f"lib_{name}.so")
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip"] + flags + \
