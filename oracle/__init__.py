@@ -14,7 +14,8 @@ file:line it follows.  It exists to *check* the HIP path, never to be it:
     ``tests/golden/*.npz``; checked by ``tests/test_oracle_golden.py``).
 
 Parity status: renderer path PINNED by
-the golden vectors G1-G12.  CLIP ViT-B/32 (a23): "parity unpinned" - the
+the golden vectors G1-G12; its differentiable variant (row a19, the
+fine-tune step's pass 2) PINNED by G11 (the reference's own autograd).  CLIP ViT-B/32 (a23): "parity unpinned" - the
 reference takes it from the un-vendored third-party ``clip`` package and
 holds no test vectors for it; the oracle there is a restatement of the
 published architecture cross-checked against ``transformers.CLIPVisionModel``.
