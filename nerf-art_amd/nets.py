@@ -88,6 +88,35 @@ class ImplicitSurface(nn.Module):
             layers.append(WNLinear(lin.weight.data, lin.bias.data))
         self.surface_fc_layers = nn.ModuleList(layers)
 
+    # ---- boundary B3 as the reference's consumers call it (mesh_util.extract_mesh :110, ray_casting.py :179) ----------
+    def _model(self):
+        owner = getattr(self, "_owner", None)
+        owner = owner() if owner is not None else None
+        if owner is None:
+            raise RuntimeError("ImplicitSurface queries run on its VolSDF / NeuS model's packed weight blob: build the model first")
+        return owner
+
+    def forward(self, x: torch.Tensor, return_h: bool = False):
+        """ImplicitSurface.forward (models/base.py:243-263): sdf [...] (no sphere clamp) and, with return_h, the geometry
+        feature [..., W_geo_feat].  HIP kernels (K2 / K3a); the feature rows of the last linear layer are one GEMM on h7."""
+        m = self._model()
+        if not return_h:
+            return m._surface_query(x, 0.0, False, False)
+        sdf, _, h7 = m._surface_query(x, 0.0, True, True)
+        last = self.surface_fc_layers[self.D]
+        w = torch._weight_norm(last.weight_v, last.weight_g, 0)
+        feat = torch.nn.functional.linear(h7, w[1:], last.bias[1:])
+        return sdf, feat.reshape(*x.shape[:-1], -1)
+
+    def forward_with_nablas(self, x: torch.Tensor, has_grad_bak=None):
+        """ImplicitSurface.forward_with_nablas (base.py:265-282) under no_grad: (sdf, nablas, geometry feature)."""
+        m = self._model()
+        sdf, nab, h7 = m._surface_query(x, 0.0, True, True)
+        last = self.surface_fc_layers[self.D]
+        w = torch._weight_norm(last.weight_v, last.weight_g, 0)
+        feat = torch.nn.functional.linear(h7, w[1:], last.bias[1:])
+        return sdf, nab, feat.reshape(*x.shape[:-1], -1)
+
 
 class RadianceNet(nn.Module):
     """Radiance MLP container (models/base.py:312-370)."""
@@ -115,6 +144,8 @@ class _PackedModel(nn.Module):
         if r.embed_multires != -1 or r.embed_multires_view not in (-1, 4):
             raise NotImplementedError("radiance embed_multires must be -1 and embed_multires_view in (-1, 4)")
         self.view_tiles = 1 if r.embed_multires_view == -1 else 3
+        import weakref
+        object.__setattr__(s, "_owner", weakref.ref(self))      # not a submodule: the surface net queries through this model's blob
         self._plans = {}
         self._blobs = None
         self._blob_key = None

@@ -298,3 +298,23 @@ def test_full_frame_properties():
     close("depth vs oracle", depth_s[0].cpu()[same], ref["depth_volume"][same], 5e-3)
     u = ex_s["iter_usage"][0].cpu()
     print("  iter_usage histogram (subset):", torch.unique(u, return_counts=True))
+
+
+def test_implicit_surface_forward_as_the_reference_consumers_call_it(pts):
+    """mesh_util.extract_mesh (:110) and ray_casting.sphere_tracing (:179) call model.implicit_surface.forward(pts) /
+    forward(pts, return_h=True) / forward_with_nablas(pts): same values as the oracle, no sphere clamp."""
+    from oracle import nets
+    from nerfart_amd import scene
+    sd, _ = scene_state("VolSDF", 0.01)
+    model, _, _ = scene.build_model("VolSDF", seed=0, beta=0.01, device=DEV)
+    p = pts[0][:257].contiguous()
+    s_ref, f_ref = nets.surface_forward(sd, p)
+    with torch.no_grad():
+        close("implicit_surface.forward", model.implicit_surface.forward(p.to(DEV)), s_ref, 2e-6)
+        s2, f2 = model.implicit_surface.forward(p.to(DEV), return_h=True)
+        close("forward(return_h) sdf", s2, s_ref, 2e-6)
+        close("forward(return_h) feature", f2, f_ref, 2e-5)
+        s3, n3, f3 = model.implicit_surface.forward_with_nablas(p.reshape(1, 257, 3).to(DEV))
+        _, n_ref, _ = nets.surface_forward_with_nablas(sd, p)
+        assert s3.shape == (1, 257) and n3.shape == (1, 257, 3) and f3.shape == (1, 257, 256)
+        close("forward_with_nablas nablas", n3[0], n_ref, 5e-6)
