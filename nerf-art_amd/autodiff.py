@@ -252,10 +252,12 @@ def accumulate_folded_grads(layers, dW, db):
             l.bias.grad = g.clone() if l.bias.grad is None else l.bias.grad + g
 
 
-def volsdf_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikonal=0.1, use_eikonal=True, white_bkgd=False, ab=None):
+def volsdf_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikonal=0.1, use_eikonal=True, white_bkgd=False, ab=None,
+                                   nbar_extra=None):
     """Pass 2 of the fine-tune step for one patch, entirely on the hand-written kernels + GEMMs: accumulates into .grad what
     rgb.backward(g_rgb) and (w_eikonal * MSE(|nabla|, 1)).backward() accumulate (volsdf.py:759-770).  Returns the eikonal loss
-    (a 0-d tensor: no host synchronisation in here; `ab` = (alpha, beta) as Python floats if the caller already has them)."""
+    (a 0-d tensor: no host synchronisation in here; `ab` = (alpha, beta) as Python floats if the caller already has them).
+    nbar_extra [R, P, 3]: a further cotangent of the nablas (the reconstruction branch's one-sample-per-ray eikonal term)."""
     from . import hip
     R, P = d_all.shape
     pts = (rays_o[:, None, :] + rays_dn[:, None, :] * d_all[:, :, None]).reshape(-1, 3).contiguous()
@@ -279,6 +281,8 @@ def volsdf_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikon
             nn_ = nab.norm(dim=-1)
             eik = w_eikonal * ((nn_ - 1.0) ** 2).mean()
             nbar = nbar + (w_eikonal * 2.0 / nn_.numel()) * ((nn_ - 1.0) / nn_)[:, None] * nab
+        if nbar_extra is not None:
+            nbar = nbar + nbar_extra.reshape(-1, 3)
         gw, gb, g_w8, g_b8 = radiance_weight_grads(model, pts, v, nab, h7, rgb_pt, g_rad.reshape(-1, 3), dump, bdump)
         dW, db = surface_weight_grads(model, pts, sbar, g_h7, nbar)
         dW[8] = dW[8] + g_w8

@@ -116,6 +116,71 @@ class Trainer(nn.Module):
             del out
         return float(eik_sum) / max(n, 1)
 
+    # ---- reconstruction-training branch (volsdf.py:784-824) -------------------------------------
+    def reconstruction_step(self, render_fn, rays_o, rays_d, target_rgb, eikonal_points, w_eikonal: float = 0.1, optimizer=None,
+                            mask_ignore=None, **render_kwargs):
+        """One step of the reconstruction objective on a batch of rays [N, 3]: loss = mean |rgb - target| + w_eikonal *
+        MSE(|nabla|, 1) over two nablas per ray - the sample of largest visibility weight and `eikonal_points` [N, 3]
+        (the reference draws them uniformly in the bounding box, volsdf.py:799-801; here the caller does, so that runs
+        are reproducible).  VolSDF; deterministic sampling (perturb=False).  Accumulates .grad; returns the losses."""
+        if self.is_neus:
+            raise NotImplementedError("reconstruction_step: VolSDF only (the NeuS branch, neus.py:578-617, is a next row)")
+        m = self.model
+        o = rays_o.reshape(-1, 3).float().contiguous()
+        d = rays_d.reshape(-1, 3).float().contiguous()
+        N = o.shape[0]
+        kw = {k: v for k, v in render_kwargs.items() if k != "rayschunk"}
+        with torch.no_grad():
+            rgb, _, ex = render_fn(o[None], d[None], detailed_output=True, require_nablas=True, calc_normal=True, **kw)
+            rgb = rgb.reshape(N, 3)
+            depths = ex["d_vals"].reshape(N, -1)
+            P = depths.shape[1]
+            nab = ex["implicit_nablas"].reshape(N, P, 3)
+            ind = ex["visibility_weights"].reshape(N, P - 1).argmax(dim=-1)                     # [N]
+            n_sel = nab[torch.arange(N, device=o.device), ind]                                    # [N, 3]
+            surf_blob, _ = m.packed()
+            _, n_eik, _ = hip.sdf_nabla_fwd(surf_blob, eikonal_points.reshape(-1, 3).float().contiguous(), 0.0, want_h7=False,
+                                            precision=m.precision_id)
+            # losses and their cotangents
+            diff = rgb - target_rgb.reshape(N, 3)
+            if mask_ignore is not None:
+                mk = mask_ignore.reshape(N, 1).float()
+                loss_img = (diff.abs() * mk).sum() / (mk.sum() + 1e-10)
+                g_rgb = torch.sign(diff) * mk / (mk.sum() + 1e-10)
+            else:
+                loss_img = diff.abs().mean()
+                g_rgb = torch.sign(diff) / diff.numel()
+            nn_all = torch.cat([n_sel.norm(dim=-1), n_eik.norm(dim=-1)])
+            loss_eik = w_eikonal * ((nn_all - 1.0) ** 2).mean()
+            coef = w_eikonal * 2.0 / nn_all.numel()
+            g_sel = coef * ((n_sel.norm(dim=-1) - 1.0) / n_sel.norm(dim=-1))[:, None] * n_sel
+            g_eik = coef * ((n_eik.norm(dim=-1) - 1.0) / n_eik.norm(dim=-1))[:, None] * n_eik
+            nbar_extra = torch.zeros(N, P, 3, device=o.device)
+            nbar_extra[torch.arange(N, device=o.device), ind] = g_sel
+        if optimizer is not None:
+            optimizer.zero_grad()
+        dn = F.normalize(d, dim=-1)
+        if self.native:
+            alpha, beta = m.forward_ab()
+            ab = (float(alpha.detach()), float(beta.detach()))
+            for i in range(0, N, self.pass2_rays):
+                sl = slice(i, i + self.pass2_rays)
+                autodiff.volsdf_backward_samples_native(m, o[sl], dn[sl], depths[sl].contiguous(), g_rgb[sl], use_eikonal=False,
+                                                        white_bkgd=kw.get("white_bkgd", False), ab=ab, nbar_extra=nbar_extra[sl])
+            with torch.no_grad():
+                pe = eikonal_points.reshape(-1, 3).float().contiguous()
+                dW, db = autodiff.surface_weight_grads(m, pe, torch.zeros(pe.shape[0], device=pe.device),
+                                                       torch.zeros(pe.shape[0], 256, device=pe.device), g_eik)
+            autodiff.accumulate_folded_grads(list(m.implicit_surface.surface_fc_layers), dW, db)
+        else:
+            for i in range(0, N, self.pass2_rays):
+                sl = slice(i, i + self.pass2_rays)
+                out = autodiff.volsdf_render_samples(m, o[sl], dn[sl], depths[sl].contiguous(), white_bkgd=kw.get("white_bkgd", False))
+                torch.autograd.backward([out["rgb"], out["implicit_nablas"]], [g_rgb[sl], nbar_extra[sl]])
+            _, nab_e, _ = autodiff.surface_forward_with_nablas(m.implicit_surface, eikonal_points.reshape(-1, 3).float())
+            nab_e.backward(g_eik)
+        return {"loss_img": float(loss_img), "loss_eikonal": float(loss_eik), "total": float(loss_img + loss_eik)}
+
     # ---- one fine-tune step ---------------------------------------------------------------------------
     def finetune_step(self, render_fn, rays_o, rays_d, target_rgb, H: int, style_loss, optimizer=None, tile: int = 2048,
                       **render_kwargs):
