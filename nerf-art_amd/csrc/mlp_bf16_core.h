@@ -203,9 +203,10 @@ __device__ __forceinline__ void epi_phase(float z0, float z1, Work& w, unsigned&
             w.y1 = (z1 >= 0.f) ? w.r1 : w.e1 * w.r1;
         } else if constexpr (MODE == 11) {
             const float t0 = pair_bcast0(z0), t1 = pair_bcast0(z1);                  // the pair's even lane: d sdf / d a
-            const float s0 = z0 * w.r0, s1 = z1 * w.r1;
-            w.y0 = is_val ? s0 : fmaf(100.0f * t0 * w.e0, 65535.0f - w.r0, s0);
-            w.y1 = is_val ? s1 : fmaf(100.0f * t1 * w.e1, 65535.0f - w.r1, s1);
+            // arithmetic mask instead of a select: hipcc turns the select into a divergent branch around the extra term
+            const float odd = is_val ? 0.f : 100.0f;
+            w.y0 = fmaf(odd * t0 * w.e0, 65535.0f - w.r0, z0 * w.r0);
+            w.y1 = fmaf(odd * t1 * w.e1, 65535.0f - w.r1, z1 * w.r1);
         } else if constexpr (MODE == 10) {
             const float v0 = relu1(z0) + __builtin_amdgcn_logf(1.0f + w.e0) * (0.69314718055994530942f / 100.0f);
             const float v1 = relu1(z1) + __builtin_amdgcn_logf(1.0f + w.e1) * (0.69314718055994530942f / 100.0f);
