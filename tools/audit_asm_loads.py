@@ -65,6 +65,34 @@ def audit(lines, kernel):
     return checked, problems
 
 
+def audit_mfma(lines, kernel, need=12):
+    """The inline-asm MFMA triples: hipcc does not pad the MFMA-result -> non-MFMA reader/writer hazard for instructions it
+    cannot see (cdna_hip_programming.md 5.7 item 2): at least `need` issue slots (s_nop n counts n + 1) must separate the last
+    MFMA of an asm statement from the first other instruction that touches its destination."""
+    problems, checked = [], 0
+    code = [(i, l.strip()) for i, l in enumerate(lines) if l.strip() and not l.strip().startswith(";")]
+    for k, (i, s) in enumerate(code):
+        if not s.startswith("v_mfma") or (k + 1 < len(code) and code[k + 1][1].startswith("v_mfma")):
+            continue
+        dst = regs_of(s.split(",")[0])
+        states = 0
+        for (j, t) in code[k + 1: k + 200]:
+            if t.endswith(":"):
+                continue
+            touched = regs_of(t.split(";")[0]) & dst
+            if touched and not t.startswith("v_mfma"):
+                checked += 1
+                if states < need:
+                    problems.append((kernel, i, f"MFMA result touched after {states} states", t))
+                break
+            if touched and t.startswith("v_mfma"):
+                checked += 1
+                break
+            m = re.match(r"s_nop (\d+)", t)
+            states += (int(m.group(1)) + 1) if m else 1
+    return checked, problems
+
+
 def main():
     total, bad = 0, []
     for src in ("mlp_chain_bf16.hip", "mlp_grad_bf16.hip", "mlp_backward_bf16.hip"):
@@ -77,9 +105,10 @@ def main():
         for a, b in zip(starts, starts[1:] + [len(text)]):
             name = text[a].rstrip(":")
             n, p = audit(text[a:b], name)
-            print(f"{src:26s} {name[:60]:60s} asm fragment reads checked: {n:5d}  problems: {len(p)}")
+            n2, p2 = audit_mfma(text[a:b], name)
+            print(f"{src:26s} {name[:60]:60s} asm fragment reads checked: {n:5d}  MFMA results: {n2:5d}  problems: {len(p) + len(p2)}")
             total += n
-            bad += p
+            bad += p + p2
     for k, i, what, s in bad[:40]:
         print("PROBLEM", k[:50], "line", i, what, "|", s)
     print(f"total reads checked {total}, problems {len(bad)}")
