@@ -69,7 +69,6 @@ def radiance_forward(rad, x, view_dirs, normals, feat):
 
 
 # ---- radiance net on the hand-written kernels (forward with activation dumps, backward chain, GEMM operands) ----
-_RAD_DUMP_PER_TILE = 5 * 8 * 8 * 1024
 _PERMS = {}        # device -> (perm, inv) on that device: a host -> device copy per call would synchronise the stream
 
 
@@ -117,7 +116,7 @@ def _bmmT(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 
 def _colsum(a: torch.Tensor) -> torch.Tensor:
-    return a.float().sum(0)          # (a GEMM against a ones column takes the N = 1 GEMV path: 70x slower)
+    return a.sum(0, dtype=torch.float32)          # (a GEMM against a ones column takes the N = 1 GEMV path: 70x slower)
 
 
 def _inv_perm(device):
@@ -139,15 +138,15 @@ def radiance_weight_grads(model, x, v, n, h7, rgb, g_rgb, dump, bdump):
     unit order; the 256 x 256 results are re-indexed."""
     M = x.shape[0]
     inv = _inv_perm(x.device)
-    acts = _dump_all(dump, M)                                               # f, r0, r1, r2, r3   [5, M_pad, 256]
-    deltas = _dump_all(bdump, M)                                            # d3, d2, d1, d0, g_f (0 for the padded points)
+    acts = _dump_all(dump)                                                  # f, r0, r1, r2, r3   [5, M_pad, 256]
+    deltas = _dump_all(bdump)                                               # d3, d2, d1, d0, g_f (0 for the padded points)
     Mp = acts.shape[1]
     pad = lambda t: t if Mp == M else torch.cat([t, torch.zeros(Mp - M, t.shape[1], device=t.device, dtype=t.dtype)], dim=0)
     d4 = g_rgb * rgb * (1.0 - rgb)
     rad = model.radiance_net
     ex = torch.cat([embed(x, rad.embed_multires), embed(v, rad.embed_multires_view), n], dim=-1)
     ww = _bmmT(deltas[0:4], acts[0:4].flip(0))                               # (d3, r2), (d2, r1), (d1, r0), (d0, f)
-    cs = deltas.float().sum(1)                                              # [5, 256] column sums
+    cs = deltas.sum(1, dtype=torch.float32)                                              # [5, 256] column sums
     gw, gb = [None] * 5, [None] * 5
     gw[4], gb[4] = _unperm(_mmT(pad(d4), acts[4]), inv, rows=False), d4.sum(0)
     for k, l in enumerate((3, 2, 1)):
@@ -162,27 +161,17 @@ def radiance_weight_grads(model, x, v, n, h7, rgb, g_rgb, dump, bdump):
 _F2_SLOTS, _R2_SLOTS = 16, 8
 
 
-def _pair_all(dump: torch.Tensor, slots: int, nslots: int, M: int, flip: bool = False) -> torch.Tensor:
-    """[nslots, 2 Mp, 256] bf16 (Mp = M rounded up to the kernels' 64-point tiles; the padded points carry zero tangents
-    and zero cotangents, so their rows add nothing to any GEMM): for every one of the first `nslots` dumped slots of a
-    column-pair kernel the even-lane column stacked on the odd-lane column (flip: odd on even); features in unit order.
-    Two copy kernels in total."""
-    T = dump.numel() // (slots * 8 * 8 * 1024)
-    M = T * 64
-    v = dump.view(torch.bfloat16).view(T, slots, 8, 8, 4, 8, 2, 8)[:, :nslots]   # tile, slot, unit, wave, g, point, column, e
-    v = v.permute(6, 1, 0, 3, 5, 2, 4, 7)                                        # column, slot, tile, wave, point, unit, g, e
-    out = torch.empty(nslots, 2, M, 256, dtype=torch.bfloat16, device=dump.device)
-    o = out.view(nslots, 2, T, 8, 8, 8, 4, 8)
-    o[:, 0].copy_(v[1 if flip else 0])
-    o[:, 1].copy_(v[0 if flip else 1])
-    return out.view(nslots, 2 * M, 256)
+def _pair_all(dump: torch.Tensor, slots: int, nslots: int) -> torch.Tensor:
+    """[nslots, 2 Mp, 256] bf16 VIEW of a column-pair kernel's dump (Mp = M rounded up to the kernels' 64-point tiles; the
+    padded points carry zero tangents and zero cotangents, so their rows add nothing to any GEMM): the kernels store
+    point-major rows, the first Mp of a slot from one column of the pair and the next Mp from the other (k_sdf_fwd2:
+    [a; adot], k_sdf_bwd2: [zbar; t d]); features in unit order."""
+    return dump.view(torch.bfloat16).view(slots, -1, 256)[:nslots]
 
 
-def _dump_all(dump: torch.Tensor, M: int) -> torch.Tensor:
-    """[5, M_pad, 256] bf16 of the radiance kernels' dumps (unit order), one copy kernel."""
-    T = dump.numel() // _RAD_DUMP_PER_TILE
-    v = dump.view(torch.bfloat16).view(T, 5, 8, 8, 4, 16, 8).permute(1, 0, 3, 5, 2, 4, 6)   # slot, tile, wave, j, unit, g, e
-    return v.reshape(5, T * 128, 256)
+def _dump_all(dump: torch.Tensor) -> torch.Tensor:
+    """[5, M_pad, 256] bf16 VIEW of the radiance kernels' point-major dumps (unit order)."""
+    return dump.view(torch.bfloat16).view(5, -1, 256)
 
 
 def embed_tangent(x, direction, multires: int):
@@ -215,13 +204,13 @@ def surface_weight_grads(model, pts, sbar, hbar7, nbar):
     e2 = torch.cat([padr(embed(pts, surf.embed_multires)), padr(embed_tangent(pts, nbar, surf.embed_multires))], dim=0).to(bf)    # [e; edot]
     rs2 = 1.0 / np.sqrt(2.0)
     sc = 1.0 / 65535.0
-    RZ = _pair_all(r2, _R2_SLOTS, 8, M, flip=True)                      # [8, 2 Mp, 256]: 65535 * [zbar_l; t_l d_l]
-    FA = _pair_all(f2, _F2_SLOTS, 8, M)                                 # [8, 2 Mp, 256]: [a_l; adot_l]
+    RZ = _pair_all(r2, _R2_SLOTS, 8)                                    # [8, 2 Mp, 256]: 65535 * [zbar_l; t_l d_l]
+    FA = _pair_all(f2, _F2_SLOTS, 8)                                    # [8, 2 Mp, 256]: [a_l; adot_l]
     sbar = padr(sbar)
     M = Mp
     ww = _bmmT(RZ[1:8], FA[0:7])                                        # layers 1..7 against the previous layer's (a | adot)
     we = _bmmT(torch.stack([RZ[0], RZ[4]]), e2[None].expand(2, -1, -1))    # layers 0 and 4 against the encoding
-    cs = RZ[:, :M].float().sum(1)                                       # [8, 256]: sum_p zbar_l
+    cs = RZ[:, :M].sum(1, dtype=torch.float32)                                       # [8, 256]: sum_p zbar_l
     dW, db = [None] * 9, [None] * 9
     for l in range(8):
         out_dim = surf.surface_fc_layers[l].out_features

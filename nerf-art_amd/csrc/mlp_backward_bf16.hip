@@ -78,12 +78,14 @@ k_sdf_fwd2_bf16(const float* __restrict__ blob, unsigned M, const float* __restr
             vx = dirv[3 * (size_t)m]; vy = dirv[3 * (size_t)m + 1]; vz = dirv[3 * (size_t)m + 2];
         }
         GradCtx gc;
-        gc.voff = lane * 16;
-        gc.ws = gc.ws_out = gc.pend_ptr = dump + (size_t)tile * F2_DUMP_PER_TILE + wv * 1024;
+        gc.ws = gc.ws_out = gc.pend_ptr = dump;        // [16 slots][2 Mp rows: value columns, then tangent columns][256] bf16
+        gc.slot_stride = (size_t)ntiles * 128 * 512;
+        gc.unit_stride = 64;
+        gc.voff = gc.voff_out = (((j & 1) ? ntiles * 64u : 0u) + tile * 64u + wv * 8 + (j >> 1)) * 512u + g * 16;
         // unit 7 of layer 3 (features 224..255 of a 217-wide layer) is never built: the reverse sweep still reads it (against
         // zero weights) - it must not hold a NaN
-        *reinterpret_cast<u32x4*>(gc.ws_out + (size_t)(3 * 8 + 7) * 8192 + gc.voff) = u32x4{0u, 0u, 0u, 0u};
-        *reinterpret_cast<u32x4*>(gc.ws_out + (size_t)(64 + 3 * 8 + 7) * 8192 + gc.voff) = u32x4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(gc.ws_out + uoff(gc, 3 * 8 + 7) + gc.voff_out) = u32x4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(gc.ws_out + uoff(gc, 64 + 3 * 8 + 7) + gc.voff_out) = u32x4{0u, 0u, 0u, 0u};
         Acc A, B;
         Unit x0, x0n, enc[2], none[1];
         encode_units_pair(px, py, pz, vx, vy, vz, g, is_val, enc);
@@ -121,8 +123,8 @@ k_sdf_fwd2_bf16(const float* __restrict__ blob, unsigned M, const float* __restr
                 epi_phase<10, 2>(t[r0], t[r0 + 1], w, h, l, 0.f, is_val, 0u, dout);
                 hi[pr] = h; dd[pr] = dout;
             }
-            *reinterpret_cast<u32x4*>(gc.ws_out + (size_t)(7 * 8 + u) * 8192 + gc.voff) = hi;
-            *reinterpret_cast<u32x4*>(gc.ws_out + (size_t)(64 + 7 * 8 + u) * 8192 + gc.voff) = dd;
+            *reinterpret_cast<u32x4*>(gc.ws_out + uoff(gc, 7 * 8 + u) + gc.voff_out) = hi;
+            *reinterpret_cast<u32x4*>(gc.ws_out + uoff(gc, 64 + 7 * 8 + u) + gc.voff_out) = dd;
         }
     }
 }
@@ -172,9 +174,15 @@ k_sdf_bwd2_bf16(const float* __restrict__ blob, unsigned M, const float* __restr
         const unsigned m = tile * 64u + wv * 8 + (j >> 1);
         const bool valid = m < M;
         GradCtx gc;
-        gc.voff = lane * 16;
-        gc.ws = f2_dump + (size_t)tile * F2_DUMP_PER_TILE + wv * 1024;
-        gc.ws_out = gc.pend_ptr = r2_dump + (size_t)tile * R2_DUMP_PER_TILE + wv * 1024;
+        gc.ws = f2_dump;
+        gc.ws_out = gc.pend_ptr = r2_dump;             // [8 slots][2 Mp rows: abar columns (zbar), then t columns (t d)][256] bf16
+        gc.slot_stride = (size_t)ntiles * 128 * 512;
+        gc.unit_stride = 64;
+        {
+            const unsigned pt = tile * 64u + wv * 8 + (j >> 1);
+            gc.voff = (((j & 1) ? ntiles * 64u : 0u) + pt) * 512u + g * 16;
+            gc.voff_out = (((j & 1) ? 0u : ntiles * 64u) + pt) * 512u + g * 16;
+        }
         const float sb = valid ? gbar_sdf[m] : 0.f;
         Acc A, B;
 #pragma unroll
@@ -187,11 +195,11 @@ k_sdf_bwd2_bf16(const float* __restrict__ blob, unsigned M, const float* __restr
         }
         Unit x0, x0n, none[1];
         {
-            const u32x4 dd = *reinterpret_cast<const u32x4*>(gc.ws + (size_t)(64 + 7 * 8) * 8192 + gc.voff);
-            const u32x4 aa = *reinterpret_cast<const u32x4*>(gc.ws + (size_t)(7 * 8) * 8192 + gc.voff);
+            const u32x4 dd = *reinterpret_cast<const u32x4*>(gc.ws + uoff(gc, 64 + 7 * 8) + gc.voff);
+            const u32x4 aa = *reinterpret_cast<const u32x4*>(gc.ws + uoff(gc, 7 * 8) + gc.voff);
             u32x4 hi;
             x0 = pair_unit(A, 0, dd, aa, is_val, hi);
-            *reinterpret_cast<u32x4*>(gc.ws_out + (size_t)(7 * 8) * 8192 + gc.voff) = hi;
+            *reinterpret_cast<u32x4*>(gc.ws_out + uoff(gc, 7 * 8) + gc.voff_out) = hi;
         }
         none[0] = x0;
         d_load2(gc, 7 * 8 + 1, 0);
@@ -207,14 +215,14 @@ k_sdf_bwd2_bf16(const float* __restrict__ blob, unsigned M, const float* __restr
             x0 = x0n;
         }
         // A = (t_0 | abar_0): the deltas of layer 0 (unit 0 was built by the last step and is still pending)
-        *reinterpret_cast<u32x4*>(gc.pend_ptr + gc.voff) = gc.dpend;
+        *reinterpret_cast<u32x4*>(gc.pend_ptr + gc.voff_out) = gc.dpend;
 #pragma unroll
         for (int u = 1; u < 8; ++u) {
-            const u32x4 dd = *reinterpret_cast<const u32x4*>(gc.ws + (size_t)(64 + u) * 8192 + gc.voff);
-            const u32x4 aa = *reinterpret_cast<const u32x4*>(gc.ws + (size_t)u * 8192 + gc.voff);
+            const u32x4 dd = *reinterpret_cast<const u32x4*>(gc.ws + uoff(gc, 64 + u) + gc.voff);
+            const u32x4 aa = *reinterpret_cast<const u32x4*>(gc.ws + uoff(gc, u) + gc.voff);
             u32x4 hi;
             (void)pair_unit(A, u, dd, aa, is_val, hi);
-            *reinterpret_cast<u32x4*>(gc.ws_out + (size_t)u * 8192 + gc.voff) = hi;
+            *reinterpret_cast<u32x4*>(gc.ws_out + uoff(gc, u) + gc.voff_out) = hi;
         }
     }
 }
@@ -287,9 +295,11 @@ k_radiance_bwd_bf16(const float* __restrict__ blob, unsigned M, const float* __r
         const unsigned m = tile * 128u + wv * 16 + j;
         const bool valid = m < M;
         GradCtx gc;
-        gc.voff = lane * 16;
-        gc.ws = fwd_dump + (size_t)tile * RAD_DUMP_PER_TILE + wv * 1024;
-        gc.ws_out = gc.pend_ptr = bwd_dump + (size_t)tile * RAD_DUMP_PER_TILE + wv * 1024;
+        gc.ws = fwd_dump;
+        gc.ws_out = gc.pend_ptr = bwd_dump;
+        gc.slot_stride = (size_t)ntiles * 128 * 512;
+        gc.unit_stride = 64;
+        gc.voff = gc.voff_out = (tile * 128u + wv * 16 + j) * 512u + g * 16;
         // delta4 = g_rgb * rgb (1 - rgb); g_r3 = R4^T delta4 (3 rows: plain FMAs)
         float d4[3] = {0.f, 0.f, 0.f};
         if (valid) {
@@ -310,9 +320,9 @@ k_radiance_bwd_bf16(const float* __restrict__ blob, unsigned M, const float* __r
         }
         Unit x0, x0n, none[1];
         {   // unit 0 of delta3 (mask = r3, slot 4); it is also the first dumped unit (delta slot 0)
-            const u32x4 mk = *reinterpret_cast<const u32x4*>(gc.ws + (size_t)(4 * 8) * 8192 + gc.voff);
+            const u32x4 mk = *reinterpret_cast<const u32x4*>(gc.ws + uoff(gc, 4 * 8) + gc.voff);
             x0 = masked_unit(A, 0, mk);
-            *reinterpret_cast<u32x4*>(gc.ws_out + gc.voff) = x0.h;
+            *reinterpret_cast<u32x4*>(gc.ws_out + gc.voff_out) = x0.h;
         }
         none[0] = x0;
         d_load(gc, 4 * 8 + 1, 0);
@@ -332,7 +342,7 @@ k_radiance_bwd_bf16(const float* __restrict__ blob, unsigned M, const float* __r
             Unit X[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const u32x4 mk = *reinterpret_cast<const u32x4*>(gc.ws + (size_t)(1 * 8 + u) * 8192 + gc.voff);
+                const u32x4 mk = *reinterpret_cast<const u32x4*>(gc.ws + uoff(gc, 1 * 8 + u) + gc.voff);
                 X[u] = masked_unit(A, u, mk);
             }
             const float* wp = stream_acquire(s) + lane * 4;
@@ -369,15 +379,20 @@ using namespace nerfart;
 namespace nerfart {
 size_t sdf_fwd2_dump_bytes(long long M) { return (size_t)((M + 63) / 64) * b16::F2_DUMP_PER_TILE; }
 size_t sdf_bwd2_dump_bytes(long long M) { return (size_t)((M + 63) / 64) * b16::R2_DUMP_PER_TILE; }
+// the per-lane byte offsets into the point-major dumps are 32 bit: rows * 512 B < 4 GiB
+static constexpr long long DUMP_MAX_POINTS = 1ll << 21;
 int sdf_fwd2_bf16(const float* blob, long long M, const float* pts, const float* dirv, void* dump, hipStream_t st) {
+    if (M > DUMP_MAX_POINTS) { set_last_error("second-order / backward kernels: at most 2^21 points per call"); return 2; }
     return b16::launch_chain(-1, M, b16::k_sdf_fwd2_bf16, (unsigned)((M + 63) / 64), st, blob, (unsigned)M, pts, dirv, (char*)dump);
 }
 int sdf_bwd2_bf16(const float* blob, long long M, const float* gbar_h7, const float* gbar_sdf, void* f2_dump, void* r2_dump, hipStream_t st) {
+    if (M > DUMP_MAX_POINTS) { set_last_error("second-order / backward kernels: at most 2^21 points per call"); return 2; }
     return b16::launch_chain(-1, M, b16::k_sdf_bwd2_bf16, (unsigned)((M + 63) / 64), st, blob, (unsigned)M, gbar_h7, gbar_sdf, (char*)f2_dump,
                              (char*)r2_dump);
 }
 int radiance_bwd_bf16(const float* blob, long long M, const float* rgb, const float* g_rgb, void* fwd_dump, void* bwd_dump, float* g_h7,
                       float* g_n, hipStream_t st) {
+    if (M > DUMP_MAX_POINTS) { set_last_error("second-order / backward kernels: at most 2^21 points per call"); return 2; }
     return b16::launch_chain(-1, M, b16::k_radiance_bwd_bf16, (unsigned)((M + 127) / 128), st, blob, (unsigned)M, rgb, g_rgb, (char*)fwd_dump,
                              (char*)bwd_dump, g_h7, g_n);
 }

@@ -246,10 +246,18 @@ __device__ __forceinline__ void epi_phase(float z0, float z1, Work& w, unsigned&
 // scratch in global memory (stays in L2 / Infinity Cache): unit u of layer l = 16 B per lane (4 pairs of unorm16) at
 // ws + ((8 l + u) * 8 + wave) * 1024 + lane * 16.
 // ---------------------------------------------------------------------------------------
+// Unit `idx` = 8 * slot + unit of a dump lives at base + slot * slot_stride + unit * unit_stride + (per-lane) voff:
+//   scratch of k_sdf_grad_bf16 (never leaves the kernel): wave-private 1 KiB pieces - unit_stride 8192, slot_stride 65536,
+//     voff = lane * 16, base includes wave * 1024;
+//   dumps that feed the weight-gradient GEMMs: POINT-MAJOR matrices [slot][row][256 features in unit order] (bf16) so that the
+//     GEMMs read them in place - unit_stride 64, slot_stride = rows * 512, voff = row * 512 + lane_group * 16.
 struct GradCtx {
-    char* ws;                 // scratch of this wave: workgroup base + wave * 1024 (wave uniform) - loads
-    char* ws_out;             // where finished units are stored (same as ws in the reverse-mode SDF kernel)
-    unsigned voff;            // lane * 16
+    char* ws;                 // base the units are loaded from (wave uniform)
+    char* ws_out;             // base finished units are stored to
+    size_t slot_stride;
+    unsigned unit_stride;
+    unsigned voff;            // per-lane byte offset of loads
+    unsigned voff_out;        // ... of stores
     int layer;                // layer whose weights are being applied (wave uniform)
     u32x4 dbuf[2];            // backward sweep: softplus' units, k-step parity double buffer
     u32x4 abuf[2];            // second-order reverse sweep: tangent units (bf16 hi parts)
@@ -258,16 +266,18 @@ struct GradCtx {
     u32x4 dpend;              // forward sweep: finished unit, stored at the first triple of the next k-step
     char* pend_ptr;
 };
+__device__ __forceinline__ size_t uoff(const GradCtx& gc, int idx) {
+    return (size_t)(idx >> 3) * gc.slot_stride + (size_t)(idx & 7) * gc.unit_stride;
+}
 // (l, unit) of the second-order kernels: softplus' at slot 8 + l, tangent / activation hi parts at slot l
 __device__ __forceinline__ void d_load2(GradCtx& gc, int idx, int buf) {
-    gc.dbuf[buf] = *reinterpret_cast<const u32x4*>(gc.ws + (size_t)(64 + idx) * 8192 + gc.voff);
-    gc.abuf[buf] = *reinterpret_cast<const u32x4*>(gc.ws + (size_t)idx * 8192 + gc.voff);
+    gc.dbuf[buf] = *reinterpret_cast<const u32x4*>(gc.ws + uoff(gc, 64 + idx) + gc.voff);
+    gc.abuf[buf] = *reinterpret_cast<const u32x4*>(gc.ws + uoff(gc, idx) + gc.voff);
 }
 // Plain (compiler-visible) loads: hipcc then keeps its own vmcnt bookkeeping for them - with the LDS-DMA pieces it
 // cannot see this can only make its wait stricter.  (Hand-counted asm loads gave wrong gradients on random waves.)
 __device__ __forceinline__ void d_load(GradCtx& gc, int idx, int buf) {
-    const char* ptr = gc.ws + (size_t)idx * 8192;
-    gc.dbuf[buf] = *reinterpret_cast<const u32x4*>(ptr + gc.voff);
+    gc.dbuf[buf] = *reinterpret_cast<const u32x4*>(gc.ws + uoff(gc, idx) + gc.voff);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -335,9 +345,9 @@ struct Items {
                 constexpr int HUP = (ks == 0) ? (L::PEND_IN ? 100 : -1) : L::hosted(ks - 1);
                 constexpr bool STORE = (ks == 0) ? L::PEND_IN : (HUP >= 0 && L::stores(L::mode_of(HUP)));
                 if constexpr (STORE) {
-                    *reinterpret_cast<u32x4*>(gc.pend_ptr + gc.voff) = gc.dpend;
+                    *reinterpret_cast<u32x4*>(gc.pend_ptr + gc.voff_out) = gc.dpend;
                     constexpr int PM = (ks == 0) ? L::MODE : L::mode_of(HUP);        // (mode 10 layers use 10 for both kinds)
-                    if constexpr (PM == 10) *reinterpret_cast<u32x4*>(gc.pend_ptr + (size_t)64 * 8192 + gc.voff) = gc.dpend2;
+                    if constexpr (PM == 10) *reinterpret_cast<u32x4*>(gc.pend_ptr + 8 * gc.slot_stride + gc.voff_out) = gc.dpend2;
                 }
                 // backward sweep: load the softplus' unit needed by the slices of the NEXT k-step
                 if constexpr (ks + 1 < L::NKS) {
@@ -388,7 +398,7 @@ struct Items {
                         const int idx = (HM == 5 || HM == 8 || HM == 10) ? (HU == 100 ? gc.layer * 8 : (gc.layer - 1) * 8 + HU)
                                         : (HM == 11)                     ? (HU == 100 ? (gc.layer - 1) * 8 : gc.layer * 8 + HU)
                                                                          : (HU == 100 ? (5 - gc.layer) * 8 : (4 - gc.layer) * 8 + HU);
-                        gc.pend_ptr = gc.ws_out + (size_t)idx * 8192;
+                        gc.pend_ptr = gc.ws_out + uoff(gc, idx);
                     }
                 }
             }
@@ -444,7 +454,7 @@ __device__ __forceinline__ void layer(const Acc& P, Acc& Q, const Unit& x0, cons
 // Epilogue of the last hidden layer: dot products of act(Q) with NROWS rows (+ the fp32 activations h7).
 template <int MODE, int NROWS>
 __device__ __forceinline__ void last_epilogue(const Acc& Q, const float* rows, float (&dot)[NROWS], float* h7, const EpiCtx& ec,
-                                              char* dump = nullptr) {
+                                              char* dump = nullptr, unsigned dump_unit_stride = 0) {     // dump: this lane's unit 0
     const int g = lane_id() >> 4;
     u32x4 du;
 #pragma unroll
@@ -476,7 +486,7 @@ __device__ __forceinline__ void last_epilogue(const Acc& Q, const float* rows, f
             if (dump != nullptr) {          // unit T/2 = (tile T regs 0..3 | tile T+1 regs 0..3), bf16 hi parts
                 du[2 * (T & 1)] = pack_bf16(y[0], y[1]);
                 du[2 * (T & 1) + 1] = pack_bf16(y[2], y[3]);
-                if (T & 1) *reinterpret_cast<u32x4*>(dump + (size_t)(T >> 1) * 8192 + (lane_id() * 16)) = du;
+                if (T & 1) *reinterpret_cast<u32x4*>(dump + (size_t)(T >> 1) * dump_unit_stride) = du;
             }
         }
     }

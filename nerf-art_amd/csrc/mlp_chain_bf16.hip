@@ -171,8 +171,10 @@ k_radiance_bf16(const float* __restrict__ blob, PointSrc src, const float* __res
         Acc A, B;
         Unit x0, x0n, none[1];
         GradCtx gc;
-        gc.voff = lane * 16;
-        gc.ws = gc.ws_out = gc.pend_ptr = DUMP ? dump + (size_t)tile * RAD_DUMP_PER_TILE + wv * 1024 : nullptr;
+        gc.ws = gc.ws_out = gc.pend_ptr = dump;                       // [5 slots][ntiles * 128 points][256] bf16, point-major
+        gc.slot_stride = (size_t)ntiles * 128 * 512;
+        gc.unit_stride = 64;
+        gc.voff = gc.voff_out = (tile * 128u + wv * 16 + j) * 512u + g * 16;
         {
             // h7 -> units: unit u slot e < 4: feature 32u + 4g + e; e >= 4: 32u + 16 + 4g + (e - 4)
             Unit hu[8];
@@ -221,7 +223,7 @@ k_radiance_bf16(const float* __restrict__ blob, PointSrc src, const float* __res
         gc.layer = 4;
         layer<Cfg<M, M, 8, 0, false, false, DUMP>>(A, B, x0, none, x0n, s, aux + 4 * 256, ec, gc);
         float dot[3] = {0.f, 0.f, 0.f};
-        last_epilogue<2, 3>(B, aux + RAD_AUX_ROWS, dot, nullptr, ec, DUMP ? gc.ws_out + (size_t)(4 * 8) * 8192 : nullptr);
+        last_epilogue<2, 3>(B, aux + RAD_AUX_ROWS, dot, nullptr, ec, DUMP ? gc.ws_out + uoff(gc, 4 * 8) + gc.voff_out : nullptr, gc.unit_stride);
         float c[3];
 #pragma unroll
         for (int n = 0; n < 3; ++n) c[n] = sigmoidf_(sum_over_groups(dot[n]) + aux[RAD_AUX_BF + n]);
@@ -253,6 +255,7 @@ int radiance_bf16(const float* blob, int view_tiles, const PointSrc& s, const fl
 size_t radiance_dump_bytes(long long M) { return (size_t)((M + 127) / 128) * b16::RAD_DUMP_PER_TILE; }
 int radiance_fwd_dump_bf16(const float* blob, int view_tiles, const PointSrc& s, const float* nabla, const float* h7, float* rgb, void* dump, hipStream_t st) {
     const unsigned nt = (s.M + 127u) / 128u;
+    if (s.M > (1u << 21)) { set_last_error("radiance_fwd_dump: at most 2^21 points per call"); return 2; }
     if (view_tiles == 1) return b16::launch_chain(2, (long long)s.M, b16::k_radiance_bf16<1, true>, nt, st, blob, s, nabla, h7, rgb, (char*)dump);
     if (view_tiles == 3) return b16::launch_chain(2, (long long)s.M, b16::k_radiance_bf16<2, true>, nt, st, blob, s, nabla, h7, rgb, (char*)dump);
     set_last_error("radiance_fwd_dump: view_tiles must be 1 or 3");

@@ -53,7 +53,9 @@ k_sdf_grad_bf16(const float* __restrict__ blob, PointSrc src, float R_bg, float*
     GradCtx gc;
     gc.ws = ws + (size_t)blockIdx.x * GRAD_WS_PER_WG + wv * 1024;
     gc.ws_out = gc.ws;
-    gc.voff = lane * 16;
+    gc.slot_stride = 8 * 8192;
+    gc.unit_stride = 8192;
+    gc.voff = gc.voff_out = lane * 16;
     gc.pend_ptr = gc.ws;
     const EpiCtx ec{0.f, 0.f, true};
     for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -115,7 +117,7 @@ k_sdf_grad_bf16(const float* __restrict__ blob, PointSrc src, float R_bg, float*
             u32x4 d0[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const char* ptr = gc.ws + (size_t)u * 8192;
+                const char* ptr = gc.ws + uoff(gc, u);
                 d0[u] = *reinterpret_cast<const u32x4*>(ptr + gc.voff);
             }
             Unit X[8];
