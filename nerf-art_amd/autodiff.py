@@ -14,15 +14,23 @@ import torch
 import torch.nn.functional as F
 
 
+_FREQS = {}
+
+
+def _freqs(device, multires: int) -> torch.Tensor:
+    key = (str(device), multires)
+    if key not in _FREQS:
+        _FREQS[key] = (2.0 ** torch.arange(multires, dtype=torch.float32))[:, None].to(device)      # [K, 1]
+    return _FREQS[key]
+
+
 def embed(x: torch.Tensor, multires: int) -> torch.Tensor:
-    """models/base.py:46-64: cat[x, sin(2^k x), cos(2^k x), ...], k = 0..multires-1; identity for multires = -1."""
+    """models/base.py:46-64: cat[x, sin(2^k x), cos(2^k x), ...], k = 0..multires-1; identity for multires = -1.
+    (All octaves in one sin and one cos launch; 2^k x is exact, so this is the loop's result bit for bit.)"""
     if multires < 0:
         return x
-    out = [x]
-    for k in range(multires):
-        f = 2.0 ** k
-        out += [torch.sin(x * f), torch.cos(x * f)]
-    return torch.cat(out, dim=-1)
+    xf = x[..., None, :] * _freqs(x.device, multires).to(x.dtype)                  # [..., K, 3]
+    return torch.cat([x, torch.stack([torch.sin(xf), torch.cos(xf)], dim=-2).flatten(-3)], dim=-1)
 
 
 def wn_linear(layer, h: torch.Tensor) -> torch.Tensor:
@@ -132,30 +140,41 @@ def _unperm(w: torch.Tensor, inv: torch.Tensor, rows: bool = True, cols: bool = 
     return w
 
 
-def radiance_weight_grads(model, x, v, n, h7, rgb, g_rgb, dump, bdump):
-    """Gradients of the FOLDED radiance weights / biases and of rows 1.. of the last SDF layer: plain GEMMs of the deltas
-    (k_radiance_bwd_bf16's dump) with the activations (k_radiance_bf16<dump>'s).  The big operands stay in the kernels'
-    unit order; the 256 x 256 results are re-indexed."""
+def radiance_weight_grads_raw(model, x, v, n, h7, rgb, g_rgb, dump, bdump):
+    """Plain GEMMs of the deltas (k_radiance_bwd_bf16's dump) with the activations (k_radiance_bf16<dump>'s), read in place;
+    the big operands stay in the kernels' unit order.  Returns the raw fp32 results - LINEAR in the cotangents, so the
+    results of several patches may be summed (GradAccumulator) before radiance_weight_grads_finish."""
     M = x.shape[0]
-    inv = _inv_perm(x.device)
     acts = _dump_all(dump)                                                  # f, r0, r1, r2, r3   [5, M_pad, 256]
-    deltas = _dump_all(bdump)                                               # d3, d2, d1, d0, g_f (0 for the padded points)
+    deltas = _dump_all(bdump)                                               # d0, d1, d2, d3, g_f (0 for the padded points)
     Mp = acts.shape[1]
     pad = lambda t: t if Mp == M else torch.cat([t, torch.zeros(Mp - M, t.shape[1], device=t.device, dtype=t.dtype)], dim=0)
     d4 = g_rgb * rgb * (1.0 - rgb)
     rad = model.radiance_net
     ex = torch.cat([embed(x, rad.embed_multires), embed(v, rad.embed_multires_view), n], dim=-1)
-    ww = _bmmT(deltas[0:4], acts[0:4].flip(0))                               # (d3, r2), (d2, r1), (d1, r0), (d0, f)
-    cs = deltas.sum(1, dtype=torch.float32)                                              # [5, 256] column sums
+    ww = _bmmT(deltas[0:4], acts[0:4])                                      # (d0, f), (d1, r0), (d2, r1), (d3, r2)
+    cs = deltas.sum(1, dtype=torch.float32)                                 # [5, 256] column sums
+    return [ww, cs, _mmT(pad(d4), acts[4]), d4.sum(0), _mmT(deltas[0], pad(ex)), _mmT(deltas[4], pad(h7))]
+
+
+def radiance_weight_grads_finish(model, raw):
+    """Gradients of the FOLDED radiance weights / biases and of rows 1.. of the last SDF layer from the raw GEMM results:
+    the 256-wide axes are re-indexed from unit order to the reference's feature order."""
+    ww, cs, w4, b4, wex, wh7 = raw
+    inv = _inv_perm(ww.device)
     gw, gb = [None] * 5, [None] * 5
-    gw[4], gb[4] = _unperm(_mmT(pad(d4), acts[4]), inv, rows=False), d4.sum(0)
-    for k, l in enumerate((3, 2, 1)):
-        gw[l], gb[l] = _unperm(ww[k], inv), cs[k][inv]
-    gw[0] = torch.cat([_unperm(_mmT(deltas[3], pad(ex)), inv, cols=False), _unperm(ww[3], inv)], dim=1)
-    gb[0] = cs[3][inv]
-    g_w8 = torch.cat([torch.zeros(1, 256, device=x.device), _unperm(_mmT(deltas[4], pad(h7)), inv, cols=False)], dim=0)
-    g_b8 = torch.cat([torch.zeros(1, device=x.device), cs[4][inv]])
+    gw[4], gb[4] = _unperm(w4, inv, rows=False), b4
+    for l in (1, 2, 3):
+        gw[l], gb[l] = _unperm(ww[l], inv), cs[l][inv]
+    gw[0] = torch.cat([_unperm(wex, inv, cols=False), _unperm(ww[0], inv)], dim=1)
+    gb[0] = cs[0][inv]
+    g_w8 = torch.cat([torch.zeros(1, 256, device=ww.device), _unperm(wh7, inv, cols=False)], dim=0)
+    g_b8 = torch.cat([torch.zeros(1, device=ww.device), cs[4][inv]])
     return gw, gb, g_w8, g_b8
+
+
+def radiance_weight_grads(model, x, v, n, h7, rgb, g_rgb, dump, bdump):
+    return radiance_weight_grads_finish(model, radiance_weight_grads_raw(model, x, v, n, h7, rgb, g_rgb, dump, bdump))
 
 
 _F2_SLOTS, _R2_SLOTS = 16, 8
@@ -176,20 +195,17 @@ def _dump_all(dump: torch.Tensor) -> torch.Tensor:
 
 def embed_tangent(x, direction, multires: int):
     """d embed(x) / d x . direction."""
-    out = [direction]
-    for k in range(multires):
-        f = 2.0 ** k
-        out += [torch.cos(x * f) * f * direction, -torch.sin(x * f) * f * direction]
-    return torch.cat(out, dim=-1)
+    f = _freqs(x.device, multires).to(x.dtype)
+    xf = x[..., None, :] * f
+    d = direction[..., None, :] * f
+    return torch.cat([direction, torch.stack([torch.cos(xf) * d, -torch.sin(xf) * d], dim=-2).flatten(-3)], dim=-1)
 
 
-def surface_weight_grads(model, pts, sbar, hbar7, nbar):
-    """Gradients of the FOLDED SDF-net weights / biases for the cotangents (sbar of sdf [M], hbar7 of the layer-7
-    activation [M,256], nbar of grad_x sdf [M,3]) on k_sdf_fwd2_bf16 / k_sdf_bwd2_bf16 + GEMMs.  Returns (dW[0..8], db[0..8]);
-    layer 8 holds the sdf row only (rows 1.. belong to radiance_weight_grads).
-
-    dW_l = zbar_l^T a_{l-1} + (t_l d_l)^T adot_{l-1} is ONE GEMM over the 2 M stacked rows of the two dumps (the reverse
-    sweep's columns flipped); the big operands stay in unit order."""
+def surface_weight_grads_raw(model, pts, sbar, hbar7, nbar):
+    """k_sdf_fwd2_bf16 / k_sdf_bwd2_bf16 + the GEMMs over their dumps for the cotangents (sbar of sdf [M], hbar7 of the
+    layer-7 activation [M,256], nbar of grad_x sdf [M,3]).  dW_l = zbar_l^T a_{l-1} + (t_l d_l)^T adot_{l-1} is ONE GEMM
+    over the 2 Mp stacked rows of the two dumps, read in place; the big operands stay in unit order.  Returns the raw fp32
+    results - linear in the cotangents, so patches may be summed before surface_weight_grads_finish."""
     from . import hip
     surf = model.implicit_surface
     surf_blob, _ = model.packed()
@@ -197,39 +213,87 @@ def surface_weight_grads(model, pts, sbar, hbar7, nbar):
     pts, nbar = pts.contiguous(), nbar.contiguous()
     f2 = hip.sdf_fwd2(surf_blob, pts, nbar)
     r2 = hip.sdf_bwd2(surf_blob, hbar7.contiguous(), sbar.contiguous(), f2)
-    inv = _inv_perm(pts.device)
     bf = torch.bfloat16
     Mp = (M + 63) // 64 * 64                                            # the kernels' tiles; padded rows are zero where it matters
     padr = lambda t: t if Mp == M else torch.cat([t, torch.zeros(Mp - M, *t.shape[1:], device=t.device, dtype=t.dtype)], dim=0)
     e2 = torch.cat([padr(embed(pts, surf.embed_multires)), padr(embed_tangent(pts, nbar, surf.embed_multires))], dim=0).to(bf)    # [e; edot]
-    rs2 = 1.0 / np.sqrt(2.0)
-    sc = 1.0 / 65535.0
     RZ = _pair_all(r2, _R2_SLOTS, 8)                                    # [8, 2 Mp, 256]: 65535 * [zbar_l; t_l d_l]
     FA = _pair_all(f2, _F2_SLOTS, 8)                                    # [8, 2 Mp, 256]: [a_l; adot_l]
     sbar = padr(sbar)
-    M = Mp
     ww = _bmmT(RZ[1:8], FA[0:7])                                        # layers 1..7 against the previous layer's (a | adot)
     we = _bmmT(torch.stack([RZ[0], RZ[4]]), e2[None].expand(2, -1, -1))    # layers 0 and 4 against the encoding
-    cs = RZ[:, :M].sum(1, dtype=torch.float32)                                       # [8, 256]: sum_p zbar_l
+    cs = RZ[:, :Mp].sum(1, dtype=torch.float32)                         # [8, 256]: sum_p zbar_l
+    a7, ad7 = FA[7][:Mp], FA[7][Mp:]
+    w8 = _mmT(a7, sbar[:, None])[:, 0] + _colsum(ad7)
+    return [ww, we, cs, w8, sbar.sum()]
+
+
+def surface_weight_grads_finish(model, raw):
+    """(dW[0..8], db[0..8]) of the FOLDED SDF-net weights / biases from the raw results; layer 8 holds the sdf row only
+    (rows 1.. belong to radiance_weight_grads)."""
+    ww, we, cs, w8row, b8sum = raw
+    surf = model.implicit_surface
+    inv = _inv_perm(ww.device)
+    rs2 = 1.0 / np.sqrt(2.0)
+    sc = 1.0 / 65535.0
     dW, db = [None] * 9, [None] * 9
     for l in range(8):
         out_dim = surf.surface_fc_layers[l].out_features
         if l == 0:
             w = _unperm(we[0], inv, cols=False)
         elif l in surf.skips:
-            hw = surf.W - e2.shape[1]
+            hw = surf.W - we.shape[2]
             w = torch.cat([_unperm(ww[l - 1], inv)[:, :hw], _unperm(we[1], inv, cols=False)], dim=1) * rs2
         else:
             w = _unperm(ww[l - 1], inv)
         dW[l] = (w * sc)[:out_dim]
         db[l] = (cs[l][inv] * sc)[:out_dim]
-    a7, ad7 = FA[7][:M], FA[7][M:]
-    w8 = torch.zeros(surf.surface_fc_layers[8].out_features, 256, device=pts.device)
-    w8[0] = (_mmT(a7, sbar[:, None])[:, 0] + _colsum(ad7))[inv]
-    b8 = torch.zeros(w8.shape[0], device=pts.device)
-    b8[0] = sbar.sum()
+    w8 = torch.zeros(surf.surface_fc_layers[8].out_features, 256, device=ww.device)
+    w8[0] = w8row[inv]
+    b8 = torch.zeros(w8.shape[0], device=ww.device)
+    b8[0] = b8sum
     dW[8], db[8] = w8, b8
     return dW, db
+
+
+def surface_weight_grads(model, pts, sbar, hbar7, nbar):
+    return surface_weight_grads_finish(model, surface_weight_grads_raw(model, pts, sbar, hbar7, nbar))
+
+
+class GradAccumulator:
+    """Sums the raw weight-gradient results of pass 2 over the patches of a step.  Everything downstream of them - un-permuting
+    the 256-wide axes, the weight_norm chain rule, the alpha / beta (or s) chain rule - is linear and runs ONCE in flush()
+    instead of once per patch (~150 tiny launches per patch otherwise)."""
+
+    def __init__(self):
+        self.sums = {}
+
+    def add(self, key: str, raw):
+        raw = [t if isinstance(t, torch.Tensor) else torch.as_tensor(t) for t in raw]
+        if key not in self.sums:
+            self.sums[key] = [t.clone() for t in raw]
+        else:
+            torch._foreach_add_(self.sums[key], raw)
+
+    def flush(self, model):
+        """.grad += of the model's parameters; empties the accumulator."""
+        if "surf" in self.sums:
+            dW, db = surface_weight_grads_finish(model, self.sums["surf"])
+            if "rad" in self.sums:
+                gw, gb, g_w8, g_b8 = radiance_weight_grads_finish(model, self.sums["rad"])
+                dW[8] = dW[8] + g_w8                              # the geometry-feature rows of the last SDF layer
+                db[8] = db[8] + g_b8
+                if any(p.requires_grad for p in model.radiance_net.parameters()):
+                    accumulate_folded_grads(list(model.radiance_net.layers), gw, gb)
+            accumulate_folded_grads(list(model.implicit_surface.surface_fc_layers), dW, db)
+        if "ab" in self.sums:
+            g_ab = self.sums["ab"][0]
+            a, b = model.forward_ab()
+            torch.autograd.backward([a, b], [g_ab[0:1].reshape(a.shape), g_ab[1:2].reshape(b.shape)])
+        if "s" in self.sums:
+            s_t = model.forward_s()
+            torch.autograd.backward([s_t], [self.sums["s"][0].reshape(s_t.shape)])
+        self.sums = {}
 
 
 def accumulate_folded_grads(layers, dW, db):
@@ -242,11 +306,12 @@ def accumulate_folded_grads(layers, dW, db):
 
 
 def volsdf_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikonal=0.1, use_eikonal=True, white_bkgd=False, ab=None,
-                                   nbar_extra=None):
+                                   nbar_extra=None, accum=None):
     """Pass 2 of the fine-tune step for one patch, entirely on the hand-written kernels + GEMMs: accumulates into .grad what
     rgb.backward(g_rgb) and (w_eikonal * MSE(|nabla|, 1)).backward() accumulate (volsdf.py:759-770).  Returns the eikonal loss
     (a 0-d tensor: no host synchronisation in here; `ab` = (alpha, beta) as Python floats if the caller already has them).
-    nbar_extra [R, P, 3]: a further cotangent of the nablas (the reconstruction branch's one-sample-per-ray eikonal term)."""
+    nbar_extra [R, P, 3]: a further cotangent of the nablas (the reconstruction branch's one-sample-per-ray eikonal term).
+    accum: a GradAccumulator shared by the patches of a step - the caller flushes it once; None: .grad is updated here."""
     from . import hip
     R, P = d_all.shape
     pts = (rays_o[:, None, :] + rays_dn[:, None, :] * d_all[:, :, None]).reshape(-1, 3).contiguous()
@@ -272,19 +337,16 @@ def volsdf_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikon
             nbar = nbar + (w_eikonal * 2.0 / nn_.numel()) * ((nn_ - 1.0) / nn_)[:, None] * nab
         if nbar_extra is not None:
             nbar = nbar + nbar_extra.reshape(-1, 3)
-        gw, gb, g_w8, g_b8 = radiance_weight_grads(model, pts, v, nab, h7, rgb_pt, g_rad.reshape(-1, 3), dump, bdump)
-        dW, db = surface_weight_grads(model, pts, sbar, g_h7, nbar)
-        dW[8] = dW[8] + g_w8
-        db[8] = db[8] + g_b8
-    accumulate_folded_grads(list(model.implicit_surface.surface_fc_layers), dW, db)
-    if any(p.requires_grad for p in model.radiance_net.parameters()):
-        accumulate_folded_grads(list(model.radiance_net.layers), gw, gb)
-    a, b = model.forward_ab()
-    torch.autograd.backward([a, b], [g_ab[0:1].reshape(a.shape), g_ab[1:2].reshape(b.shape)])
+        acc = accum if accum is not None else GradAccumulator()
+        acc.add("rad", radiance_weight_grads_raw(model, pts, v, nab, h7, rgb_pt, g_rad.reshape(-1, 3), dump, bdump))
+        acc.add("surf", surface_weight_grads_raw(model, pts, sbar, g_h7, nbar))
+        acc.add("ab", [g_ab])
+    if accum is None:
+        acc.flush(model)
     return eik
 
 
-def neus_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikonal=0.1, use_eikonal=True, white_bkgd=False, s_val=None):
+def neus_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikonal=0.1, use_eikonal=True, white_bkgd=False, s_val=None, accum=None):
     """Pass 2 for one NeuS patch on the hand-written kernels + GEMMs (neus.py:310-395, :520-576): SDF + nablas at the P
     samples (alpha, eikonal), SDF + nablas + radiance at the P-1 mid-points; the radiance net is frozen (neus.py:455-456).
     Returns the eikonal loss (0-d tensor)."""
@@ -310,19 +372,13 @@ def neus_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikonal
             eik = w_eikonal * ((nn_ - 1.0) ** 2).mean()
             nbar = (w_eikonal * 2.0 / nn_.numel()) * ((nn_ - 1.0) / nn_)[:, None] * nab
         # samples: cotangents of sdf (alpha) and of the nablas (eikonal); mid-points: of h7 and of the normal (radiance)
-        dW, db = surface_weight_grads(model, pts, g_sdf.reshape(-1), torch.zeros(pts.shape[0], 256, device=pts.device), nbar)
-        dW2, db2 = surface_weight_grads(model, pts_m, torch.zeros(pts_m.shape[0], device=pts.device), g_h7, g_n)
-        dW = [a + b for a, b in zip(dW, dW2)]
-        db = [a + b for a, b in zip(db, db2)]
-        trainable_rad = any(p.requires_grad for p in model.radiance_net.parameters())
-        gw, gb, g_w8, g_b8 = radiance_weight_grads(model, pts_m, v_m, nab_m, h7_m, rgb_m, g_rad.reshape(-1, 3), dump, bdump)
-        dW[8] = dW[8] + g_w8                                      # the geometry-feature rows of the last SDF layer are trainable
-        db[8] = db[8] + g_b8
-    accumulate_folded_grads(list(model.implicit_surface.surface_fc_layers), dW, db)
-    if trainable_rad:
-        accumulate_folded_grads(list(model.radiance_net.layers), gw, gb)
-    s_t = model.forward_s()
-    torch.autograd.backward([s_t], [g_s.reshape(s_t.shape)])
+        acc = accum if accum is not None else GradAccumulator()
+        acc.add("surf", surface_weight_grads_raw(model, pts, g_sdf.reshape(-1), torch.zeros(pts.shape[0], 256, device=pts.device), nbar))
+        acc.add("surf", surface_weight_grads_raw(model, pts_m, torch.zeros(pts_m.shape[0], device=pts.device), g_h7, g_n))
+        acc.add("rad", radiance_weight_grads_raw(model, pts_m, v_m, nab_m, h7_m, rgb_m, g_rad.reshape(-1, 3), dump, bdump))
+        acc.add("s", [g_s])
+    if accum is None:
+        acc.flush(model)
     return eik
 
 

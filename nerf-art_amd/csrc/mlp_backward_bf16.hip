@@ -13,10 +13,11 @@ namespace b16 {
 //     t_{l-1} = W_l^T (t_l * d_l)                                    (t_7 = w8: the reverse sweep of k_sdf_grad_bf16)
 //     abar_{l-1} = W_l^T zbar_l,  zbar_l = abar_l * d_l + 100 t_l adot_l (1 - d_l)      (softplus'' = 100 d (1 - d))
 //     dW_l = sum_points zbar_l (x) a_{l-1} + (t_l d_l) (x) adot_{l-1},   db_l = sum zbar_l
-// Two kernels with COLUMN PAIRS (8 points per wave), both dumping bf16 GEMM operands in unit order
-// ([tile of 64 points][slot][unit 8][wave 8][lane 64][8]):
-//   k_sdf_fwd2_bf16: columns (value, tangent along nbar): slots 0..7 = (a_l | adot_l), slots 8..15 = softplus'(z_l) unorm16
-//   k_sdf_bwd2_bf16: columns (t, abar): consumes those, slots 0..7 = 65535 * (t_l d_l | zbar_l)
+// Two kernels with COLUMN PAIRS (8 points per wave), both dumping bf16 GEMM operands as POINT-MAJOR matrices the library
+// GEMMs read in place: [slot][2 Mp rows][256 features in unit order], Mp = 64 * tiles; rows 0..Mp-1 of a slot come from one
+// column of each pair and rows Mp.. from the other (GradCtx in mlp_bf16_core.h):
+//   k_sdf_fwd2_bf16: columns (value, tangent along nbar): slots 0..7 = [a_l; adot_l], slots 8..15 = softplus'(z_l) unorm16
+//   k_sdf_bwd2_bf16: columns (t, abar): consumes those, slots 0..7 = 65535 * [zbar_l; t_l d_l]
 // The weight-gradient GEMMs and the weight_norm chain rule are host side (autodiff.SurfaceBackward).
 // =======================================================================================
 constexpr int F2_DUMP_PER_TILE = 16 * 8 * 8 * 1024;
@@ -233,7 +234,8 @@ k_sdf_bwd2_bf16(const float* __restrict__ blob, unsigned M, const float* __restr
 // kernel dumped (k_radiance_bf16<VE, true>: f = geometry feature, r0..r3 = relu outputs, bf16 hi parts in unit
 // order) - only their signs here - and streams the transposed-weight chunks that follow the forward program in the
 // blob (packing.radiance_plan_bf16): R3^T, R2^T, R1^T, the normal rows of R0^T, the feature rows of R0^T, W8[1:]^T.
-// Dumps (bf16, unit order, same [tile][slot][unit][wave][lane] layout): delta3, delta2, delta1, delta0, g_f.
+// Dumps (bf16, point-major [slot][128 * tiles points][256 in unit order] like the forward dump): delta0 .. delta3 (in the
+// slots of the activations f, r0, r1, r2 they are multiplied with), g_f.
 // =======================================================================================
 template <int IT>
 struct NrmItems {      // the 3 normal rows of R0^T: 8 k-steps x 1 output tile from one 16 KiB chunk
@@ -319,10 +321,10 @@ k_radiance_bwd_bf16(const float* __restrict__ blob, unsigned M, const float* __r
             for (int r = 0; r < 4; ++r) A.t[T][r] = fmaf(d4[2], w2[r], fmaf(d4[1], w1[r], d4[0] * w0[r]));
         }
         Unit x0, x0n, none[1];
-        {   // unit 0 of delta3 (mask = r3, slot 4); it is also the first dumped unit (delta slot 0)
+        {   // unit 0 of delta3 (mask = r3, slot 4); it is also the first dumped unit (delta slot 3)
             const u32x4 mk = *reinterpret_cast<const u32x4*>(gc.ws + uoff(gc, 4 * 8) + gc.voff);
             x0 = masked_unit(A, 0, mk);
-            *reinterpret_cast<u32x4*>(gc.ws_out + gc.voff_out) = x0.h;
+            *reinterpret_cast<u32x4*>(gc.ws_out + uoff(gc, 3 * 8) + gc.voff_out) = x0.h;
         }
         none[0] = x0;
         d_load(gc, 4 * 8 + 1, 0);

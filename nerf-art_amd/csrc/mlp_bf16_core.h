@@ -18,7 +18,7 @@ constexpr int CHUNK_KS = 2;                         // k-steps per chunk
 constexpr int CHUNK_FLOATS = CHUNK_KS * KS_FLOATS;  // 64 KiB
 constexpr int AUX_FLOATS_MAX = 2560;
 constexpr int LDS_FLOATS = 2 * CHUNK_FLOATS + AUX_FLOATS_MAX + TAB_INTS;   // 141,824 B
-// dump / scratch sizes shared by producers and consumers (bf16 or unorm16 units of 16 B per lane: 1 KiB per wave)
+// dump sizes shared by producers and consumers (bf16 or unorm16 units of 16 B per lane)
 constexpr int RAD_DUMP_PER_TILE = 5 * 8 * 8 * 1024;      // radiance: 5 activations x 8 units x 8 waves, per 128 points
 
 struct Unit { u32x4 h, l; };                        // 32 feature slots: packed bf16 pairs, hi and lo terms
@@ -266,6 +266,8 @@ struct GradCtx {
     u32x4 dpend;              // forward sweep: finished unit, stored at the first triple of the next k-step
     char* pend_ptr;
 };
+// k_radiance_bwd_bf16's sweep position `layer` (4: R3^T .. 1: R0^T, 0: W8^T) -> slot of the delta that sweep step produces
+__device__ __forceinline__ int rad_delta_slot(int layer) { return layer > 0 ? layer - 1 : 4; }
 __device__ __forceinline__ size_t uoff(const GradCtx& gc, int idx) {
     return (size_t)(idx >> 3) * gc.slot_stride + (size_t)(idx & 7) * gc.unit_stride;
 }
@@ -394,10 +396,12 @@ struct Items {
                         gc.dpend = gc.dacc;
                         if constexpr (HM == 10) gc.dpend2 = gc.dacc2;
                         // forward sweeps (5, 8): slot = the layer that PRODUCED the activation; radiance backward (7, 9):
-                        // slot 4 - layer (deltas of R3, R2, R1, R0, then the geometry-feature cotangent)
+                        // rad_delta_slot(layer the delta is the cotangent of): the deltas of R0 .. R3 in the slots of THEIR
+                        // layers' input activations (f, r0, r1, r2), then the geometry-feature cotangent
                         const int idx = (HM == 5 || HM == 8 || HM == 10) ? (HU == 100 ? gc.layer * 8 : (gc.layer - 1) * 8 + HU)
                                         : (HM == 11)                     ? (HU == 100 ? (gc.layer - 1) * 8 : gc.layer * 8 + HU)
-                                                                         : (HU == 100 ? (5 - gc.layer) * 8 : (4 - gc.layer) * 8 + HU);
+                                                                         : (HU == 100 ? rad_delta_slot(gc.layer - 1) * 8
+                                                                                      : rad_delta_slot(gc.layer) * 8 + HU);
                         gc.pend_ptr = gc.ws_out + uoff(gc, idx);
                     }
                 }

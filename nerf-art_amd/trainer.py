@@ -80,6 +80,7 @@ class Trainer(nn.Module):
         g_all = gradient.reshape(-1, 3)
         eik_sum, n = 0.0, 0
         ab = s_val = None
+        accum = autodiff.GradAccumulator() if self.native else None     # raw GEMM results summed over patches, one flush
         if self.native and self.is_neus:
             s_val = float(self.model.forward_s().detach())
         elif self.native:
@@ -92,13 +93,14 @@ class Trainer(nn.Module):
                 depths = self._samples(o, dn, d_raw, render_kwargs) if depths_all is None else depths_all[i:i + self.pass2_rays].contiguous()
             if self.native and self.is_neus:
                 eik_sum = eik_sum + autodiff.neus_backward_samples_native(self.model, o, dn, depths, g_all[i:i + self.pass2_rays], self.w_eikonal,
-                                                                          self.use_eikonal, render_kwargs.get("white_bkgd", False), s_val=s_val)
+                                                                          self.use_eikonal, render_kwargs.get("white_bkgd", False), s_val=s_val,
+                                                                          accum=accum)
                 n += 1
                 continue
             if self.native:
                 eik_sum = eik_sum + autodiff.volsdf_backward_samples_native(self.model, o, dn, depths, g_all[i:i + self.pass2_rays],
                                                                             self.w_eikonal, self.use_eikonal,
-                                                                            render_kwargs.get("white_bkgd", False), ab=ab)
+                                                                            render_kwargs.get("white_bkgd", False), ab=ab, accum=accum)
                 n += 1
                 continue
             fn = autodiff.neus_render_samples if self.is_neus else autodiff.volsdf_render_samples
@@ -114,6 +116,8 @@ class Trainer(nn.Module):
                 out["rgb"].backward(g_all[i:i + self.pass2_rays])
             n += 1
             del out
+        if accum is not None:
+            accum.flush(self.model)
         return float(eik_sum) / max(n, 1)
 
     # ---- reconstruction-training branch (volsdf.py:784-824) -------------------------------------
@@ -163,15 +167,17 @@ class Trainer(nn.Module):
         if self.native:
             alpha, beta = m.forward_ab()
             ab = (float(alpha.detach()), float(beta.detach()))
+            accum = autodiff.GradAccumulator()
             for i in range(0, N, self.pass2_rays):
                 sl = slice(i, i + self.pass2_rays)
                 autodiff.volsdf_backward_samples_native(m, o[sl], dn[sl], depths[sl].contiguous(), g_rgb[sl], use_eikonal=False,
-                                                        white_bkgd=kw.get("white_bkgd", False), ab=ab, nbar_extra=nbar_extra[sl])
+                                                        white_bkgd=kw.get("white_bkgd", False), ab=ab, nbar_extra=nbar_extra[sl],
+                                                        accum=accum)
             with torch.no_grad():
                 pe = eikonal_points.reshape(-1, 3).float().contiguous()
-                dW, db = autodiff.surface_weight_grads(m, pe, torch.zeros(pe.shape[0], device=pe.device),
-                                                       torch.zeros(pe.shape[0], 256, device=pe.device), g_eik)
-            autodiff.accumulate_folded_grads(list(m.implicit_surface.surface_fc_layers), dW, db)
+                accum.add("surf", autodiff.surface_weight_grads_raw(m, pe, torch.zeros(pe.shape[0], device=pe.device),
+                                                                    torch.zeros(pe.shape[0], 256, device=pe.device), g_eik))
+            accum.flush(m)
         else:
             for i in range(0, N, self.pass2_rays):
                 sl = slice(i, i + self.pass2_rays)
