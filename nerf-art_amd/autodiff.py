@@ -305,13 +305,33 @@ def accumulate_folded_grads(layers, dW, db):
             l.bias.grad = g.clone() if l.bias.grad is None else l.bias.grad + g
 
 
+def _eikonal_terms(nab, R: int, P: int, w_eikonal: float, group_rays):
+    """(sum over patches of w * mean_patch((|nabla| - 1)^2), its gradient w.r.t. the nablas [R P, 3]) when the R rays of
+    one launch are `group_rays`-ray patches of the reference's pass 2 (each patch has its OWN mean; the last may be
+    ragged).  group_rays None: one patch."""
+    nn_ = nab.norm(dim=-1)
+    err = nn_ - 1.0
+    if group_rays is None or group_rays >= R:
+        return w_eikonal * (err ** 2).mean(), (w_eikonal * 2.0 / nn_.numel()) * (err / nn_)[:, None] * nab
+    wr = torch.full((R,), 1.0 / (group_rays * P), device=nab.device)
+    tail = R % group_rays
+    if tail:
+        wr[R - tail:] = 1.0 / (tail * P)
+    eik = w_eikonal * ((err ** 2).reshape(R, P).sum(1) * wr).sum()
+    coef = (2.0 * w_eikonal) * wr[:, None].expand(R, P).reshape(-1)
+    return eik, (coef * err / nn_)[:, None] * nab
+
+
 def volsdf_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikonal=0.1, use_eikonal=True, white_bkgd=False, ab=None,
-                                   nbar_extra=None, accum=None):
+                                   nbar_extra=None, accum=None, state=None, eik_group_rays=None):
     """Pass 2 of the fine-tune step for one patch, entirely on the hand-written kernels + GEMMs: accumulates into .grad what
     rgb.backward(g_rgb) and (w_eikonal * MSE(|nabla|, 1)).backward() accumulate (volsdf.py:759-770).  Returns the eikonal loss
     (a 0-d tensor: no host synchronisation in here; `ab` = (alpha, beta) as Python floats if the caller already has them).
     nbar_extra [R, P, 3]: a further cotangent of the nablas (the reconstruction branch's one-sample-per-ray eikonal term).
-    accum: a GradAccumulator shared by the patches of a step - the caller flushes it once; None: .grad is updated here."""
+    accum: a GradAccumulator shared by the patches of a step - the caller flushes it once; None: .grad is updated here.
+    state: (sdf, nablas, h7) of these points kept from pass 1 (same weights: identical values) - skips their re-evaluation.
+    eik_group_rays: the rays are several `eik_group_rays`-ray patches of the reference in one launch (the eikonal mean is
+    per patch); the returned loss is then the SUM over those patches."""
     from . import hip
     R, P = d_all.shape
     pts = (rays_o[:, None, :] + rays_dn[:, None, :] * d_all[:, :, None]).reshape(-1, 3).contiguous()
@@ -319,7 +339,7 @@ def volsdf_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikon
     surf_blob, rad_blob = model.packed()
     Rbg = model.obj_bounding_radius
     with torch.no_grad():
-        sdf, nab, h7 = hip.sdf_nabla_fwd(surf_blob, pts, Rbg, precision=model.precision_id)
+        sdf, nab, h7 = state if state is not None else hip.sdf_nabla_fwd(surf_blob, pts, Rbg, precision=model.precision_id)
         rgb_pt, dump = hip.radiance_fwd_dump(rad_blob, model.view_tiles, pts, v, nab, h7)
         if ab is None:
             alpha, beta = model.forward_ab()
@@ -332,9 +352,8 @@ def volsdf_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikon
         nbar = g_n
         eik = torch.zeros((), device=pts.device)
         if use_eikonal:
-            nn_ = nab.norm(dim=-1)
-            eik = w_eikonal * ((nn_ - 1.0) ** 2).mean()
-            nbar = nbar + (w_eikonal * 2.0 / nn_.numel()) * ((nn_ - 1.0) / nn_)[:, None] * nab
+            eik, g_eik = _eikonal_terms(nab, R, P, w_eikonal, eik_group_rays)
+            nbar = nbar + g_eik
         if nbar_extra is not None:
             nbar = nbar + nbar_extra.reshape(-1, 3)
         acc = accum if accum is not None else GradAccumulator()
@@ -346,7 +365,8 @@ def volsdf_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikon
     return eik
 
 
-def neus_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikonal=0.1, use_eikonal=True, white_bkgd=False, s_val=None, accum=None):
+def neus_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikonal=0.1, use_eikonal=True, white_bkgd=False, s_val=None, accum=None,
+                                 eik_group_rays=None):
     """Pass 2 for one NeuS patch on the hand-written kernels + GEMMs (neus.py:310-395, :520-576): SDF + nablas at the P
     samples (alpha, eikonal), SDF + nablas + radiance at the P-1 mid-points; the radiance net is frozen (neus.py:455-456).
     Returns the eikonal loss (0-d tensor)."""
@@ -368,9 +388,7 @@ def neus_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikonal
         nbar = torch.zeros_like(nab)
         eik = torch.zeros((), device=pts.device)
         if use_eikonal:
-            nn_ = nab.norm(dim=-1)
-            eik = w_eikonal * ((nn_ - 1.0) ** 2).mean()
-            nbar = (w_eikonal * 2.0 / nn_.numel()) * ((nn_ - 1.0) / nn_)[:, None] * nab
+            eik, nbar = _eikonal_terms(nab, R, P, w_eikonal, eik_group_rays)
         # samples: cotangents of sdf (alpha) and of the nablas (eikonal); mid-points: of h7 and of the normal (radiance)
         acc = accum if accum is not None else GradAccumulator()
         acc.add("surf", surface_weight_grads_raw(model, pts, g_sdf.reshape(-1), torch.zeros(pts.shape[0], 256, device=pts.device), nbar))

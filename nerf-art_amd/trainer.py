@@ -22,7 +22,8 @@ from .nets import NeuS, VolSDF
 
 
 class Trainer(nn.Module):
-    def __init__(self, model, w_eikonal: float = 0.1, use_eikonal: bool = True, pass2_rays: int = 1200, native: bool = None):
+    def __init__(self, model, w_eikonal: float = 0.1, use_eikonal: bool = True, pass2_rays: int = 1200, native: bool = None,
+                 patches_per_launch: int = 4):
         super().__init__()
         if not isinstance(model, (VolSDF, NeuS)):
             raise TypeError("Trainer expects a nerfart_amd VolSDF or NeuS model")
@@ -32,6 +33,10 @@ class Trainer(nn.Module):
         # native: pass 2 entirely on the hand-written kernels + GEMMs (VolSDF, split-bf16 blobs); otherwise autograd over
         # the per-sample networks with the native compositing / radiance kernels where available
         self.native = (model.precision == "bf16x3") if native is None else native
+        # native pass 2: this many of the reference's pass2_rays-ray patches share one set of kernel launches (the per-patch
+        # eikonal means are kept); bounded by the kernels' 2^21 points per launch
+        self.patches_per_launch = patches_per_launch
+        self._kept = None
         if self.is_neus:                       # neus.py:455-456: only the SDF net (and ln_s) is fine-tuned
             for p in model.radiance_net.parameters():
                 p.requires_grad_(False)
@@ -71,40 +76,102 @@ class Trainer(nn.Module):
         d_coarse = (near * (1.0 - t) + far * t)[None, :].expand(o.shape[0], ns)
         return torch.sort(torch.cat([d_coarse, d_fine], dim=-1), dim=-1)[0]
 
-    def backward_patches(self, rays_o, rays_d, gradient, depths_all=None, **render_kwargs):
+    def _launch_rays(self, P: int) -> int:
+        k = max(1, min(self.patches_per_launch, (1 << 21) // max(self.pass2_rays * P, 1)))
+        return self.pass2_rays * k
+
+    @torch.no_grad()
+    def render_keep(self, rays_o, rays_d, **rk):
+        """Pass 1 of the native VolSDF fine-tune step, on the per-stage C-ABI entries in the fused renderer's order (sampler,
+        k_sdf_grad, radiance, composite), KEEPING every launch group's sample depths, sdf, nablas and layer-7 activations
+        (1 KiB / point in HBM) for pass 2: the weights do not change between the passes and perturb=False is
+        deterministic, so pass 2 would recompute exactly these.  Returns rgb [N, 3]; the state waits in self._kept."""
+        m = self.model
+        o = rays_o.reshape(-1, 3).float().contiguous()
+        d_raw = rays_d.reshape(-1, 3).float().contiguous()
+        surf_blob, rad_blob = m.packed()
+        alpha, beta = m.forward_ab()
+        ab = (float(alpha.detach()), float(beta.detach()))
+        white = rk.get("white_bkgd", False)
+        P = rk.get("N_samples", 128) + rk.get("N_importance", 64)
+        step = self._launch_rays(P)
+        kept, rgbs = [], []
+        for i in range(0, o.shape[0], step):
+            oi, di = o[i:i + step], d_raw[i:i + step]
+            dn = F.normalize(di, dim=-1)
+            depths = self._samples(oi, dn, di, rk)
+            R = oi.shape[0]
+            pts = (oi[:, None, :] + dn[:, None, :] * depths[:, :, None]).reshape(-1, 3).contiguous()
+            v = dn[:, None, :].expand(R, P, 3).reshape(-1, 3).contiguous()
+            sdf, nab, h7 = hip.sdf_nabla_fwd(surf_blob, pts, m.obj_bounding_radius, precision=m.precision_id)
+            rgb_pt = hip.radiance_fwd(rad_blob, m.view_tiles, pts, v, nab, h7, precision=m.precision_id)
+            rgb, _, _ = hip.volsdf_composite(depths, sdf.reshape(R, P), rgb_pt.reshape(R, P, 3), ab[0], ab[1], white)
+            kept.append((depths, sdf, nab, h7))
+            rgbs.append(rgb)
+        self._kept = kept
+        return torch.cat(rgbs, 0) if rgbs else torch.zeros(0, 3, device=o.device)
+
+    def backward_patches(self, rays_o, rays_d, gradient, depths_all=None, kept=None, **render_kwargs):
         """Pass 2: accumulates parameter gradients for d loss / d rgb = `gradient` [N, 3] (+ the eikonal term).
-        depths_all [N, P]: sample depths from pass 1 (skips the re-sampling).  Returns the mean eikonal loss over the
-        patches (what the reference prints)."""
+        depths_all [N, P]: sample depths from pass 1 (skips the re-sampling); kept: render_keep's per-group state of
+        exactly these rays (skips the SDF re-evaluation too).  Returns the mean eikonal loss over the reference's
+        pass2_rays-ray patches (what the reference prints)."""
         o_all = rays_o.reshape(-1, 3).float().contiguous()
         d_all_ = rays_d.reshape(-1, 3).float().contiguous()
         g_all = gradient.reshape(-1, 3)
+        N = o_all.shape[0]
+        white = render_kwargs.get("white_bkgd", False)
         eik_sum, n = 0.0, 0
-        ab = s_val = None
-        accum = autodiff.GradAccumulator() if self.native else None     # raw GEMM results summed over patches, one flush
-        if self.native and self.is_neus:
-            s_val = float(self.model.forward_s().detach())
-        elif self.native:
-            alpha, beta = self.model.forward_ab()
-            ab = (float(alpha.detach()), float(beta.detach()))
-        for i in range(0, o_all.shape[0], self.pass2_rays):
+        if self.native:
+            accum = autodiff.GradAccumulator()                    # raw GEMM results summed over patches, flushed once
+            ab = s_val = None
+            if self.is_neus:
+                s_val = float(self.model.forward_s().detach())
+                P = render_kwargs.get("N_samples", 64) + render_kwargs.get("N_importance", 64)
+            else:
+                alpha, beta = self.model.forward_ab()
+                ab = (float(alpha.detach()), float(beta.detach()))
+                P = render_kwargs.get("N_samples", 128) + render_kwargs.get("N_importance", 64)
+            if kept is not None:
+                bounds, i = [], 0
+                for grp in kept:
+                    bounds.append((i, i + grp[0].shape[0]))
+                    i += grp[0].shape[0]
+                if i != N:
+                    raise ValueError("backward_patches: the kept pass-1 state does not cover these rays")
+            else:
+                step = self._launch_rays(P)
+                bounds = [(i, min(i + step, N)) for i in range(0, N, step)]
+            for gi, (i0, i1) in enumerate(bounds):
+                o, d_raw, g = o_all[i0:i1], d_all_[i0:i1], g_all[i0:i1]
+                dn = F.normalize(d_raw, dim=-1)
+                state = None
+                if kept is not None:
+                    depths, state = kept[gi][0], kept[gi][1:]
+                    kept[gi] = None                                # release the group's state as soon as it is consumed
+                elif depths_all is not None:
+                    depths = depths_all[i0:i1].contiguous()
+                else:
+                    with torch.no_grad():
+                        depths = self._samples(o, dn, d_raw, render_kwargs)
+                if self.is_neus:
+                    eik = autodiff.neus_backward_samples_native(self.model, o, dn, depths, g, self.w_eikonal, self.use_eikonal, white,
+                                                                s_val=s_val, accum=accum, eik_group_rays=self.pass2_rays)
+                else:
+                    eik = autodiff.volsdf_backward_samples_native(self.model, o, dn, depths, g, self.w_eikonal, self.use_eikonal, white,
+                                                                  ab=ab, accum=accum, state=state, eik_group_rays=self.pass2_rays)
+                eik_sum = eik_sum + eik
+                n += -(-(i1 - i0) // self.pass2_rays)
+                del state
+            accum.flush(self.model)
+            return float(eik_sum) / max(n, 1)
+        for i in range(0, N, self.pass2_rays):
             o, d_raw = o_all[i:i + self.pass2_rays], d_all_[i:i + self.pass2_rays]
             dn = F.normalize(d_raw, dim=-1)
             with torch.no_grad():
                 depths = self._samples(o, dn, d_raw, render_kwargs) if depths_all is None else depths_all[i:i + self.pass2_rays].contiguous()
-            if self.native and self.is_neus:
-                eik_sum = eik_sum + autodiff.neus_backward_samples_native(self.model, o, dn, depths, g_all[i:i + self.pass2_rays], self.w_eikonal,
-                                                                          self.use_eikonal, render_kwargs.get("white_bkgd", False), s_val=s_val,
-                                                                          accum=accum)
-                n += 1
-                continue
-            if self.native:
-                eik_sum = eik_sum + autodiff.volsdf_backward_samples_native(self.model, o, dn, depths, g_all[i:i + self.pass2_rays],
-                                                                            self.w_eikonal, self.use_eikonal,
-                                                                            render_kwargs.get("white_bkgd", False), ab=ab, accum=accum)
-                n += 1
-                continue
             fn = autodiff.neus_render_samples if self.is_neus else autodiff.volsdf_render_samples
-            out = fn(self.model, o, dn, depths, white_bkgd=render_kwargs.get("white_bkgd", False))
+            out = fn(self.model, o, dn, depths, white_bkgd=white)
             if self.use_eikonal:
                 # the reference calls rgb.backward(g, retain_graph=True) and then eikonal.backward(): the same sum of
                 # gradients from ONE traversal of the (double-backward) graph of the SDF net
@@ -116,8 +183,6 @@ class Trainer(nn.Module):
                 out["rgb"].backward(g_all[i:i + self.pass2_rays])
             n += 1
             del out
-        if accum is not None:
-            accum.flush(self.model)
         return float(eik_sum) / max(n, 1)
 
     # ---- reconstruction-training branch (volsdf.py:784-824) -------------------------------------
@@ -197,11 +262,21 @@ class Trainer(nn.Module):
         loss on the full image and keeps its own rays' d loss / d rgb; pass 2 runs on its own rays; one flat
         all-reduce(SUM) of the gradients before the caller's optimizer.step()."""
         sharded = nd.world_size() > 1
+        keep = self.native and not self.is_neus           # pass 1 on the staged entries, its per-point state kept for pass 2
+        self._kept = None
         if sharded:
             kw = {k: v for k, v in render_kwargs.items() if k != "rayschunk"}
-            rgb = nd.render_sharded(render_fn, rays_o.reshape(1, -1, 3), rays_d.reshape(1, -1, 3), keys=("rgb",), tile=tile,
+            if keep:
+                def fn(ro, rd, **kw_):
+                    r = self.render_keep(ro, rd, **kw_)
+                    return r, None, {"rgb": r[None]}
+            else:
+                fn = render_fn
+            rgb = nd.render_sharded(fn, rays_o.reshape(1, -1, 3), rays_d.reshape(1, -1, 3), keys=("rgb",), tile=tile,
                                     detailed_output=False, require_nablas=True, calc_normal=True, **kw)["rgb"]
             depths_all = None
+        elif keep:
+            rgb, depths_all = self.render_keep(rays_o, rays_d, **render_kwargs), None
         else:
             rgb, depths_all = self.render_image(render_fn, rays_o, rays_d, want_depths=True, **render_kwargs)
         rgb = rgb.detach().reshape(1, -1, 3).requires_grad_(True)
@@ -214,12 +289,14 @@ class Trainer(nn.Module):
             optimizer.zero_grad()
         if sharded:
             idx = nd.my_ray_indices(rgb.shape[1], tile, nd.rank(), nd.world_size(), rgb.device)
-            eik = self.backward_patches(rays_o.reshape(-1, 3)[idx], rays_d.reshape(-1, 3)[idx], gradient[0][idx], **render_kwargs)
+            eik = self.backward_patches(rays_o.reshape(-1, 3)[idx], rays_d.reshape(-1, 3)[idx], gradient[0][idx], kept=self._kept,
+                                        **render_kwargs)
             # ranks that own fewer parameters' gradients than others (none here: every rank touches every tensor)
             for p in self.model.parameters():
                 if p.requires_grad and p.grad is None:
                     p.grad = torch.zeros_like(p)
             nd.allreduce_gradients([p for p in self.model.parameters() if p.requires_grad])
         else:
-            eik = self.backward_patches(rays_o, rays_d, gradient[0], depths_all=depths_all, **render_kwargs)
+            eik = self.backward_patches(rays_o, rays_d, gradient[0], depths_all=depths_all, kept=self._kept, **render_kwargs)
+        self._kept = None
         return {"loss": float(loss.detach()), "eikonal": eik, "rgb": rgb.detach()}

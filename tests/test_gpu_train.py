@@ -309,3 +309,36 @@ def test_reconstruction_step_native_matches_autograd_and_descends():
         opt.step()
         hist.append(out["loss_img"])
     assert hist[-1] < hist[0], hist
+
+
+def test_pass1_state_reuse_matches_recompute():
+    """render_keep (staged pass 1 that keeps depths / sdf / nablas / h7 per launch group) renders what the fused renderer
+    renders, and pass 2 from the kept state accumulates the gradients pass 2 accumulates when it re-samples and
+    re-evaluates; several reference patches per launch group (with a ragged tail) keep their per-patch eikonal means."""
+    from nerfart_amd import scene, rend_util
+    from nerfart_amd.trainer import Trainer
+    model, rk, render_fn = scene.build_model("VolSDF", seed=0, beta=0.01, device=DEV, precision="bf16x3")
+    H, W = 10, 7
+    c2w, K = scene.camera(H, W)
+    o, d, _ = rend_util.get_rays(c2w[None].to(DEV), K[None].to(DEV), H, W)
+    g = torch.rand(H * W, 3, generator=torch.Generator().manual_seed(5)).to(DEV) * 1e-2
+    kw = {k: v for k, v in rk.items() if k != "rayschunk"}
+    with torch.no_grad():
+        ref_rgb, _, _ = render_fn(o, d, detailed_output=False, require_nablas=True, calc_normal=True, **kw)
+    res, eiks = {}, {}
+    for mode in ("patchwise", "grouped", "kept"):
+        tr = Trainer(model, pass2_rays=16, patches_per_launch=1 if mode == "patchwise" else 3)
+        model.zero_grad()
+        kept = None
+        if mode == "kept":
+            rgb = tr.render_keep(o[0], d[0], **kw)
+            np.testing.assert_allclose(rgb.cpu().numpy(), ref_rgb.reshape(-1, 3).cpu().numpy(), atol=2e-4, rtol=0)
+            kept = tr._kept
+            assert [k[0].shape[0] for k in kept] == [48, 22]
+        eiks[mode] = tr.backward_patches(o[0], d[0], g, kept=kept, **kw)
+        res[mode] = {n: p.grad.clone() for n, p in model.named_parameters()}
+    for mode in ("grouped", "kept"):
+        assert abs(eiks[mode] - eiks["patchwise"]) <= 1e-5 * abs(eiks["patchwise"]) + 1e-9, (mode, eiks)
+        for name, ref in res["patchwise"].items():
+            rel = float((res[mode][name] - ref).norm() / (ref.norm() + 1e-12))
+            assert rel < 2e-3, (mode, name, rel)                  # bf16 operands of the GEMMs are summed in a different order
