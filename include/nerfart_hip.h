@@ -70,12 +70,14 @@ int nerfart_radiance_fwd_rays(const float* rad_blob, int precision, int view_til
                               const float* nabla, const float* h7, float* rgb_out, void* stream);
 
 /* ---- B2 "bwd", radiance half (row a19; split-bf16 blobs only).  nerfart_radiance_fwd_dump = nerfart_radiance_fwd
- * that also writes the activations of the five layers (geometry feature, four ReLU outputs; bf16, in the kernels'
- * unit order: [tile of 128 points][5][unit 8][wave 8][lane 64][8]) into `dump` (nerfart_radiance_dump_bytes(M) bytes).
+ * that also writes the activations of the five layers (geometry feature f, four ReLU outputs r0..r3) into `dump`
+ * (nerfart_radiance_dump_bytes(M) bytes): a bf16 matrix [5][Mp][256], Mp = M rounded up to 128, rows = points, the 256
+ * features in the kernels' unit order (nerf-art_amd/packing.py: unit_feature_hidden) - GEMM operands, read in place.
  * nerfart_radiance_bwd: d loss / d rgb[M,3] -> g_h7[M,256] (cotangent of the SDF net's layer-7 activation through the
  * geometry-feature rows), g_n[M,3] (cotangent of the normal input), and bwd_dump (same layout: the deltas of
- * R3, R2, R1, R0 and the geometry-feature cotangent) - the operands of the weight-gradient GEMMs
- * (dW_l = delta_l^T act_{l-1}, plain library GEMMs; see nerf-art_amd/autodiff.py:RadianceNetFn). */
+ * R0, R1, R2, R3 - each in the slot of the activation it multiplies - and the geometry-feature cotangent): the operands
+ * of the weight-gradient GEMMs (dW_l = delta_l^T act_{l-1}, plain library GEMMs; nerf-art_amd/autodiff.py).
+ * At most 2^21 points per call. */
 long long nerfart_radiance_dump_bytes(long long M);
 int nerfart_radiance_fwd_dump(const float* rad_blob, int view_tiles, const float* pts, const float* view, long long M,
                               const float* nabla, const float* h7, float* rgb_out, void* dump, void* stream);
@@ -86,10 +88,13 @@ int nerfart_radiance_bwd(const float* rad_blob, long long M, const float* rgb, c
  *        sbar * sdf + hbar7 . h7 + nbar . grad_x sdf        (what rgb.backward + eikonal.backward ask of the SDF net,
  * volsdf.py:766-770, through ImplicitSurface.forward_with_nablas' create_graph=True, base.py:272-279) need, per layer,
  * the operands of  dW_l = sum_p zbar_l (x) a_{l-1} + (t_l d_l) (x) adot_{l-1}  (see csrc/mlp_chain_bf16.hip):
- *   nerfart_sdf_fwd2: pts[M,3], dir[M,3] = nbar -> f2_dump: (a_l | adot_l) bf16 and softplus'(z_l) unorm16, l = 0..7
- *   nerfart_sdf_bwd2: gbar_h7[M,256], gbar_sdf[M], f2_dump -> r2_dump: 65535 * (t_l d_l | zbar_l) bf16, l = 0..7
- * (unit order, [tile of 64 points][slot][unit 8][wave 8][lane 64][8]; even lanes = first, odd lanes = second column).
- * The GEMMs and the weight_norm chain rule are host side (nerf-art_amd/autodiff.py: surface_weight_grads). */
+ *   nerfart_sdf_fwd2: pts[M,3], dir[M,3] = nbar -> f2_dump: [a_l; adot_l] bf16 (slots l = 0..7) and softplus'(z_l) unorm16
+ *                     (slots 8 + l)
+ *   nerfart_sdf_bwd2: gbar_h7[M,256], gbar_sdf[M], f2_dump -> r2_dump: 65535 * [zbar_l; t_l d_l] bf16, l = 0..7
+ * Both dumps are matrices [slot][2 Mp][256], Mp = M rounded up to 64: rows 0..Mp-1 of a slot hold the first, rows Mp..
+ * the second quantity of the pair, per point; features in unit order; so dW_l is ONE GEMM over the stacked rows, read in
+ * place.  At most 2^21 points per call.
+ * The GEMMs and the weight_norm chain rule are host side (nerf-art_amd/autodiff.py: surface_weight_grads_raw / _finish). */
 long long nerfart_sdf_fwd2_dump_bytes(long long M);
 long long nerfart_sdf_bwd2_dump_bytes(long long M);
 int nerfart_sdf_fwd2(const float* surf_blob, const float* pts, const float* dir, long long M, void* f2_dump, void* stream);
