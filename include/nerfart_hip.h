@@ -115,28 +115,30 @@ int nerfart_linspace_depths(const float* t_dev, int n, const float* near, const 
  * utils/rend_util.py sample_pdf :256-293, sample_cdf :295-328).  Exposed one by one for parity tests;
  * nerfart_volsdf_fine_sample chains them. */
 int nerfart_volsdf_first_check(int n_rays, int n, int cap, int n_final, float eps, float alpha_net, float beta_net,
-                               const float* dA, const float* sA, const float* u_final, float beta_plus0_denom,
-                               const float* far, float far_s, float* d_fine, float* beta_plus, float* beta_map,
-                               float* iter_usage, int* act_out, int* act_count, void* stream);
+                               const float* dA, const float* sA, const float* u_final, int u_final_stride,
+                               float beta_plus0_denom, const float* far, float far_s, float* d_fine, float* beta_plus,
+                               float* beta_map, float* iter_usage, int* act_out, int* act_count, void* stream);
 int nerfart_volsdf_upsample(int n_active, int n, int cap, int n_up, const float* dA, const float* sA, const int* act,
                             const float* beta_plus, const float* u_up, int clamp_bounds, float* d_new, void* stream);
 int nerfart_volsdf_merge_check(int n_active, int n, int cap, int n_up, int n_final, int max_bisect, int it, float eps,
                                float alpha_net, float beta_net, const float* dA, const float* sA, float* dB, float* sB,
                                const int* act, const float* d_new, const float* s_new, const float* u_final,
-                               float* d_fine, float* beta_plus, float* beta_map, float* iter_usage, int* act_out,
-                               int* act_count, void* stream);
+                               int u_final_stride, float* d_fine, float* beta_plus, float* beta_map, float* iter_usage,
+                               int* act_out, int* act_count, void* stream);
 int nerfart_volsdf_finalize(int n_active, int n, int cap, int n_final, const float* dA, const float* sA, const int* act,
-                            const float* u_final, const float* beta_plus, float* d_fine, float* beta_map,
-                            float* iter_usage, void* stream);
+                            const float* u_final, int u_final_stride, const float* beta_plus, float* d_fine,
+                            float* beta_map, float* iter_usage, void* stream);
 long long nerfart_volsdf_sampler_workspace_bytes(int n_rays, int n_init, int n_up, int n_final, int max_iter);
 int nerfart_volsdf_fine_sample(const float* surf_blob, int precision, const float* rays_o, const float* rays_dn, int n_rays,
                                const float* near, const float* far, float near_s, float far_s, float R_bg,
                                float alpha_net, float beta_net, float eps, int n_init, int n_up, int n_final,
                                int max_iter, int max_bisect, const float* t_init_dev, const float* u_up_dev,
-                               const float* u_final_dev, float* d_fine, float* beta_map, float* iter_usage,
-                               void* workspace, long long workspace_bytes, void* stream);
+                               const float* u_final_dev, int u_final_per_ray, float* d_fine, float* beta_map,
+                               float* iter_usage, void* workspace, long long workspace_bytes, void* stream);
 /* t_init_dev / u_up_dev / u_final_dev: device copies of torch.linspace(0,1,n) for n = n_init, n_up+2, n_final
- * (the reference's tables, volsdf.py:483, rend_util.py:269,304); all three NULL -> nerfart_linspace is used. */
+ * (the reference's tables, volsdf.py:483, rend_util.py:269,304); all three NULL -> nerfart_linspace is used.
+ * u_final_per_ray != 0 (perturb=True: sample_cdf(det=False), rend_util.py:306-307): u_final_dev is [n_rays, n_final], the
+ * caller's uniform random numbers, a row per ray (u_final_stride = n_final in the stage entry points; 0 = shared table). */
 
 /* out[r] = sort(cat(a[r, :na], b[r, :nb]))  (volsdf.py:501-502) */
 int nerfart_sort_concat(int n_rays, const float* a, int na, int a_stride, const float* b, int nb, int b_stride,
@@ -167,8 +169,8 @@ int nerfart_volsdf_render_fwd(const float* surf_blob, const float* rad_blob, int
                               const float* rays_d, int n_rays, float near_s, float far_s, float R_bg, float alpha,
                               float beta, float eps, int n_samples, int n_importance, int max_upsample_steps,
                               int max_bisection_steps, int white_bkgd, int k3_rays_chunk, const float* t_coarse_dev,
-                              const float* t_init_dev, const float* u_up_dev, const float* u_final_dev, float* rgb,
-                              float* depth, float* acc, float* normals, float* d_all_out, float* sdf_out, float* nabla_out,
+                              const float* t_init_dev, const float* u_up_dev, const float* u_final_dev, int u_final_per_ray,
+                              float* rgb, float* depth, float* acc, float* normals, float* d_all_out, float* sdf_out, float* nabla_out,
                               float* radiance_out, float* sigma_out, float* p_out, float* tau_out, float* beta_map_out,
                               float* iter_usage_out, void* workspace, long long workspace_bytes, void* stream);
 
@@ -177,7 +179,7 @@ int nerfart_volsdf_render_fwd(const float* surf_blob, const float* rad_blob, int
 int nerfart_near_far_from_sphere(const float* rays_o, const float* rays_dn, int n_rays, float r, float* near,
                                  float* far, void* stream);
 int nerfart_neus_upsample_step(int n_rays, int n, int cap, int n_new, float inv_s, const float* d, const float* sdf,
-                               const float* u_new, float* d_new, void* stream);
+                               const float* u_new, int u_new_stride, float* d_new, void* stream);
 int nerfart_merge_sorted_pairs(int n_rays, int n, int cap, int n_new, float* d, float* sdf, const float* d_new,
                                const float* s_new, void* stream);
 int nerfart_neus_composite(int n_rays, int P, const float* d_all, const float* sdf, const float* radiance_mid,
@@ -188,10 +190,13 @@ long long nerfart_neus_render_workspace_bytes(int n_rays, int n_samples, int n_i
 int nerfart_neus_render_fwd(const float* surf_blob, const float* rad_blob, int precision, int view_tiles, const float* rays_o,
                             const float* rays_d, int n_rays, float obj_bounding_radius, float s, int n_samples,
                             int n_importance, int n_upsample_iters, int white_bkgd, int k3_rays_chunk,
-                            const float* t_coarse_dev, const float* u_new_dev, float* rgb,
+                            const float* t_coarse_dev, const float* u_new_dev, int u_new_per_ray, float* rgb,
                             float* depth, float* acc, float* normals, float* d_all_out, float* sdf_out,
                             float* nabla_out, float* radiance_out, float* cdf_out, float* alpha_out, float* w_out,
                             float* d_mid_out, void* workspace, long long workspace_bytes, void* stream);
+/* u_new_per_ray != 0 (perturb=True: sample_pdf(det=False), rend_util.py:269-272): u_new_dev is [n_rays, n_importance], the
+ * caller's uniform random numbers - up-sampling round i uses columns [i * n_new, (i + 1) * n_new); 0: the shared
+ * linspace(0, 1, n_new) table (u_new_dev [n_new] or NULL). */
 
 #ifdef __cplusplus
 }

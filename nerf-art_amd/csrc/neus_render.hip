@@ -31,9 +31,10 @@ __global__ void k_midpoints(const float* __restrict__ d, int P, int n_rays, floa
 // sigmoid CDF with fixed inv_s, alpha -> visibility weights, n_new inverse-CDF samples.
 __global__ void __launch_bounds__(64)
 k_neus_upsample(int n, int cap, int n_new, float inv_s, const float* __restrict__ dA, const float* __restrict__ sA,
-                const float* __restrict__ u_new, float* __restrict__ d_new) {
+                const float* __restrict__ u_new, int u_new_stride, float* __restrict__ d_new) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int ray = blockIdx.x, lane = threadIdx.x;
+    u_new += (size_t)ray * u_new_stride;            // 0: the shared linspace table (det); else this ray's random numbers
     float* d = sm; float* s = sm + n; float* w = sm + 2 * n; float* cdf = sm + 3 * n; float* out = sm + 4 * n;
     for (int i = lane; i < n; i += 64) { d[i] = dA[(size_t)ray * cap + i]; s[i] = sA[(size_t)ray * cap + i]; }
     __syncthreads();
@@ -188,13 +189,13 @@ int nerfart_near_far_from_sphere(const float* rays_o, const float* rays_dn, int 
 }
 
 int nerfart_neus_upsample_step(int n_rays, int n, int cap, int n_new, float inv_s, const float* d, const float* sdf,
-                               const float* u_new, float* d_new, void* stream) {
+                               const float* u_new, int u_new_stride, float* d_new, void* stream) {
     if (n_rays <= 0) return 0;
     if (n_new > 64 && (n_new & (n_new - 1))) { set_last_error("neus upsample: n_new must be <= 64 or a power of two"); return 2; }
     const int npad = n_new < 64 ? 64 : n_new;
     const size_t lds = ((size_t)4 * n + npad) * sizeof(float);
     if (int rc = set_lds_n((const void*)k_neus_upsample, lds)) return rc;
-    hipLaunchKernelGGL(k_neus_upsample, dim3(n_rays), dim3(64), lds, (hipStream_t)stream, n, cap, n_new, inv_s, d, sdf, u_new, d_new);
+    hipLaunchKernelGGL(k_neus_upsample, dim3(n_rays), dim3(64), lds, (hipStream_t)stream, n, cap, n_new, inv_s, d, sdf, u_new, u_new_stride, d_new);
     NERFART_HIP(hipGetLastError());
     return 0;
 }
@@ -261,7 +262,7 @@ long long nerfart_neus_render_workspace_bytes(int n_rays, int n_samples, int n_i
 int nerfart_neus_render_fwd(const float* surf_blob, const float* rad_blob, int precision, int view_tiles, const float* rays_o,
                             const float* rays_d, int n_rays, float obj_bounding_radius, float s, int n_samples,
                             int n_importance, int n_upsample_iters, int white_bkgd, int k3_rays_chunk,
-                            const float* t_coarse_dev, const float* u_new_dev, float* rgb,
+                            const float* t_coarse_dev, const float* u_new_dev, int u_new_per_ray, float* rgb,
                             float* depth, float* acc, float* normals, float* d_all_out, float* sdf_out,
                             float* nabla_out, float* radiance_out, float* cdf_out, float* alpha_out, float* w_out,
                             float* d_mid_out, void* workspace, long long workspace_bytes, void* stream_) {
@@ -271,6 +272,7 @@ int nerfart_neus_render_fwd(const float* surf_blob, const float* rad_blob, int p
         set_last_error("neus render: bad sample counts"); return 2;
     }
     const int P = n_samples + n_importance, n_new = n_importance / n_upsample_iters;
+    if (u_new_per_ray && !u_new_dev) { set_last_error("neus render: u_new_per_ray needs u_new_dev [n_rays, n_importance]"); return 2; }
     neus_ws_t w;
     const size_t need = carve_neus((char*)workspace, n_rays, n_samples, n_importance, k3_rays_chunk, &w);
     if (!workspace || (size_t)workspace_bytes < need) { set_last_error("neus render: workspace too small"); return 2; }
@@ -289,6 +291,7 @@ int nerfart_neus_render_fwd(const float* surf_blob, const float* rad_blob, int p
         hipError_t e3 = hipStreamSynchronize(stream);
         free(h);
         NERFART_HIP(e1); NERFART_HIP(e2); NERFART_HIP(e3);
+        if (u_new_per_ray) w.u_new = const_cast<float*>(u_new_dev);
     }
     if (int rc = nerfart_normalize_dirs(rays_d, w.rays_dn, n_rays, stream)) return rc;
     if (int rc = nerfart_near_far_from_sphere(rays_o, w.rays_dn, n_rays, obj_bounding_radius, w.near, w.far, stream)) return rc;
@@ -296,7 +299,9 @@ int nerfart_neus_render_fwd(const float* surf_blob, const float* rad_blob, int p
     if (int rc = nerfart_sdf_fwd_rays(surf_blob, precision, rays_o, w.rays_dn, nullptr, w.d, n_rays, n_samples, P, 0.f, w.s, P, stream)) return rc;
     int n = n_samples;
     for (int i = 0; i < n_upsample_iters; ++i) {
-        if (int rc = nerfart_neus_upsample_step(n_rays, n, P, n_new, 64.f * (float)(1 << i), w.d, w.s, w.u_new, w.d_new, stream)) return rc;
+        if (int rc = nerfart_neus_upsample_step(n_rays, n, P, n_new, 64.f * (float)(1 << i), w.d, w.s,
+                                                u_new_per_ray ? w.u_new + (size_t)i * n_new : w.u_new, u_new_per_ray ? n_importance : 0,
+                                                w.d_new, stream)) return rc;
         if (int rc = nerfart_sdf_fwd_rays(surf_blob, precision, rays_o, w.rays_dn, nullptr, w.d_new, n_rays, n_new, n_new, 0.f, w.s_new, n_new, stream)) return rc;
         if (int rc = nerfart_merge_sorted_pairs(n_rays, n, P, n_new, w.d, w.s, w.d_new, w.s_new, stream)) return rc;
         n += n_new;

@@ -24,6 +24,7 @@ struct SamplerParams {
     int it;           // round number written to iter_usage on convergence
     float eps;
     float alpha_net, beta_net;
+    int u_final_stride;   // 0: one shared table u_final[n_final] (det = True: linspace); n_final: a row per ray (perturb: rand)
 };
 
 // d = near * (1 - t) + far * t with the reference's three roundings (volsdf.py:474, :484)
@@ -74,7 +75,7 @@ k_first_check(SamplerParams P, const float* __restrict__ dA, const float* __rest
     if (!(mx > P.eps)) {
         opacity_cdf(d, s, P.n, P.alpha_net, P.beta_net, cdf);
         __syncthreads();
-        emit_final_samples(d, cdf, P.n, u_final, P.n_final, d_fine + (size_t)ray * P.n_final);
+        emit_final_samples(d, cdf, P.n, u_final + (size_t)ray * P.u_final_stride, P.n_final, d_fine + (size_t)ray * P.n_final);
         if (threadIdx.x == 0) { iter_usage[ray] = 0.f; beta_map[ray] = P.beta_net; }
     } else if (threadIdx.x == 0) {
         beta_plus[ray] = sqrtf((fr * fr) / beta_plus0_denom);           // volsdf.py:149
@@ -152,7 +153,7 @@ k_merge_check(SamplerParams P, const float* __restrict__ dA, const float* __rest
         float* cdf = d_old;                      // old copies are dead; n + nu <= 2n + 2nu floats available
         opacity_cdf(d, s, nm, P.alpha_net, P.beta_net, cdf);
         __syncthreads();
-        emit_final_samples(d, cdf, nm, u_final, P.n_final, d_fine + (size_t)ray * P.n_final);
+        emit_final_samples(d, cdf, nm, u_final + (size_t)ray * P.u_final_stride, P.n_final, d_fine + (size_t)ray * P.n_final);
         if (threadIdx.x == 0) { iter_usage[ray] = (float)P.it; beta_map[ray] = P.beta_net; }
     } else {
         float hi = beta_plus[ray], lo = P.beta_net;
@@ -184,7 +185,7 @@ k_finalize_unconverged(SamplerParams P, const float* __restrict__ dA, const floa
     const float bp = beta_plus[ray];
     opacity_cdf(d, s, n, 1.f / bp, bp, cdf);
     __syncthreads();
-    emit_final_samples(d, cdf, n, u_final, P.n_final, d_fine + (size_t)ray * P.n_final);
+    emit_final_samples(d, cdf, n, u_final + (size_t)ray * P.u_final_stride, P.n_final, d_fine + (size_t)ray * P.n_final);
     if (threadIdx.x == 0) { iter_usage[ray] = -1.f; beta_map[ray] = bp; }
 }
 
@@ -313,11 +314,11 @@ static int set_lds(const void* k, size_t bytes) {
 }
 
 int nerfart_volsdf_first_check(int n_rays, int n, int cap, int n_final, float eps, float alpha_net, float beta_net,
-                               const float* dA, const float* sA, const float* u_final, float beta_plus0_denom,
-                               const float* far, float far_s, float* d_fine, float* beta_plus, float* beta_map,
-                               float* iter_usage, int* act_out, int* act_count, void* stream) {
+                               const float* dA, const float* sA, const float* u_final, int u_final_stride,
+                               float beta_plus0_denom, const float* far, float far_s, float* d_fine, float* beta_plus,
+                               float* beta_map, float* iter_usage, int* act_out, int* act_count, void* stream) {
     if (n_rays <= 0) return 0;
-    SamplerParams P{n, cap, 0, n_final, 0, 0, eps, alpha_net, beta_net};
+    SamplerParams P{n, cap, 0, n_final, 0, 0, eps, alpha_net, beta_net, u_final_stride};
     const size_t lds = (size_t)3 * n * sizeof(float);
     if (int rc = set_lds((const void*)k_first_check, lds)) return rc;
     hipLaunchKernelGGL(k_first_check, dim3(n_rays), dim3(64), lds, (hipStream_t)stream, P, dA, sA, u_final,
@@ -342,10 +343,10 @@ int nerfart_volsdf_upsample(int n_active, int n, int cap, int n_up, const float*
 int nerfart_volsdf_merge_check(int n_active, int n, int cap, int n_up, int n_final, int max_bisect, int it, float eps,
                                float alpha_net, float beta_net, const float* dA, const float* sA, float* dB, float* sB,
                                const int* act, const float* d_new, const float* s_new, const float* u_final,
-                               float* d_fine, float* beta_plus, float* beta_map, float* iter_usage, int* act_out,
-                               int* act_count, void* stream) {
+                               int u_final_stride, float* d_fine, float* beta_plus, float* beta_map, float* iter_usage,
+                               int* act_out, int* act_count, void* stream) {
     if (n_active <= 0) return 0;
-    SamplerParams P{n, cap, n_up, n_final, max_bisect, it, eps, alpha_net, beta_net};
+    SamplerParams P{n, cap, n_up, n_final, max_bisect, it, eps, alpha_net, beta_net, u_final_stride};
     const size_t lds = ((size_t)4 * n + 4 * n_up) * sizeof(float);
     if (int rc = set_lds((const void*)k_merge_check, lds)) return rc;
     hipLaunchKernelGGL(k_merge_check, dim3(n_active), dim3(64), lds, (hipStream_t)stream, P, dA, sA, dB, sB, act, d_new,
@@ -355,10 +356,10 @@ int nerfart_volsdf_merge_check(int n_active, int n, int cap, int n_up, int n_fin
 }
 
 int nerfart_volsdf_finalize(int n_active, int n, int cap, int n_final, const float* dA, const float* sA, const int* act,
-                            const float* u_final, const float* beta_plus, float* d_fine, float* beta_map,
-                            float* iter_usage, void* stream) {
+                            const float* u_final, int u_final_stride, const float* beta_plus, float* d_fine,
+                            float* beta_map, float* iter_usage, void* stream) {
     if (n_active <= 0) return 0;
-    SamplerParams P{n, cap, 0, n_final, 0, 0, 0.f, 0.f, 0.f};
+    SamplerParams P{n, cap, 0, n_final, 0, 0, 0.f, 0.f, 0.f, u_final_stride};
     const size_t lds = (size_t)3 * n * sizeof(float);
     if (int rc = set_lds((const void*)k_finalize_unconverged, lds)) return rc;
     hipLaunchKernelGGL(k_finalize_unconverged, dim3(n_active), dim3(64), lds, (hipStream_t)stream, P, dA, sA, act,
@@ -431,10 +432,12 @@ int nerfart_volsdf_fine_sample(const float* surf_blob, int precision, const floa
                                const float* near, const float* far, float near_s, float far_s, float R_bg,
                                float alpha_net, float beta_net, float eps, int n_init, int n_up, int n_final,
                                int max_iter, int max_bisect, const float* t_init_dev, const float* u_up_dev,
-                               const float* u_final_dev, float* d_fine, float* beta_map, float* iter_usage,
-                               void* workspace, long long workspace_bytes, void* stream_) {
+                               const float* u_final_dev, int u_final_per_ray, float* d_fine, float* beta_map,
+                               float* iter_usage, void* workspace, long long workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_rays <= 0) return 0;
+    if (u_final_per_ray && !u_final_dev) { set_last_error("fine_sample: u_final_per_ray needs u_final_dev [n_rays, n_final]"); return 2; }
+    const int u_stride = u_final_per_ray ? n_final : 0;
     const int cap = n_init + max_iter * n_up;
     sampler_ws_t w;
     const size_t need = carve_sampler((char*)workspace, n_rays, cap, n_up, n_init, n_final, &w);
@@ -456,13 +459,14 @@ int nerfart_volsdf_fine_sample(const float* surf_blob, int precision, const floa
         hipError_t e4 = hipStreamSynchronize(stream);
         free(h);
         NERFART_HIP(e1); NERFART_HIP(e2); NERFART_HIP(e3); NERFART_HIP(e4);
+        if (u_final_per_ray) w.u_final = const_cast<float*>(u_final_dev);
     }
     if (int rc = nerfart_linspace_depths(w.t_init, n_init, near, far, near_s, far_s, n_rays, w.dA, cap, stream)) return rc;
     if (int rc = nerfart_sdf_fwd_rays(surf_blob, precision, rays_o, rays_dn, nullptr, w.dA, n_rays, n_init, cap, R_bg, w.sA, cap, stream)) return rc;
     NERFART_HIP(hipMemsetAsync(w.count, 0, 256, stream));
     const float denom = (float)(4.0 * (double)(n_init - 1) * log(1.0 + (double)eps));     // volsdf.py:149
     if (int rc = nerfart_volsdf_first_check(n_rays, n_init, cap, n_final, eps, alpha_net, beta_net, w.dA, w.sA, w.u_final,
-                                            denom, far, far_s, d_fine, w.beta_plus, beta_map, iter_usage, w.act0,
+                                            u_stride, denom, far, far_s, d_fine, w.beta_plus, beta_map, iter_usage, w.act0,
                                             w.count, stream)) return rc;
     int n_act = 0;
     NERFART_HIP(hipMemcpyAsync(&n_act, w.count, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -475,8 +479,8 @@ int nerfart_volsdf_fine_sample(const float* surf_blob, int precision, const floa
         if (int rc = nerfart_sdf_fwd_rays(surf_blob, precision, rays_o, rays_dn, act, w.d_new, n_act, n_up, n_up, R_bg, w.s_new, n_up, stream)) return rc;
         NERFART_HIP(hipMemsetAsync(w.count + it, 0, sizeof(int), stream));
         if (int rc = nerfart_volsdf_merge_check(n_act, n, cap, n_up, n_final, max_bisect, it, eps, alpha_net, beta_net, dA, sA,
-                                                dB, sB, act, w.d_new, w.s_new, w.u_final, d_fine, w.beta_plus, beta_map,
-                                                iter_usage, act_next, w.count + it, stream)) return rc;
+                                                dB, sB, act, w.d_new, w.s_new, w.u_final, u_stride, d_fine, w.beta_plus,
+                                                beta_map, iter_usage, act_next, w.count + it, stream)) return rc;
         NERFART_HIP(hipMemcpyAsync(&n_act, w.count + it, sizeof(int), hipMemcpyDeviceToHost, stream));
         NERFART_HIP(hipStreamSynchronize(stream));
         float* t;
@@ -486,8 +490,8 @@ int nerfart_volsdf_fine_sample(const float* surf_blob, int precision, const floa
         n += n_up;
     }
     if (n_act > 0)
-        if (int rc = nerfart_volsdf_finalize(n_act, n, cap, n_final, dA, sA, act, w.u_final, w.beta_plus, d_fine, beta_map,
-                                             iter_usage, stream)) return rc;
+        if (int rc = nerfart_volsdf_finalize(n_act, n, cap, n_final, dA, sA, act, w.u_final, u_stride, w.beta_plus, d_fine,
+                                             beta_map, iter_usage, stream)) return rc;
     return 0;
 }
 
@@ -534,8 +538,8 @@ int nerfart_volsdf_render_fwd(const float* surf_blob, const float* rad_blob, int
                               const float* rays_d, int n_rays, float near_s, float far_s, float R_bg, float alpha,
                               float beta, float eps, int n_samples, int n_importance, int max_upsample_steps,
                               int max_bisection_steps, int white_bkgd, int k3_rays_chunk, const float* t_coarse_dev,
-                              const float* t_init_dev, const float* u_up_dev, const float* u_final_dev, float* rgb,
-                              float* depth, float* acc, float* normals, float* d_all_out, float* sdf_out, float* nabla_out,
+                              const float* t_init_dev, const float* u_up_dev, const float* u_final_dev, int u_final_per_ray,
+                              float* rgb, float* depth, float* acc, float* normals, float* d_all_out, float* sdf_out, float* nabla_out,
                               float* radiance_out, float* sigma_out, float* p_out, float* tau_out, float* beta_map_out,
                               float* iter_usage_out, void* workspace, long long workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -556,7 +560,7 @@ int nerfart_volsdf_render_fwd(const float* surf_blob, const float* rad_blob, int
     if (int rc = nerfart_volsdf_fine_sample(surf_blob, precision, rays_o, w.rays_dn, n_rays, nullptr, nullptr, near_s, far_s, R_bg,
                                             alpha, beta, eps, 4 * n_samples, 4 * n_samples, n_importance,
                                             max_upsample_steps, max_bisection_steps, t_init_dev, u_up_dev, u_final_dev,
-                                            w.d_fine, beta_map, iter_usage, w.sampler, (long long)w.sampler_bytes, stream)) return rc;
+                                            u_final_per_ray, w.d_fine, beta_map, iter_usage, w.sampler, (long long)w.sampler_bytes, stream)) return rc;
     if (t_coarse_dev) {
         w.t_coarse = const_cast<float*>(t_coarse_dev);
     } else {

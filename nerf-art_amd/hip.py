@@ -38,12 +38,12 @@ _SIGS = {
     "nerfart_get_rays": (_i, [_p, _p, _i, _i, _p, _i, _p, _p, _p]),
     "nerfart_normalize_dirs": (_i, [_p, _p, _i, _p]),
     "nerfart_linspace_depths": (_i, [_p, _i, _p, _p, _f, _f, _i, _p, _i, _p]),
-    "nerfart_volsdf_first_check": (_i, [_i, _i, _i, _i, _f, _f, _f, _p, _p, _p, _f, _p, _f, _p, _p, _p, _p, _p, _p, _p]),
+    "nerfart_volsdf_first_check": (_i, [_i, _i, _i, _i, _f, _f, _f, _p, _p, _p, _i, _f, _p, _f, _p, _p, _p, _p, _p, _p, _p]),
     "nerfart_volsdf_upsample": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p]),
-    "nerfart_volsdf_merge_check": (_i, [_i, _i, _i, _i, _i, _i, _i, _f, _f, _f] + [_p] * 15),
-    "nerfart_volsdf_finalize": (_i, [_i, _i, _i, _i] + [_p] * 9),
+    "nerfart_volsdf_merge_check": (_i, [_i, _i, _i, _i, _i, _i, _i, _f, _f, _f] + [_p] * 8 + [_i] + [_p] * 7),
+    "nerfart_volsdf_finalize": (_i, [_i, _i, _i, _i] + [_p] * 4 + [_i] + [_p] * 5),
     "nerfart_volsdf_sampler_workspace_bytes": (_ll, [_i, _i, _i, _i, _i]),
-    "nerfart_volsdf_fine_sample": (_i, [_p, _i, _p, _p, _i, _p, _p, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _ll, _p]),
+    "nerfart_volsdf_fine_sample": (_i, [_p, _i, _p, _p, _i, _p, _p, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _ll, _p]),
     "nerfart_sort_concat": (_i, [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p]),
     "nerfart_volsdf_composite": (_i, [_i, _i, _p, _p, _p, _p, _f, _f, _i] + [_p] * 8),
     "nerfart_volsdf_composite_bwd": (_i, [_i, _i, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p]),
@@ -56,13 +56,13 @@ _SIGS = {
     "nerfart_radiance_fwd_dump": (_i, [_p, _i, _p, _p, _ll, _p, _p, _p, _p, _p]),
     "nerfart_radiance_bwd": (_i, [_p, _ll, _p, _p, _p, _p, _p, _p, _p]),
     "nerfart_volsdf_render_workspace_bytes": (_ll, [_i, _i, _i, _i, _i]),
-    "nerfart_volsdf_render_fwd": (_i, [_p, _p, _i, _i, _p, _p, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i] + [_p] * 4 + [_p] * 13 + [_p, _ll, _p]),
+    "nerfart_volsdf_render_fwd": (_i, [_p, _p, _i, _i, _p, _p, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i] + [_p] * 4 + [_i] + [_p] * 13 + [_p, _ll, _p]),
     "nerfart_near_far_from_sphere": (_i, [_p, _p, _i, _f, _p, _p, _p]),
-    "nerfart_neus_upsample_step": (_i, [_i, _i, _i, _i, _f, _p, _p, _p, _p, _p]),
+    "nerfart_neus_upsample_step": (_i, [_i, _i, _i, _i, _f, _p, _p, _p, _i, _p, _p]),
     "nerfart_merge_sorted_pairs": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "nerfart_neus_composite": (_i, [_i, _i, _p, _p, _p, _p, _f, _i] + [_p] * 9),
     "nerfart_neus_render_workspace_bytes": (_ll, [_i, _i, _i, _i]),
-    "nerfart_neus_render_fwd": (_i, [_p, _p, _i, _i, _p, _p, _i, _f, _f, _i, _i, _i, _i, _i] + [_p] * 2 + [_p] * 12 + [_p, _ll, _p]),
+    "nerfart_neus_render_fwd": (_i, [_p, _p, _i, _i, _p, _p, _i, _f, _f, _i, _i, _i, _i, _i] + [_p] * 2 + [_i] + [_p] * 12 + [_p, _ll, _p]),
 }
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)          # AttributeError here = header / library mismatch
@@ -198,9 +198,14 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 
 def volsdf_fine_sample(surf_blob, rays_o, rays_dn, near: float, far: float, R_bg: float, alpha: float, beta: float,
-                       eps: float, n_init: int, n_up: int, n_final: int, max_iter: int, max_bisect: int, precision: int = 0):
+                       eps: float, n_init: int, n_up: int, n_final: int, max_iter: int, max_bisect: int, precision: int = 0,
+                       u_final=None):
+    """u_final [R, n_final]: the caller's uniform random numbers for the final inverse-CDF samples (perturb=True:
+    sample_cdf(det=False), rend_util.py:306-307); None: the deterministic linspace table."""
     R = rays_o.shape[0]
     dev = rays_o.device
+    if u_final is not None and tuple(u_final.shape) != (R, n_final):
+        raise ValueError(f"u_final must be [{R}, {n_final}]")
     d_fine = torch.empty(R, n_final, dtype=torch.float32, device=dev)
     beta_map = torch.empty(R, dtype=torch.float32, device=dev)
     usage = torch.empty(R, dtype=torch.float32, device=dev)
@@ -209,7 +214,8 @@ def volsdf_fine_sample(surf_blob, rays_o, rays_dn, near: float, far: float, R_bg
     _check(lib.nerfart_volsdf_fine_sample(_dev(surf_blob), int(precision), _dev(rays_o), _dev(rays_dn), R, None, None, float(near), float(far),
                                           float(R_bg), float(alpha), float(beta), float(eps), n_init, n_up, n_final, max_iter,
                                           max_bisect, _dev(lin_table(n_init, dev)), _dev(lin_table(n_up + 2, dev)),
-                                          _dev(lin_table(n_final, dev)), _dev(d_fine), _dev(beta_map), _dev(usage), ws.data_ptr(), ws.numel(),
+                                          _dev(lin_table(n_final, dev) if u_final is None else u_final, name="u_final"),
+                                          int(u_final is not None), _dev(d_fine), _dev(beta_map), _dev(usage), ws.data_ptr(), ws.numel(),
                                           _stream()), "nerfart_volsdf_fine_sample")
     return d_fine, beta_map, usage
 
@@ -296,11 +302,14 @@ def neus_composite_bwd(sdf, rad_mid, s: float, g_rgb, white_bkgd: bool = False):
 
 def volsdf_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, near, far, R_bg, alpha, beta, eps=0.1,
                   n_samples=128, n_importance=64, max_upsample_steps=5, max_bisection_steps=10, white_bkgd=False,
-                  calc_normal=True, detailed=False, k3_rays_chunk=8192, precision=0):
-    """One chunk of rays through nerfart_volsdf_render_fwd.  Returns a dict of flat [R, ...] tensors."""
+                  calc_normal=True, detailed=False, k3_rays_chunk=8192, precision=0, u_final=None):
+    """One chunk of rays through nerfart_volsdf_render_fwd.  Returns a dict of flat [R, ...] tensors.
+    u_final [R, n_importance]: uniform random numbers of the final samples (perturb=True); None: deterministic."""
     R = rays_o.shape[0]
     dev = rays_o.device
     P = n_samples + n_importance
+    if u_final is not None and tuple(u_final.shape) != (R, n_importance):
+        raise ValueError(f"u_final must be [{R}, {n_importance}]")
     f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
     out = {"rgb": f(R, 3), "depth_volume": f(R), "mask_volume": f(R)}
     if calc_normal:
@@ -317,7 +326,7 @@ def volsdf_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, near, far,
         float(near), float(far), float(R_bg), float(alpha), float(beta), float(eps), n_samples, n_importance,
         max_upsample_steps, max_bisection_steps, int(bool(white_bkgd)), k3_rays_chunk,
         _dev(lin_table(n_samples, dev)), _dev(lin_table(4 * n_samples, dev)), _dev(lin_table(4 * n_samples + 2, dev)),
-        _dev(lin_table(n_importance, dev)),
+        _dev(lin_table(n_importance, dev) if u_final is None else u_final, name="u_final"), int(u_final is not None),
         _dev(out["rgb"]), _dev(out["depth_volume"]), _dev(out["mask_volume"]), _dev(out.get("normals_volume")),
         g("d_vals"), g("implicit_surface"), g("implicit_nablas"), g("radiance"), g("sigma"), g("p_i"),
         g("visibility_weights"), g("beta_map"), g("iter_usage"), ws.data_ptr(), ws.numel(), _stream()),
@@ -327,10 +336,15 @@ def volsdf_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, near, far,
 
 
 def neus_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, obj_bounding_radius, s, n_samples=64, n_importance=64,
-                n_upsample_iters=4, white_bkgd=False, calc_normal=True, detailed=False, k3_rays_chunk=8192, precision=0):
+                n_upsample_iters=4, white_bkgd=False, calc_normal=True, detailed=False, k3_rays_chunk=8192, precision=0,
+                u_new=None):
+    """One chunk of rays through nerfart_neus_render_fwd.  u_new [R, n_importance]: uniform random numbers of the
+    up-sampling rounds (perturb=True; round i takes columns i * n_new ..); None: deterministic."""
     R = rays_o.shape[0]
     dev = rays_o.device
     P = n_samples + n_importance
+    if u_new is not None and tuple(u_new.shape) != (R, n_importance):
+        raise ValueError(f"u_new must be [{R}, {n_importance}]")
     f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
     out = {"rgb": f(R, 3), "depth_volume": f(R), "mask_volume": f(R)}
     if calc_normal:
@@ -345,8 +359,8 @@ def neus_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, obj_bounding
     _check(lib.nerfart_neus_render_fwd(
         _dev(surf_blob), _dev(rad_blob), int(precision), int(view_tiles), _dev(rays_o, name="rays_o"), _dev(rays_d, name="rays_d"), R,
         float(obj_bounding_radius), float(s), n_samples, n_importance, n_upsample_iters, int(bool(white_bkgd)), k3_rays_chunk,
-        _dev(lin_table(n_samples, dev)), _dev(lin_table(n_importance // n_upsample_iters, dev)),
-        _dev(out["rgb"]), _dev(out["depth_volume"]), _dev(out["mask_volume"]), _dev(out.get("normals_volume")),
+        _dev(lin_table(n_samples, dev)), _dev(lin_table(n_importance // n_upsample_iters, dev) if u_new is None else u_new, name="u_new"),
+        int(u_new is not None), _dev(out["rgb"]), _dev(out["depth_volume"]), _dev(out["mask_volume"]), _dev(out.get("normals_volume")),
         g("d_all"), g("implicit_surface"), g("implicit_nablas"), g("radiance"), g("cdf"), g("alpha"),
         g("visibility_weights"), g("d_final"), ws.data_ptr(), ws.numel(), _stream()), "nerfart_neus_render_fwd")
     out.update(det)

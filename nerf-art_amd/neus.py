@@ -26,8 +26,6 @@ def volume_render(rays_o, rays_d, model: NeuS, obj_bounding_radius=1.0, batched=
     if upsample_algo != "official_solution" or N_outside > 0 or near_bypass is not None or far_bypass is not None:
         raise NotImplementedError("NeuS render: only upsample_algo='official_solution', N_outside=0, no near/far "
                                   "bypass (the reference configs) are on the HIP path")
-    if perturb:
-        raise NotImplementedError("perturb=True belongs to the reconstruction-training sampler (SURVEY.md 8f)")
     if not use_view_dirs:
         raise NotImplementedError("use_view_dirs=False is not used by any reference config")
     lead = rays_o.shape[:-1]
@@ -39,11 +37,13 @@ def volume_render(rays_o, rays_d, model: NeuS, obj_bounding_radius=1.0, batched=
     chunk = int(rayschunk) if rayschunk else DEFAULT_RAYSCHUNK
     parts = []
     for i in range(0, N, chunk):
+        # perturb (neus.py:296, rend_util.py:269-272): every up-sampling round inverts its CDF at uniform random numbers
+        u_new = torch.rand(min(chunk, N - i), N_importance, device=ro.device) if perturb else None
         parts.append(hip.neus_render(
             surf_blob, rad_blob, model.view_tiles, ro[i:i + chunk], rd[i:i + chunk],
             obj_bounding_radius=obj_bounding_radius, s=s, n_samples=N_samples, n_importance=N_importance,
             n_upsample_iters=N_upsample_iters, white_bkgd=white_bkgd, calc_normal=calc_normal,
-            detailed=detailed_output, k3_rays_chunk=k3_rays_chunk, precision=model.precision_id))
+            detailed=detailed_output, k3_rays_chunk=k3_rays_chunk, precision=model.precision_id, u_new=u_new))
     ret = OrderedDict()
     for k in ["rgb", "depth_volume", "mask_volume", "normals_volume", "implicit_nablas", "implicit_surface", "radiance",
               "alpha", "cdf", "visibility_weights", "d_final", "d_all"]:      # d_all: the P sample depths (an extra key)

@@ -8,9 +8,12 @@
             rgb_patch.backward(d loss / d rgb[patch]); eikonal = w * MSE(|nabla|, 1) over the patch's nablas, backward.
     caller  optimizer.step()  (train.py:247); with N ranks: dist.allreduce_gradients first.
 
-Differences from the reference, all deliberate: perturb=False in both passes (the
-reference draws different random samples in pass 1 and pass 2); NeuS keeps `radiance_net` frozen exactly like
-neus.py:455-456.
+Differences from the reference, all deliberate: native pass 2 evaluates the samples pass 1
+drew (their depths - and for VolSDF sdf / nablas / h7 - are kept in HBM; with perturb=False re-sampling would reproduce
+them, with perturb=True the reference draws NEW random samples in pass 2 for the gradient of a loss it evaluated on
+pass 1's: reusing them is the consistent estimator; `Trainer(native=False)` re-samples like the reference); several
+reference patches share one launch group (per-patch eikonal means kept); NeuS keeps `radiance_net` frozen exactly
+like neus.py:455-456.
 """
 import torch
 import torch.nn as nn
@@ -56,14 +59,18 @@ class Trainer(nn.Module):
 
     # ---- pass 2 ---------------------------------------------------------------------------------------
     def _samples(self, o, dn, d_raw, rk):
-        """Sample depths of a patch (no grad): the HIP sampler."""
+        """Sample depths of a patch (no grad): the HIP sampler.  perturb=True draws the uniform numbers of the inverse-CDF
+        samples from torch's generator (a fresh draw per call, as the reference's two passes draw separately)."""
         m = self.model
         surf_blob, rad_blob = m.packed()
+        perturb = bool(rk.get("perturb", False))
         if self.is_neus:
+            ni = rk.get("N_importance", 64)
             out = hip.neus_render(surf_blob, rad_blob, m.view_tiles, o, d_raw, obj_bounding_radius=rk.get("obj_bounding_radius", 1.0),
                                   s=float(m.forward_s().detach()), n_samples=rk.get("N_samples", 64),
-                                  n_importance=rk.get("N_importance", 64), n_upsample_iters=rk.get("N_upsample_iters", 4),
-                                  calc_normal=False, detailed=True, precision=m.precision_id)
+                                  n_importance=ni, n_upsample_iters=rk.get("N_upsample_iters", 4),
+                                  calc_normal=False, detailed=True, precision=m.precision_id,
+                                  u_new=torch.rand(o.shape[0], ni, device=o.device) if perturb else None)
             return out["d_all"]
         alpha, beta = m.forward_ab()
         ns, ni = rk.get("N_samples", 128), rk.get("N_importance", 64)
@@ -71,7 +78,8 @@ class Trainer(nn.Module):
         d_fine, _, _ = hip.volsdf_fine_sample(surf_blob, o, dn, near, far, rk.get("obj_bounding_radius", 3.0), float(alpha.detach()),
                                               float(beta.detach()), rk.get("epsilon", 0.1), 4 * ns, 4 * ns, ni,
                                               rk.get("max_upsample_steps", 5), rk.get("max_bisection_steps", 10),
-                                              precision=m.precision_id)
+                                              precision=m.precision_id,
+                                              u_final=torch.rand(o.shape[0], ni, device=o.device) if perturb else None)
         t = hip.lin_table(ns, o.device)
         d_coarse = (near * (1.0 - t) + far * t)[None, :].expand(o.shape[0], ns)
         return torch.sort(torch.cat([d_coarse, d_fine], dim=-1), dim=-1)[0]

@@ -6,8 +6,8 @@ set (:389-424) and returns the reference's ``extras`` keys (:566-594); ``SingleR
 integration) is one call into the HIP library; Python only slices rays into chunks and reshapes.
 
 Differences that cannot change results: chunks default to 65,536 rays instead of
-2,048-4,000 (rays are independent and ``perturb=False`` is deterministic; the reference sizes were 24 GB
-fits); the 256-d feature map the reference materialises and drops in ``fine_sample`` never exists;
+2,048-4,000 (rays are independent; the reference sizes were 24 GB fits; with ``perturb=True`` the uniform random
+numbers of the final samples come from torch's generator, one draw per chunk instead of one per converged subset); the 256-d feature map the reference materialises and drops in ``fine_sample`` never exists;
 weight_norm is folded once per weight update.
 """
 from __future__ import annotations
@@ -32,10 +32,6 @@ def volume_render(rays_o, rays_d, model: VolSDF, near=0.0, far=6.0, obj_bounding
     """rays_o / rays_d: [(B,) N_rays, 3], rays_d un-normalised.  See module docstring."""
     if use_nerfplusplus:
         raise NotImplementedError("outside_scene: nerf++ is outside the hot-path scope (SURVEY.md 2, row 19)")
-    if perturb:
-        raise NotImplementedError("perturb=True (stratified jitter of the 64 final samples, rend_util.py:307) is the "
-                                  "reconstruction-training sampler: a 'next' row of SURVEY.md 8f; the render / "
-                                  "fine-tune-evaluation path uses perturb=False")
     if not use_view_dirs:
         raise NotImplementedError("use_view_dirs=False is not used by any reference config")
     if torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters()) and rays_o.requires_grad:
@@ -51,12 +47,15 @@ def volume_render(rays_o, rays_d, model: VolSDF, near=0.0, far=6.0, obj_bounding
     want_normal = bool(calc_normal and require_nablas)
     parts = []
     for i in range(0, N, chunk):
+        # perturb (volsdf.py:122, rend_util.py:306-307): the 64 final samples invert the opacity CDF at uniform random numbers
+        # instead of linspace(0, 1, 64); drawn here from torch's generator of the device, a row per ray
+        u_final = torch.rand(min(chunk, N - i), N_importance, device=ro.device) if perturb else None
         parts.append(hip.volsdf_render(
             surf_blob, rad_blob, model.view_tiles, ro[i:i + chunk], rd[i:i + chunk], near=near, far=far,
             R_bg=obj_bounding_radius, alpha=alpha, beta=beta, eps=epsilon, n_samples=N_samples,
             n_importance=N_importance, max_upsample_steps=max_upsample_steps,
             max_bisection_steps=max_bisection_steps, white_bkgd=white_bkgd, calc_normal=want_normal,
-            detailed=detailed_output, k3_rays_chunk=k3_rays_chunk, precision=model.precision_id))
+            detailed=detailed_output, k3_rays_chunk=k3_rays_chunk, precision=model.precision_id, u_final=u_final))
     ret = OrderedDict()
     order = ["rgb", "depth_volume", "mask_volume", "normals_volume", "implicit_surface", "implicit_nablas", "radiance",
              "alpha", "p_i", "visibility_weights", "d_vals", "sigma", "beta_map", "iter_usage"]

@@ -103,8 +103,9 @@ def volsdf_composite(d_all, sigma, radiances, nablas=None, white_bkgd=False):
 def volsdf_render(sd, rays_o, rays_d, near=0.0, far=6.0, obj_bounding_radius=3.0,
                   N_samples=128, N_importance=64, max_upsample_steps=5, max_bisection_steps=10,
                   epsilon=0.1, white_bkgd=False, speed_factor=10.0, multires=6, skips=(4,),
-                  rad_multires=-1, rad_multires_view=-1, calc_normal=True, chunk=1024, differentiable=False):
-    """differentiable=True: the per-sample network queries and the compositing keep their autograd graph w.r.t.
+                  rad_multires=-1, rad_multires_view=-1, calc_normal=True, chunk=1024, differentiable=False, u_final=None):
+    """u_final [N_rays, N_importance]: perturb=True with the uniform random numbers given (see sampling.fine_sample).
+    differentiable=True: the per-sample network queries and the compositing keep their autograd graph w.r.t.
     the tensors of `sd` (sampling stays under no_grad, volsdf.py:479) - Trainer.forward's pass 2."""
     rays_o = rays_o.reshape(-1, 3).float()
     rays_d = F.normalize(rays_d.reshape(-1, 3).float(), dim=-1)               # volsdf.py:442
@@ -125,7 +126,7 @@ def volsdf_render(sd, rays_o, rays_d, near=0.0, far=6.0, obj_bounding_radius=3.0
                 lambda x: nets.volsdf_forward_surface(sd, x, R_bg, multires, skips)[0],
                 d_init, o, d, alpha, beta, fars, eps=epsilon, max_iter=max_upsample_steps,
                 max_bisection=max_bisection_steps, final_N_importance=N_importance,
-                N_up=N_samples * 4, det=True)
+                N_up=N_samples * 4, det=u_final is None, u_final=None if u_final is None else u_final[c0:c0 + chunk])
         d_all, _ = torch.sort(torch.cat([d_coarse, d_fine], dim=-1), dim=-1)   # volsdf.py:501-502
         pts = o[:, None, :] + d[:, None, :] * d_all[:, :, None]
         v = d[:, None, :].expand_as(pts)
@@ -159,8 +160,11 @@ def alpha_to_w(alpha):
     return alpha * T
 
 
-def neus_upsample(sdf_fn, d, o, v, N_importance=64, N_upsample_iters=4):
-    """'official_solution' up-sampling  (neus.py:275-303)."""
+def neus_upsample(sdf_fn, d, o, v, N_importance=64, N_upsample_iters=4, u_new=None):
+    """'official_solution' up-sampling  (neus.py:275-303).  u_new [R, N_importance]: perturb=True (det=not perturb,
+    neus.py:296) with the uniform numbers given - round i takes columns i * n_new .. (the reference draws them per
+    round, rend_util.py:272)."""
+    n_new = N_importance // N_upsample_iters
     def query(dv):
         pts = o[:, None, :] + dv[:, :, None] * v[:, None, :]
         return sdf_fn(pts.reshape(-1, 3)).reshape(dv.shape)
@@ -179,7 +183,7 @@ def neus_upsample(sdf_fn, d, o, v, N_importance=64, N_upsample_iters=4):
         nc = cdf_Phi_s(ne, 64 * (2 ** i))
         a = (pc - nc + 1e-5) / (pc + 1e-5)
         w = alpha_to_w(a)
-        d_new = sample_pdf(d, w, N_importance // N_upsample_iters, det=True)
+        d_new = sample_pdf(d, w, n_new, det=u_new is None, u=None if u_new is None else u_new[:, i * n_new:(i + 1) * n_new])
         s_new = query(d_new)
         d = torch.cat([d, d_new], -1)
         s = torch.cat([s, s_new], -1)
@@ -191,7 +195,7 @@ def neus_upsample(sdf_fn, d, o, v, N_importance=64, N_upsample_iters=4):
 # a18  NeuS volume_render  (neus.py:142-424), upsample_algo='official_solution', N_outside=0
 def neus_render(sd, rays_o, rays_d, obj_bounding_radius=1.0, N_samples=64, N_importance=64,
                 N_upsample_iters=4, white_bkgd=False, speed_factor=10.0, multires=6, skips=(4,),
-                rad_multires=-1, rad_multires_view=4, calc_normal=True, chunk=1024):
+                rad_multires=-1, rad_multires_view=4, calc_normal=True, chunk=1024, u_new=None):
     rays_o = rays_o.reshape(-1, 3).float()
     rays_d = F.normalize(rays_d.reshape(-1, 3).float(), dim=-1)
     outs = []
@@ -203,7 +207,7 @@ def neus_render(sd, rays_o, rays_d, obj_bounding_radius=1.0, N_samples=64, N_imp
         d_coarse = near * (1 - t) + far * t
         with torch.no_grad():
             d_all, _ = neus_upsample(lambda x: nets.surface_forward(sd, x, multires, skips)[0], d_coarse, o, v,
-                                     N_importance, N_upsample_iters)
+                                     N_importance, N_upsample_iters, None if u_new is None else u_new[c0:c0 + chunk])
         pts = o[:, None, :] + v[:, None, :] * d_all[:, :, None]
         d_mid = 0.5 * (d_all[..., 1:] + d_all[..., :-1])
         pts_mid = o[:, None, :] + v[:, None, :] * d_mid[:, :, None]

@@ -74,9 +74,10 @@ def sample_cdf(bins, cdf, n, det=True, u=None):
     return _invert_cdf(bins, cdf, n, det, u)
 
 
-def opacity_invert_cdf_sample(d, sdf, alpha, beta, n, det=True):
-    """Inverse-CDF samples of the opacity 1 - exp(-R_t)  (volsdf.py:122-136)."""
-    return sample_cdf(d, 1 - torch.exp(-_opacity_R(d, sdf, alpha, beta)), n, det=det)
+def opacity_invert_cdf_sample(d, sdf, alpha, beta, n, det=True, u=None):
+    """Inverse-CDF samples of the opacity 1 - exp(-R_t)  (volsdf.py:122-136).  u [..., n]: the uniform numbers
+    sample_cdf(det=False) would draw (rend_util.py:306-307), supplied so that a run is reproducible."""
+    return sample_cdf(d, 1 - torch.exp(-_opacity_R(d, sdf, alpha, beta)), n, det=det, u=u)
 
 
 def _merge_sorted(d_old, s_old, d_new, s_new):
@@ -89,8 +90,10 @@ def _merge_sorted(d_old, s_old, d_new, s_new):
 
 # a13  fine_sample  (volsdf.py:97-302) - VolSDF Algorithm 1
 def fine_sample(sdf_fn, d_init, rays_o, rays_d, alpha_net, beta_net, far,
-                eps=0.1, max_iter=5, max_bisection=10, final_N_importance=64, N_up=128, det=True):
+                eps=0.1, max_iter=5, max_bisection=10, final_N_importance=64, N_up=128, det=True, u_final=None):
     """
+    u_final [R, final_N]: perturb=True (det = not perturb, volsdf.py:122) with the uniform random numbers of every
+    ray given (the reference draws them per converged subset, rend_util.py:307: same distribution, not reproducible).
     sdf_fn(pts[M,3]) -> sdf[M]      (VolSDF.forward_surface incl. the sphere clamp)
     d_init[R, N0], rays_o/rays_d[R,3], alpha_net/beta_net scalar tensors, far scalar or [R,1]
     returns d_fine[R, final_N], beta_map[R, 1], iter_usage[R] (0..max_iter, -1 = never converged)
@@ -116,7 +119,7 @@ def fine_sample(sdf_fn, d_init, rays_o, rays_d, alpha_net, beta_net, far,
     done = all_idx[~need]
     if done.numel() > 0:
         d_fine[done] = opacity_invert_cdf_sample(d_all[done], s_all[done], alpha_net, beta_net,
-                                                 final_N_importance, det)
+                                                 final_N_importance, det, None if u_final is None else u_final[done])
         converged[done] = True
     d_act, s_act = d_all[act], s_all[act]
     b_act = error_bound(d_act, s_act, 1.0 / beta[act], beta[act])
@@ -133,7 +136,7 @@ def fine_sample(sdf_fn, d_init, rays_o, rays_d, alpha_net, beta_net, far,
         if ok.any():
             fin = act[ok]
             d_fine[fin] = opacity_invert_cdf_sample(d_act[ok], s_act[ok], alpha_net, beta_net,
-                                                    final_N_importance, det)
+                                                    final_N_importance, det, None if u_final is None else u_final[fin])
             usage[fin] = it
             converged[fin] = True
         keep = ~ok
@@ -155,7 +158,8 @@ def fine_sample(sdf_fn, d_init, rays_o, rays_d, alpha_net, beta_net, far,
 
     if act.numel() > 0:                      # never converged: sample with the last beta_+ (volsdf.py:294-300)
         bp = beta[act]
-        d_fine[act] = opacity_invert_cdf_sample(d_act, s_act, 1.0 / bp, bp, final_N_importance, det)
+        d_fine[act] = opacity_invert_cdf_sample(d_act, s_act, 1.0 / bp, bp, final_N_importance, det,
+                                                None if u_final is None else u_final[act])
         usage[act] = -1
     beta[converged] = beta_net
     return d_fine, beta, usage

@@ -30,6 +30,13 @@ def golden():
     return {k: z[k] for k in z.files}
 
 
+@pytest.fixture(scope="session")
+def perturb_golden():
+    """perturb=True vectors (tests/golden/make_golden_perturb.py)."""
+    z = np.load(os.path.join(os.path.dirname(GOLDEN), "perturb_golden.npz"), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
 _states = {}
 
 

@@ -318,3 +318,69 @@ def test_implicit_surface_forward_as_the_reference_consumers_call_it(pts):
         _, n_ref, _ = nets.surface_forward_with_nablas(sd, p)
         assert s3.shape == (1, 257) and n3.shape == (1, 257, 3) and f3.shape == (1, 257, 256)
         close("forward_with_nablas nablas", n3[0], n_ref, 5e-6)
+
+
+# ---- perturb=True: the samplers invert their CDFs at the caller's uniform numbers -----------------------------------
+def test_volsdf_perturb_matches_reference_golden(perturb_golden):
+    """fine_sample / volume_render with perturb=True against the reference's outputs for the uniform numbers it drew
+    (tests/golden/make_golden_perturb.py)."""
+    from nerfart_amd import hip, rend_util
+    pg = perturb_golden
+    model, rk, _ = _model("VolSDF", 0.01)
+    H, W = int(pg["P_H"]), int(pg["P_W"])
+    o, d, _ = rend_util.get_rays(tt(pg["P_c2w"])[None].to(DEV), tt(pg["P_K"])[None].to(DEV), H, W)
+    o, d = o[0].contiguous(), d[0].contiguous()
+    dn = hip.normalize_dirs(d)
+    surf_blob, rad_blob = model.packed()
+    alpha, b = model.forward_ab()
+    d_fine, beta_map, usage = hip.volsdf_fine_sample(surf_blob, o, dn, 0.0, 6.0, 3.0, float(alpha), float(b), 0.1, 512, 512, 64, 6, 10,
+                                                     u_final=tt(pg["P2_u_final"]).to(DEV))
+    same = usage.cpu().numpy() == pg["P2_iter_usage"]
+    assert same.mean() >= 0.95
+    bm_ref = tt(pg["P2_beta_map"])[:, 0]
+    m = torch.from_numpy(same) & ((beta_map.cpu() - bm_ref).abs() <= 1e-4 * bm_ref)
+    assert m.double().mean() >= 0.95
+    close("d_fine (random u)", d_fine.cpu()[m], tt(pg["P2_d_fine"])[m], 3e-4, 0.0, frac=0.99)
+    out = hip.volsdf_render(surf_blob, rad_blob, model.view_tiles, o, d, near=rk["near"], far=rk["far"], R_bg=rk["obj_bounding_radius"],
+                            alpha=float(alpha), beta=float(b), max_upsample_steps=rk["max_upsample_steps"], detailed=True,
+                            u_final=tt(pg["P3_u_final"]).to(DEV))
+    same = torch.from_numpy(out["iter_usage"].cpu().numpy() == pg["P3_iter_usage"])
+    assert same.double().mean() >= 0.95
+    close("d_vals", out["d_vals"].cpu()[same], tt(pg["P3_d_vals"])[same], 3e-4, 0.0, frac=0.99)
+    close("rgb", out["rgb"].cpu()[same], tt(pg["P3_rgb"])[same], 1e-3)
+    close("depth", out["depth_volume"].cpu()[same], tt(pg["P3_depth_volume"])[same], 5e-3)
+
+
+def test_neus_perturb_matches_reference_golden(perturb_golden):
+    from nerfart_amd import hip, rend_util
+    pg = perturb_golden
+    model, rk, _ = _model("NeuS", None)
+    H, W = int(pg["P_H"]), int(pg["P_W"])
+    o, d, _ = rend_util.get_rays(tt(pg["P_c2w"])[None].to(DEV), tt(pg["P_K"])[None].to(DEV), H, W)
+    surf_blob, rad_blob = model.packed()
+    out = hip.neus_render(surf_blob, rad_blob, model.view_tiles, o[0].contiguous(), d[0].contiguous(),
+                          obj_bounding_radius=rk["obj_bounding_radius"], s=float(model.forward_s()), n_upsample_iters=rk["N_upsample_iters"],
+                          calc_normal=True, detailed=True, u_new=tt(pg["P4_u_new"]).to(DEV))
+    close("d_final", out["d_final"], pg["P4_d_final"], 3e-4, 3e-4, frac=0.99)
+    close("implicit_surface", out["implicit_surface"], pg["P4_implicit_surface"], 3e-5, 3e-4, frac=0.99)
+    close("rgb", out["rgb"], pg["P4_rgb"], 1e-3)
+    close("depth", out["depth_volume"], pg["P4_depth_volume"], 5e-3)
+
+
+def test_render_fn_perturb_draws_fresh_samples():
+    """render_fn(perturb=True) (the reference's training default, volsdf.py:982): two calls draw different final samples,
+    the coarse samples stay, and the image stays close to the deterministic render (it is the same quadrature rule)."""
+    from nerfart_amd import rend_util, scene
+    for fw, key in (("VolSDF", "d_vals"), ("NeuS", "d_all")):
+        model, rk, render_fn = _model(fw, 0.01 if fw == "VolSDF" else None)
+        c2w, K = scene.camera(8, 8)
+        o, d, _ = rend_util.get_rays(c2w[None].to(DEV), K[None].to(DEV), 8, 8)
+        kw = dict(rk); kw["perturb"] = False
+        _, _, ex0 = render_fn(o, d, detailed_output=True, **kw)
+        kw["perturb"] = True
+        torch.manual_seed(1)
+        _, _, ex1 = render_fn(o, d, detailed_output=True, **kw)
+        _, _, ex2 = render_fn(o, d, detailed_output=True, **kw)
+        assert not torch.equal(ex1[key], ex2[key]) and not torch.equal(ex1[key], ex0[key])
+        assert torch.all(ex1[key][..., 1:] >= ex1[key][..., :-1])
+        assert float((ex1["rgb"] - ex0["rgb"]).abs().max()) < 0.1

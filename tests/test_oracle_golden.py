@@ -164,3 +164,47 @@ def test_G11_backward_matches_reference(golden):
         np.testing.assert_allclose(float(g.norm()), ref_norm, rtol=2e-3, atol=1e-7, err_msg=n)
         head = golden["G11_gradhead_" + n]
         np.testing.assert_allclose(g.reshape(-1)[:head.size].numpy(), head, rtol=2e-2, atol=2e-3 * ref_norm / max(1.0, np.sqrt(g.numel())) + 1e-8, err_msg=n)
+
+
+# ---- perturb=True (det=False samplers): the oracle takes the uniform numbers the reference drew ----------------------
+def test_P1_samplers_with_given_uniforms(perturb_golden):
+    pg = perturb_golden
+    bins, w, cdf = tt(pg["P1_bins"]), tt(pg["P1_w"]), tt(pg["P1_cdf"])
+    close(sampling.sample_pdf(bins, w, 16, det=False, u=tt(pg["P1_u_pdf"])), pg["P1_pdf16"], 0, 0)
+    close(sampling.sample_cdf(bins, cdf, 16, det=False, u=tt(pg["P1_u_cdf"])), pg["P1_cdf16"], 0, 0)
+
+
+def test_P2_P3_volsdf_perturb(perturb_golden):
+    pg = perturb_golden
+    sd, rk = scene_state("VolSDF", 0.01)
+    assert state_checksum(sd) == str(pg["P2_state_sha256"])
+    H, W = int(pg["P_H"]), int(pg["P_W"])
+    o, d = render.get_rays(tt(pg["P_c2w"]), tt(pg["P_K"]), H, W)
+    dn = torch.nn.functional.normalize(d, dim=-1)
+    alpha, bnet = nets.volsdf_ab(sd)
+    t = torch.linspace(0, 1, 512)
+    d_init = 0.0 * (1 - t) + 6.0 * torch.ones(H * W, 1) * t
+    with torch.no_grad():
+        d_fine, beta_map, usage = sampling.fine_sample(lambda x: nets.volsdf_forward_surface(sd, x)[0], d_init, o, dn, alpha, bnet,
+                                                       6.0 * torch.ones(H * W, 1), eps=0.1, max_iter=6, max_bisection=10,
+                                                       final_N_importance=64, N_up=512, det=False, u_final=tt(pg["P2_u_final"]))
+    assert np.array_equal(usage.numpy(), pg["P2_iter_usage"])
+    close(beta_map, pg["P2_beta_map"], 1e-7, 1e-5)
+    close(d_fine, pg["P2_d_fine"], 2e-5, 1e-5)
+    assert not np.all(np.diff(pg["P2_d_fine"], axis=-1) >= 0), "fixture must hold unsorted (random) samples"
+    with torch.no_grad():
+        out = render.volsdf_render(sd, o, d, near=rk["near"], far=rk["far"], obj_bounding_radius=rk["obj_bounding_radius"],
+                                   max_upsample_steps=rk["max_upsample_steps"], u_final=tt(pg["P3_u_final"]))
+    for k in ("rgb", "depth_volume", "d_vals", "iter_usage", "beta_map"):
+        close(out[k], pg["P3_" + k], 2e-5, 1e-5)
+
+
+def test_P4_neus_perturb(perturb_golden, neus_state):
+    pg = perturb_golden
+    sd, rk = neus_state
+    o, d = render.get_rays(tt(pg["P_c2w"]), tt(pg["P_K"]), int(pg["P_H"]), int(pg["P_W"]))
+    with torch.no_grad():
+        out = render.neus_render(sd, o, d, obj_bounding_radius=rk["obj_bounding_radius"], N_upsample_iters=rk["N_upsample_iters"],
+                                 u_new=tt(pg["P4_u_new"]))
+    for k in ("rgb", "depth_volume", "d_final", "implicit_surface"):
+        close(out[k], pg["P4_" + k], 3e-5, 2e-4)
