@@ -157,11 +157,21 @@ class PatchNCELoss(nn.Module):
         H, W = x.shape[-2:]
         th = tw = 224 if is_full_res else 112
         crops = crops if crops is not None else self.crop_origins(H, W, th, tw, is_full_res)
-        total = 0
+        imgs = []
         for (i, j) in crops:
             img = x[..., i:i + th, j:j + tw]
-            if not is_full_res:
-                img = F.interpolate(img, size=(224, 224), mode="bicubic", align_corners=False)
+            imgs.append(img if is_full_res else F.interpolate(img, size=(224, 224), mode="bicubic", align_corners=False))
+        if x.shape[0] == 1 and all(im.shape == imgs[0].shape for im in imgs):
+            # the 12 crops as ONE batch through the image encoder (each crop's loss depends on its own features only;
+            # the reference's 12 B=1 encodes are launch-bound)
+            f = self.feats.image_features(self.preprocess(torch.cat(imgs, dim=0)))[:, None, :]      # [12, 1, 512]
+            pos = torch.exp(F.cosine_similarity(f, self.feats.text_features(target_class).detach()[None], dim=-1) / self.temperature)
+            neg = 0
+            for s in source_classes:
+                neg = neg + torch.exp(F.cosine_similarity(f, self.feats.text_features(s).detach()[None], dim=-1) / self.temperature)
+            return (-torch.log(pos / (pos + neg))).mean(dim=1).sum()
+        total = 0
+        for img in imgs:
             total = total + self.patch_loss(source_classes, img, target_class)
         return total
 

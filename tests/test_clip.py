@@ -111,6 +111,11 @@ def test_loss_heads_closed_form(feats):
     pn = criteria.PatchNCELoss(feats, (128, 96), n_patches=2)
     v3 = pn(["photo", "sketch"], pred, "painting", False, crops=[(4, 3), (10, 20)])
     assert v3.ndim == 0 and torch.isfinite(v3)
+    # the 12 crops go through the encoder as one batch: same value as the reference's crop-by-crop loop
+    xp = criteria.resize(torch.nn.functional.pad(pred, (270, 270, 480, 480)), (128, 96), "bicubic")
+    up = lambda t: torch.nn.functional.interpolate(t, size=(224, 224), mode="bicubic", align_corners=False)
+    ref3 = sum(pn.patch_loss(["photo", "sketch"], up(xp[..., i:i + 112, j:j + 112]), "painting") for (i, j) in [(4, 3), (10, 20)])
+    np.testing.assert_allclose(float(v3), float(ref3), rtol=1e-4, atol=1e-5)
     (v + v2 + v3).backward()
     assert torch.isfinite(pred.grad).all() and float(pred.grad.abs().max()) > 0
 
