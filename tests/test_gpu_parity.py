@@ -11,6 +11,8 @@ order, the hardware exp2/log2 softplus and libm sin/cos):
     inverse-CDF sample sits on a plateau of the CDF), so a 1e-7 difference in one sdf can move a handful of
     samples by 1e-3..1e-2 in depth; the pixels they composite into stay inside the pixel bound.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -384,3 +386,30 @@ def test_render_fn_perturb_draws_fresh_samples():
         assert not torch.equal(ex1[key], ex2[key]) and not torch.equal(ex1[key], ex0[key])
         assert torch.all(ex1[key][..., 1:] >= ex1[key][..., :-1])
         assert float((ex1["rgb"] - ex0["rgb"]).abs().max()) < 0.1
+
+
+def test_dataset_to_frames(tmp_path):
+    """The data-side rows feeding the renderer end to end (render.py:286-330, :527-533): scene folder -> SceneDataset ->
+    spiral camera path -> get_rays -> render_fn -> H x W x 3 frames."""
+    from PIL import Image
+    from nerfart_amd import camera_path, dataio, rend_util
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "campath_golden.npz"))
+    os.makedirs(tmp_path / "images"); os.makedirs(tmp_path / "matte")
+    cams = {}
+    for i in range(4):
+        Image.fromarray(np.full((96, 54, 3), 40 * i, np.uint8)).save(tmp_path / "images" / f"{i:06d}.png")
+        Image.fromarray(np.full((96, 54, 3), 255, np.uint8)).save(tmp_path / "matte" / f"{i:06d}.png")
+        cams[f"world_mat_{i}"], cams[f"scale_mat_{i}"] = z[f"C2_world_mat_{i}"], z[f"C2_scale_mat_{i}"]
+    np.savez(tmp_path / "cameras.npz", **cams)
+    ds = dataio.SceneDataset(False, str(tmp_path), downscale=2, scale_radius=3.0)
+    assert (ds.H, ds.W) == (48, 27)
+    K, H, W = camera_path.render_intrinsics(ds, H=24, W=16)
+    c2ws = torch.stack(ds.c2w_all, 0).numpy()
+    path = camera_path.spiral_path(c2ws, 3, rot_percentile=85, rot_rad=0.3)
+    model, rk, render_fn = _model("VolSDF", 0.01)
+    for c2w in path:
+        o, d, _ = rend_util.get_rays(torch.from_numpy(c2w).float().to(DEV)[None], K.to(DEV)[None], H, W)
+        rgb, depth, ex = render_fn(o, d, require_nablas=True, calc_normal=True, detailed_output=False, **rk)
+        img = (rgb.cpu().reshape(H, W, 3).numpy() * 255.0).astype(np.uint8)
+        assert img.shape == (24, 16, 3) and torch.isfinite(rgb).all() and torch.isfinite(depth).all()
+        assert ex["normals_volume"].shape[-2:] == (H * W, 3)
