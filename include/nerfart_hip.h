@@ -149,18 +149,19 @@ int nerfart_volsdf_composite(int n_rays, int P, const float* d_all, const float*
                              const float* nabla, float alpha, float beta, int white_bkgd, float* rgb, float* depth,
                              float* acc, float* normals, float* sigma_out, float* p_out, float* tau_out, void* stream);
 
-/* Backward of nerfart_volsdf_composite w.r.t. the rgb output only (the reference's losses use nothing else,
- * volsdf.py:766): g_rgb [R,3] -> g_sdf [R,P] (through sdf_to_sigma, volsdf.py:34-53), g_rad [R,P,3], and
+/* Backward of nerfart_volsdf_composite w.r.t. the rgb output (volsdf.py:766) and, optionally, the opacity output acc
+ * (g_acc [R] or NULL: the cotangent of mask_volume, the mask BCE of the reconstruction objective, neus.py:600-603):
+ * g_rgb [R,3] -> g_sdf [R,P] (through sdf_to_sigma, volsdf.py:34-53), g_rad [R,P,3], and
  * g_alpha_beta[2] += (d loss / d alpha, d loss / d beta) (accumulated with atomics: zero it first; may be NULL).
  * What `rgb.backward(gradient)` (volsdf.py:766) does to the per-ray stage; first hand-written piece of B1 "bwd". */
 int nerfart_volsdf_composite_bwd(int n_rays, int P, const float* d_all, const float* sdf, const float* radiance, float alpha,
-                                 float beta, int white_bkgd, const float* g_rgb, float* g_sdf, float* g_rad,
+                                 float beta, int white_bkgd, const float* g_rgb, const float* g_acc, float* g_sdf, float* g_rad,
                                  float* g_alpha_beta, void* stream);
 
 /* The same for NeuS (neus.py:29-78, :373-395): sdf [R,P] at the samples, radiance [R,P-1,3] at the mid-points, s =
  * exp(ln_s * speed_factor) -> g_sdf [R,P], g_rad_mid [R,P-1,3], g_s[0] += d loss / d s. */
 int nerfart_neus_composite_bwd(int n_rays, int P, const float* sdf, const float* rad_mid, float s, int white_bkgd, const float* g_rgb,
-                               float* g_sdf, float* g_rad_mid, float* g_s, void* stream);
+                               const float* g_acc, float* g_sdf, float* g_rad_mid, float* g_s, void* stream);
 
 /* ---- B1: VolSDF volume_render (volsdf.py:389-615) for one chunk of rays (rays_d un-normalised). */
 long long nerfart_volsdf_render_workspace_bytes(int n_rays, int n_samples, int n_importance, int max_upsample_steps,

@@ -366,10 +366,11 @@ def volsdf_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikon
 
 
 def neus_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikonal=0.1, use_eikonal=True, white_bkgd=False, s_val=None, accum=None,
-                                 eik_group_rays=None):
+                                 eik_group_rays=None, g_acc=None):
     """Pass 2 for one NeuS patch on the hand-written kernels + GEMMs (neus.py:310-395, :520-576): SDF + nablas at the P
-    samples (alpha, eikonal), SDF + nablas + radiance at the P-1 mid-points; the radiance net is frozen (neus.py:455-456).
-    Returns the eikonal loss (0-d tensor)."""
+    samples (alpha, eikonal), SDF + nablas + radiance at the P-1 mid-points.  Radiance-net gradients are accumulated only if
+    its parameters require grad (the fine-tune step freezes it, neus.py:455-456; reconstruction trains it).  g_acc [R]: a
+    cotangent of the opacity mask_volume (the mask BCE of the reconstruction objective).  Returns the eikonal loss (0-d)."""
     from . import hip
     R, P = d_all.shape
     pts = (rays_o[:, None, :] + rays_dn[:, None, :] * d_all[:, :, None]).reshape(-1, 3).contiguous()
@@ -383,7 +384,8 @@ def neus_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikonal
         sdf, nab, _ = hip.sdf_nabla_fwd(surf_blob, pts, 0.0, want_h7=False, precision=model.precision_id)
         _, nab_m, h7_m = hip.sdf_nabla_fwd(surf_blob, pts_m, 0.0, precision=model.precision_id)
         rgb_m, dump = hip.radiance_fwd_dump(rad_blob, model.view_tiles, pts_m, v_m, nab_m, h7_m)
-        g_sdf, g_rad, g_s = hip.neus_composite_bwd(sdf.reshape(R, P), rgb_m.reshape(R, P - 1, 3), s_val, g_rgb.contiguous(), white_bkgd)
+        g_sdf, g_rad, g_s = hip.neus_composite_bwd(sdf.reshape(R, P), rgb_m.reshape(R, P - 1, 3), s_val, g_rgb.contiguous(), white_bkgd,
+                                                      g_acc=None if g_acc is None else g_acc.contiguous())
         g_h7, g_n, bdump = hip.radiance_bwd(rad_blob, rgb_m, g_rad.reshape(-1, 3), dump)
         nbar = torch.zeros_like(nab)
         eik = torch.zeros((), device=pts.device)

@@ -29,7 +29,8 @@ __device__ __forceinline__ float wave_excl_suffix_sum(float v) {
 __global__ void __launch_bounds__(64)
 k_composite_volsdf_bwd(int P, const float* __restrict__ d_all, const float* __restrict__ sdf,
                        const float* __restrict__ radiance, float alpha, float beta, int white_bkgd,
-                       const float* __restrict__ g_rgb, float* __restrict__ g_sdf, float* __restrict__ g_rad,
+                       const float* __restrict__ g_rgb, const float* __restrict__ g_acc, float* __restrict__ g_sdf,
+                       float* __restrict__ g_rad,
                        float* __restrict__ g_alpha_beta) {
     const int ray = blockIdx.x, lane = threadIdx.x;
     const int nint = P - 1;
@@ -38,7 +39,8 @@ k_composite_volsdf_bwd(int P, const float* __restrict__ d_all, const float* __re
     const float* dr = d_all + (size_t)ray * P;
     const float* sr = sdf + (size_t)ray * P;
     const float gr = g_rgb[3 * (size_t)ray], gg = g_rgb[3 * (size_t)ray + 1], gb = g_rgb[3 * (size_t)ray + 2];
-    const float gbg = white_bkgd ? -(gr + gg + gb) : 0.f;
+    // cotangent of the opacity acc = sum of the weights: the white background (rgb += 1 - acc) plus the caller's (mask loss)
+    const float gbg = (white_bkgd ? -(gr + gg + gb) : 0.f) + (g_acc ? g_acc[ray] : 0.f);
     // pass 1: transmittance at the start of this lane's segment, and the segment's sum of (1 - p + eps) T g_tau
     float lp = 1.f;
     for (int k = k0; k < k1; ++k) lp *= expf(-fmaxf(sdf_to_sigma(sr[k], alpha, beta) * (dr[k + 1] - dr[k]), 0.f));
@@ -97,12 +99,13 @@ k_composite_volsdf_bwd(int P, const float* __restrict__ d_all, const float* __re
 //   g_sdf_k = g_cdf_k cdf_k (1 - cdf_k) s;  g_s += g_cdf_k cdf_k (1 - cdf_k) sdf_k
 __global__ void __launch_bounds__(64)
 k_composite_neus_bwd(int P, const float* __restrict__ sdf, const float* __restrict__ rad_mid, float s_inv, int white_bkgd,
-                     const float* __restrict__ g_rgb, float* __restrict__ g_sdf, float* __restrict__ g_rad, float* __restrict__ g_s) {
+                     const float* __restrict__ g_rgb, const float* __restrict__ g_acc, float* __restrict__ g_sdf, float* __restrict__ g_rad, float* __restrict__ g_s) {
     const int ray = blockIdx.x, lane = threadIdx.x;
     const int nint = P - 1, seg = (nint + 63) >> 6, k0 = lane * seg, k1 = (k0 + seg < nint) ? k0 + seg : nint;
     const float* sr = sdf + (size_t)ray * P;
     const float gr = g_rgb[3 * (size_t)ray], gg = g_rgb[3 * (size_t)ray + 1], gb = g_rgb[3 * (size_t)ray + 2];
-    const float gbg = white_bkgd ? -(gr + gg + gb) : 0.f;
+    // cotangent of the opacity acc = sum of the weights: the white background (rgb += 1 - acc) plus the caller's (mask loss)
+    const float gbg = (white_bkgd ? -(gr + gg + gb) : 0.f) + (g_acc ? g_acc[ray] : 0.f);
     float lp = 1.f;
     for (int k = k0; k < k1; ++k) {
         const float c0 = sigmoidf_(sr[k] * s_inv), c1 = sigmoidf_(sr[k + 1] * s_inv);
@@ -172,23 +175,23 @@ using namespace nerfart;
 extern "C" {
 // g_alpha_beta: 2 floats, ACCUMULATED into (zero them first); may be NULL.
 int nerfart_volsdf_composite_bwd(int n_rays, int P, const float* d_all, const float* sdf, const float* radiance, float alpha,
-                                 float beta, int white_bkgd, const float* g_rgb, float* g_sdf, float* g_rad,
+                                 float beta, int white_bkgd, const float* g_rgb, const float* g_acc, float* g_sdf, float* g_rad,
                                  float* g_alpha_beta, void* stream) {
     if (n_rays <= 0) return 0;
     if (P < 2 || P > 513) { set_last_error("composite_bwd: 2 <= P <= 513"); return 2; }
     hipLaunchKernelGGL(k_composite_volsdf_bwd, dim3(n_rays), dim3(64), 0, (hipStream_t)stream, P, d_all, sdf, radiance, alpha,
-                       beta, white_bkgd, g_rgb, g_sdf, g_rad, g_alpha_beta);
+                       beta, white_bkgd, g_rgb, g_acc, g_sdf, g_rad, g_alpha_beta);
     NERFART_HIP(hipGetLastError());
     return 0;
 }
 
 // NeuS: sdf [R,P], rad_mid [R,P-1,3], s = exp(ln_s * speed_factor); g_s: 1 float, ACCUMULATED into (may be NULL).
 int nerfart_neus_composite_bwd(int n_rays, int P, const float* sdf, const float* rad_mid, float s, int white_bkgd, const float* g_rgb,
-                               float* g_sdf, float* g_rad_mid, float* g_s, void* stream) {
+                               const float* g_acc, float* g_sdf, float* g_rad_mid, float* g_s, void* stream) {
     if (n_rays <= 0) return 0;
     if (P < 2 || P > 513) { set_last_error("neus_composite_bwd: 2 <= P <= 513"); return 2; }
-    hipLaunchKernelGGL(k_composite_neus_bwd, dim3(n_rays), dim3(64), 0, (hipStream_t)stream, P, sdf, rad_mid, s, white_bkgd, g_rgb, g_sdf,
-                       g_rad_mid, g_s);
+    hipLaunchKernelGGL(k_composite_neus_bwd, dim3(n_rays), dim3(64), 0, (hipStream_t)stream, P, sdf, rad_mid, s, white_bkgd, g_rgb, g_acc,
+                       g_sdf, g_rad_mid, g_s);
     NERFART_HIP(hipGetLastError());
     return 0;
 }

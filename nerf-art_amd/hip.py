@@ -46,8 +46,8 @@ _SIGS = {
     "nerfart_volsdf_fine_sample": (_i, [_p, _i, _p, _p, _i, _p, _p, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _ll, _p]),
     "nerfart_sort_concat": (_i, [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p]),
     "nerfart_volsdf_composite": (_i, [_i, _i, _p, _p, _p, _p, _f, _f, _i] + [_p] * 8),
-    "nerfart_volsdf_composite_bwd": (_i, [_i, _i, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p]),
-    "nerfart_neus_composite_bwd": (_i, [_i, _i, _p, _p, _f, _i, _p, _p, _p, _p, _p]),
+    "nerfart_volsdf_composite_bwd": (_i, [_i, _i, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p]),
+    "nerfart_neus_composite_bwd": (_i, [_i, _i, _p, _p, _f, _i, _p, _p, _p, _p, _p, _p]),
     "nerfart_sdf_fwd2_dump_bytes": (_ll, [_ll]),
     "nerfart_sdf_bwd2_dump_bytes": (_ll, [_ll]),
     "nerfart_sdf_fwd2": (_i, [_p, _p, _p, _ll, _p, _p]),
@@ -275,28 +275,29 @@ def volsdf_composite(d_all, sdf, radiance, alpha: float, beta: float, white_bkgd
     return rgb, depth, acc
 
 
-def volsdf_composite_bwd(d_all, sdf, radiance, alpha: float, beta: float, g_rgb, white_bkgd: bool = False):
-    """Cotangents (g_sdf [R,P], g_radiance [R,P,3], g_alpha_beta [2]) for d loss / d rgb = g_rgb [R,3]."""
+def volsdf_composite_bwd(d_all, sdf, radiance, alpha: float, beta: float, g_rgb, white_bkgd: bool = False, g_acc=None):
+    """Cotangents (g_sdf [R,P], g_radiance [R,P,3], g_alpha_beta [2]) for d loss / d rgb = g_rgb [R,3] (and d loss / d acc
+    = g_acc [R], the opacity / mask_volume output, if given)."""
     R, P = d_all.shape
     dev = d_all.device
     g_sdf = torch.empty(R, P, dtype=torch.float32, device=dev)
     g_rad = torch.empty(R, P, 3, dtype=torch.float32, device=dev)
     g_ab = torch.zeros(2, dtype=torch.float32, device=dev)
     _check(lib.nerfart_volsdf_composite_bwd(R, P, _dev(d_all), _dev(sdf), _dev(radiance), float(alpha), float(beta),
-                                            int(bool(white_bkgd)), _dev(g_rgb), _dev(g_sdf), _dev(g_rad), _dev(g_ab), _stream()),
-           "nerfart_volsdf_composite_bwd")
+                                            int(bool(white_bkgd)), _dev(g_rgb), _dev(g_acc, name="g_acc"), _dev(g_sdf), _dev(g_rad), _dev(g_ab),
+                                            _stream()), "nerfart_volsdf_composite_bwd")
     return g_sdf, g_rad, g_ab
 
 
-def neus_composite_bwd(sdf, rad_mid, s: float, g_rgb, white_bkgd: bool = False):
-    """(g_sdf [R,P], g_rad_mid [R,P-1,3], g_s [1]) for d loss / d rgb = g_rgb [R,3]."""
+def neus_composite_bwd(sdf, rad_mid, s: float, g_rgb, white_bkgd: bool = False, g_acc=None):
+    """(g_sdf [R,P], g_rad_mid [R,P-1,3], g_s [1]) for d loss / d rgb = g_rgb [R,3] (and d loss / d acc = g_acc [R])."""
     R, P = sdf.shape
     dev = sdf.device
     g_sdf = torch.empty(R, P, dtype=torch.float32, device=dev)
     g_rad = torch.empty(R, P - 1, 3, dtype=torch.float32, device=dev)
     g_s = torch.zeros(1, dtype=torch.float32, device=dev)
-    _check(lib.nerfart_neus_composite_bwd(R, P, _dev(sdf), _dev(rad_mid), float(s), int(bool(white_bkgd)), _dev(g_rgb), _dev(g_sdf),
-                                          _dev(g_rad), _dev(g_s), _stream()), "nerfart_neus_composite_bwd")
+    _check(lib.nerfart_neus_composite_bwd(R, P, _dev(sdf), _dev(rad_mid), float(s), int(bool(white_bkgd)), _dev(g_rgb), _dev(g_acc, name="g_acc"),
+                                          _dev(g_sdf), _dev(g_rad), _dev(g_s), _stream()), "nerfart_neus_composite_bwd")
     return g_sdf, g_rad, g_s
 
 

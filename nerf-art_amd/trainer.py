@@ -26,7 +26,7 @@ from .nets import NeuS, VolSDF
 
 class Trainer(nn.Module):
     def __init__(self, model, w_eikonal: float = 0.1, use_eikonal: bool = True, pass2_rays: int = 1200, native: bool = None,
-                 patches_per_launch: int = 4):
+                 patches_per_launch: int = 4, freeze_radiance: bool = None):
         super().__init__()
         if not isinstance(model, (VolSDF, NeuS)):
             raise TypeError("Trainer expects a nerfart_amd VolSDF or NeuS model")
@@ -40,7 +40,9 @@ class Trainer(nn.Module):
         # eikonal means are kept); bounded by the kernels' 2^21 points per launch
         self.patches_per_launch = patches_per_launch
         self._kept = None
-        if self.is_neus:                       # neus.py:455-456: only the SDF net (and ln_s) is fine-tuned
+        # neus.py:455-456: NeuS fine-tuning trains only the SDF net (and ln_s); pass freeze_radiance=False for the
+        # reconstruction objective (reconstruction_step), which trains everything
+        if self.is_neus if freeze_radiance is None else freeze_radiance:
             for p in model.radiance_net.parameters():
                 p.requires_grad_(False)
 
@@ -194,14 +196,21 @@ class Trainer(nn.Module):
         return float(eik_sum) / max(n, 1)
 
     # ---- reconstruction-training branch (volsdf.py:784-824) -------------------------------------
-    def reconstruction_step(self, render_fn, rays_o, rays_d, target_rgb, eikonal_points, w_eikonal: float = 0.1, optimizer=None,
-                            mask_ignore=None, **render_kwargs):
-        """One step of the reconstruction objective on a batch of rays [N, 3]: loss = mean |rgb - target| + w_eikonal *
-        MSE(|nabla|, 1) over two nablas per ray - the sample of largest visibility weight and `eikonal_points` [N, 3]
-        (the reference draws them uniformly in the bounding box, volsdf.py:799-801; here the caller does, so that runs
-        are reproducible).  VolSDF; deterministic sampling (perturb=False).  Accumulates .grad; returns the losses."""
+    def reconstruction_step(self, render_fn, rays_o, rays_d, target_rgb, eikonal_points=None, w_eikonal: float = 0.1, optimizer=None,
+                            mask_ignore=None, target_mask=None, w_mask: float = 0.0, **render_kwargs):
+        """One step of the reconstruction objective on a batch of rays [N, 3].  Accumulates .grad; returns the losses.
+
+        VolSDF (volsdf.py:784-824): mean |rgb - target| + w_eikonal * MSE(|nabla|, 1) over two nablas per ray - the sample
+        of largest visibility weight and `eikonal_points` [N, 3] (the reference draws them uniformly in the bounding box,
+        volsdf.py:799-801; here the caller does, so that runs are reproducible).
+        NeuS (neus.py:578-617): |rgb - target| (masked mean over target_mask if given: `with_mask`) + w_eikonal * MSE over
+        the nablas of ALL samples + w_mask * BCE(clamp(mask_volume, 1e-3, 1 - 1e-3), target_mask); the radiance net trains
+        if its parameters require grad."""
         if self.is_neus:
-            raise NotImplementedError("reconstruction_step: VolSDF only (the NeuS branch, neus.py:578-617, is a next row)")
+            return self._reconstruction_step_neus(render_fn, rays_o, rays_d, target_rgb, w_eikonal, optimizer, mask_ignore, target_mask,
+                                                  w_mask, **render_kwargs)
+        if eikonal_points is None:
+            raise ValueError("reconstruction_step (VolSDF) needs eikonal_points [N, 3]")
         m = self.model
         o = rays_o.reshape(-1, 3).float().contiguous()
         d = rays_d.reshape(-1, 3).float().contiguous()
@@ -259,6 +268,60 @@ class Trainer(nn.Module):
             _, nab_e, _ = autodiff.surface_forward_with_nablas(m.implicit_surface, eikonal_points.reshape(-1, 3).float())
             nab_e.backward(g_eik)
         return {"loss_img": float(loss_img), "loss_eikonal": float(loss_eik), "total": float(loss_img + loss_eik)}
+
+    def _reconstruction_step_neus(self, render_fn, rays_o, rays_d, target_rgb, w_eikonal, optimizer, mask_ignore, target_mask, w_mask,
+                                  **render_kwargs):
+        m = self.model
+        o = rays_o.reshape(-1, 3).float().contiguous()
+        d = rays_d.reshape(-1, 3).float().contiguous()
+        N = o.shape[0]
+        kw = {k: v for k, v in render_kwargs.items() if k != "rayschunk"}
+        white = kw.get("white_bkgd", False)
+        with torch.no_grad():
+            rgb, _, ex = render_fn(o[None], d[None], detailed_output=True, calc_normal=False, **kw)
+            rgb = rgb.reshape(N, 3)
+            depths = ex["d_all"].reshape(N, -1).contiguous()
+            P = depths.shape[1]
+            acc = ex["mask_volume"].reshape(N)
+            nn_ = ex["implicit_nablas"].reshape(N * P, 3).norm(dim=-1)
+            loss_eik = w_eikonal * ((nn_ - 1.0) ** 2).mean()
+            diff = rgb - target_rgb.reshape(N, 3)
+            g_acc, loss_mask = None, torch.zeros((), device=o.device)
+            weight = None                                             # per-ray weights of the masked image loss (neus.py:600-611)
+            if target_mask is not None:
+                tm = target_mask.reshape(N).float()
+                mv = torch.clamp(acc, 1e-3, 1.0 - 1e-3)
+                loss_mask = w_mask * F.binary_cross_entropy(mv, tm, reduction="mean")
+                inside = ((acc > 1e-3) & (acc < 1.0 - 1e-3)).float()  # clamp passes no gradient outside
+                g_acc = (w_mask / N) * (-(tm / mv) + (1.0 - tm) / (1.0 - mv)) * inside
+                weight = tm if mask_ignore is None else tm * mask_ignore.reshape(N).float()
+            elif mask_ignore is not None:
+                weight = mask_ignore.reshape(N).float()
+            if weight is not None:
+                loss_img = (diff.abs() * weight[:, None]).sum() / (weight.sum() + 1e-10)
+                g_rgb = torch.sign(diff) * weight[:, None] / (weight.sum() + 1e-10)
+            else:
+                loss_img = diff.abs().mean()
+                g_rgb = torch.sign(diff) / diff.numel()
+        if optimizer is not None:
+            optimizer.zero_grad()
+        dn = F.normalize(d, dim=-1)
+        if self.native:
+            if N * P > (1 << 21):
+                raise ValueError("reconstruction_step (NeuS): at most 2^21 sample points per step (the eikonal mean spans the batch)")
+            autodiff.neus_backward_samples_native(m, o, dn, depths, g_rgb, w_eikonal, True, white, g_acc=g_acc)
+        else:
+            out = autodiff.neus_render_samples(m, o, dn, depths, white_bkgd=white, calc_normal=False)
+            nn_g = out["implicit_nablas"].reshape(-1, 3).norm(dim=-1)
+            eik = w_eikonal * F.mse_loss(nn_g, torch.ones_like(nn_g), reduction="mean")
+            tensors, grads = [out["rgb"], eik], [g_rgb, torch.ones_like(eik)]
+            if g_acc is not None:
+                tensors.append(out["mask_volume"]); grads.append(g_acc)
+            torch.autograd.backward(tensors, grads)
+        out = {"loss_img": float(loss_img), "loss_eikonal": float(loss_eik), "total": float(loss_img + loss_eik + loss_mask)}
+        if target_mask is not None:
+            out["loss_mask"] = float(loss_mask)
+        return out
 
     # ---- one fine-tune step ---------------------------------------------------------------------------
     def finetune_step(self, render_fn, rays_o, rays_d, target_rgb, H: int, style_loss, optimizer=None, tile: int = 2048,

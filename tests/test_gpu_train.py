@@ -342,3 +342,32 @@ def test_pass1_state_reuse_matches_recompute():
         for name, ref in res["patchwise"].items():
             rel = float((res[mode][name] - ref).norm() / (ref.norm() + 1e-12))
             assert rel < 2e-3, (mode, name, rel)                  # bf16 operands of the GEMMs are summed in a different order
+
+
+@pytest.mark.parametrize("with_mask", [False, True])
+def test_neus_reconstruction_step_native_matches_autograd(with_mask):
+    """NeuS reconstruction branch (neus.py:578-617): L1 (masked mean with a target mask) + eikonal over all samples + mask
+    BCE on the opacity; every tensor (radiance net included: it trains here) against the autograd formulation."""
+    from nerfart_amd import scene, rend_util
+    from nerfart_amd.trainer import Trainer
+    model, rk, render_fn = scene.build_model("NeuS", seed=0, beta=None, device=DEV, precision="bf16x3")
+    H, W = 10, 9
+    c2w, K = scene.camera(H, W)
+    o, d, _ = rend_util.get_rays(c2w[None].to(DEV), K[None].to(DEV), H, W)
+    g = torch.Generator().manual_seed(21)
+    target = torch.rand(H * W, 3, generator=g).to(DEV)
+    tmask = (torch.rand(H * W, generator=g) > 0.4).to(DEV) if with_mask else None
+    res = {}
+    for native in (False, True):
+        tr = Trainer(model, native=native, freeze_radiance=False)
+        for p in model.parameters():
+            p.requires_grad_(True)
+        model.zero_grad()
+        out = tr.reconstruction_step(render_fn, o[0], d[0], target, w_eikonal=0.1, target_mask=tmask, w_mask=0.3, **rk)
+        res[native] = ({n: p.grad.clone() for n, p in model.named_parameters()}, out)
+        assert all(p.grad is not None for p in model.radiance_net.parameters())
+    assert abs(res[True][1]["total"] - res[False][1]["total"]) < 1e-6
+    assert ("loss_mask" in res[True][1]) == with_mask
+    for name, ref in res[False][0].items():
+        rel = float((res[True][0][name] - ref).norm() / (ref.norm() + 1e-12))
+        assert rel < 3e-2, (name, rel)
