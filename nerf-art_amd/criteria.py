@@ -1,5 +1,5 @@
 """CLIP-driven style losses of the fine-tune step (rows a20-a22): directional CLIP loss, global contrastive loss,
-local PatchNCE loss - the arithmetic of criteria/clip_loss.py:155-304, contrastive_loss.py:91-186 and
+local PatchNCE loss (+ the VGG perceptual term of vgg.py) - the arithmetic of criteria/clip_loss.py:155-304, contrastive_loss.py:91-186 and
 patchnce_loss.py:91-220, including the quirks SURVEY.md (a21, a22, Appendix C) lists.
 
 One CLIP instance is shared by the three heads (the reference loads three identical copies) and text features are
@@ -209,14 +209,16 @@ def create_fine_neg_texts(target_text: str, path: str = "criteria/neg_text.txt")
 
 
 class StyleLoss(nn.Module):
-    """calc_style_loss (volsdf.py:878-915) without the VGG term (out of scope):
-    w_clip * directional + w_contrastive * global + w_patchnce * local."""
+    """calc_style_loss (volsdf.py:878-915): w_clip * directional + w_perceptual * VGG + w_contrastive * global +
+    w_patchnce * local.  `perceptual`: a `vgg.VGGPerceptualLoss` (pass torchvision's vgg16 weights to it
+    for the reference's objective); None leaves the term out."""
 
     def __init__(self, feats: ClipFeatures, target_hw, src_text="photo", target_text="painting", neg_texts=("photo",),
-                 w_clip=1.0, w_contrastive=0.2, w_patchnce=0.1, is_full_res=False, seed=0):
+                 w_clip=1.0, w_contrastive=0.2, w_patchnce=0.1, is_full_res=False, seed=0, perceptual=None, w_perceptual=2.0):
         super().__init__()
         self.clip, self.contrastive = CLIPLoss(feats), ContrastiveLoss(feats)
         self.patchnce = PatchNCELoss(feats, target_hw)
+        self.perceptual, self.w_perceptual = perceptual, w_perceptual
         self.src_text, self.target_text, self.neg_texts = src_text, target_text, list(neg_texts)
         self.w = (w_clip, w_contrastive, w_patchnce)
         self.is_full_res = is_full_res
@@ -224,6 +226,8 @@ class StyleLoss(nn.Module):
 
     def forward(self, rgb_pred, rgb_gt):
         loss = self.w[0] * self.clip(rgb_gt, self.src_text, rgb_pred, self.target_text)
+        if self.perceptual is not None:
+            loss = loss + self.w_perceptual * self.perceptual(rgb_pred, rgb_gt)
         k = torch.randint(0, len(self.neg_texts), (1,), generator=self.gen).item()
         loss = loss + self.w[1] * self.contrastive(rgb_gt, self.neg_texts[k], rgb_pred, self.target_text)
         idx = torch.randperm(len(self.neg_texts), generator=self.gen)[:8].tolist()

@@ -19,8 +19,9 @@ def main():
     ap.add_argument("--pass2-rays", type=int, default=1200)
     ap.add_argument("--patches-per-launch", type=int, default=4)
     ap.add_argument("--no-keep", action="store_true")
+    ap.add_argument("--no-vgg", action="store_true", help="leave the VGG16 perceptual term (random weights) out of the style loss")
     args = ap.parse_args()
-    from nerfart_amd import scene, rend_util, criteria, clip_vit
+    from nerfart_amd import scene, rend_util, criteria, clip_vit, vgg
     from nerfart_amd.trainer import Trainer
     dev = torch.device("cuda", 0)
     model, rk, render_fn = scene.build_model("VolSDF", seed=0, beta=0.01, device=dev, precision="bf16x3")
@@ -28,7 +29,8 @@ def main():
     c2w, K = scene.camera(H, W)
     o, d, _ = rend_util.get_rays(c2w[None].to(dev), K[None].to(dev), H, W)
     feats = criteria.ClipFeatures(model=clip_vit.build_clip(dev, seed=0), device=dev)
-    style = criteria.StyleLoss(feats, (H, W), neg_texts=[f"negative prompt {i}" for i in range(16)])
+    style = criteria.StyleLoss(feats, (H, W), neg_texts=[f"negative prompt {i}" for i in range(16)],
+                               perceptual=None if args.no_vgg else vgg.VGGPerceptualLoss().to(dev))
     with torch.no_grad():
         target, _, _ = render_fn(o, d, detailed_output=False, require_nablas=True, calc_normal=True, **{k: v for k, v in rk.items() if k != "rayschunk"})
     # the "photo" the render is compared with: the render itself, low-pass perturbed (pred == gt would make the
@@ -61,8 +63,8 @@ def main():
         if it > 0:
             times.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3))
     m = [sum(x[i] for x in times) / len(times) for i in range(4)]
-    print(json.dumps({"workload": f"fine-tune step {H}x{W}, VolSDF 128+64 spp, CLIP ViT-B/32 random weights", "steps": args.steps, "pass1_state_kept": not args.no_keep, "patches_per_launch": args.patches_per_launch,
-                      "s_per_step": round(sum(m), 3), "pass1_render_s": round(m[0], 3), "clip_losses_fwd_bwd_s": round(m[1], 3),
+    print(json.dumps({"workload": f"fine-tune step {H}x{W}, VolSDF 128+64 spp, CLIP ViT-B/32 + VGG16 random weights", "steps": args.steps, "pass1_state_kept": not args.no_keep, "patches_per_launch": args.patches_per_launch, "vgg_perceptual_term": not args.no_vgg,
+                      "s_per_step": round(sum(m), 3), "pass1_render_s": round(m[0], 3), "style_losses_fwd_bwd_s": round(m[1], 3),
                       "pass2_sampler_autograd_s": round(m[2], 3), "adam_s": round(m[3], 4), "loss": float(loss), "eikonal": eik,
                       "rays_per_s": round(H * W / sum(m), 1), "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1)}))
 
