@@ -406,7 +406,9 @@ struct Items {
                     }
                 }
             }
+#ifndef NERFART_EXP_NOSCHED
             __builtin_amdgcn_sched_barrier(0);
+#endif
             Items<L, C, NKC, IT + 1>::run(P, Q, xb, xs, x0n, w, r, addr, s, ec, gc);
         }
     }

@@ -48,6 +48,12 @@ k_sdf_only_bf16(const float* __restrict__ blob, PointSrc src, float R_bg, float*
     Stream s = make_stream(blob, aux, smem, hdr[2]);
     s.wrap = (blockIdx.x + gridDim.x) < ntiles;
     stream_start(s);
+#ifdef NERFART_EXP_PRIO_YOUNG      // timing experiments (tools/ablate_bf16.py): static priority for one half of the waves
+    if (wv >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
+#ifdef NERFART_EXP_PRIO_OLD
+    if (wv < 4) __builtin_amdgcn_s_setprio(1);
+#endif
     for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         s.wrap = (tile + gridDim.x) < ntiles;
         const unsigned m = tile * 128u + wv * 16 + j;

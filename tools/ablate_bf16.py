@@ -10,6 +10,9 @@ VARIANTS = {"full": [], "nodma": ["-DNERFART_ABLATE_DMA"], "noepi": ["-DNERFART_
             "mfma_only": ["-DNERFART_ABLATE_DMA", "-DNERFART_ABLATE_EPI", "-DNERFART_ABLATE_LDSREAD"],
             "nobarrier": ["-DNERFART_ABLATE_BARRIER"], "nobarrier_novmwait": ["-DNERFART_ABLATE_BARRIER", "-DNERFART_ABLATE_VMWAIT"],
             "mfma_only_nobarrier": ["-DNERFART_ABLATE_DMA", "-DNERFART_ABLATE_EPI", "-DNERFART_ABLATE_LDSREAD", "-DNERFART_ABLATE_BARRIER"]}
+if os.environ.get("NERFART_ABLATE_SET") == "exp":      # scheduling experiments (results stay correct except where noted)
+    VARIANTS = {"full": [], "prio_young": ["-DNERFART_EXP_PRIO_YOUNG"], "prio_old": ["-DNERFART_EXP_PRIO_OLD"],
+                "nosched": ["-DNERFART_EXP_NOSCHED"]}
 OUT = os.path.join(ROOT, "gpurun_ablate")
 
 def build():
@@ -17,7 +20,7 @@ def build():
     srcs = ["capi_common.cpp", "mlp_chain.hip", "mlp_chain_bf16.hip", "mlp_grad_bf16.hip", "mlp_backward_bf16.hip", "volsdf_render.hip", "volsdf_backward.hip", "neus_render.hip", "raygen.hip"]
     for name, flags in VARIANTS.items():
         lib = os.path.join(OUT, f"lib_{name}.so")
-        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip"] + flags + \
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-shared", "-x", "hip"] + flags + \
               [os.path.join(CSRC, s) for s in srcs] + ["-o", lib]
         print(" ".join(cmd[-3:]), flush=True)
         subprocess.check_call(cmd)
