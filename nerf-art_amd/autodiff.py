@@ -366,7 +366,7 @@ def volsdf_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikon
 
 
 def neus_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikonal=0.1, use_eikonal=True, white_bkgd=False, s_val=None, accum=None,
-                                 eik_group_rays=None, g_acc=None):
+                                 eik_group_rays=None, g_acc=None, state=None):
     """Pass 2 for one NeuS patch on the hand-written kernels + GEMMs (neus.py:310-395, :520-576): SDF + nablas at the P
     samples (alpha, eikonal), SDF + nablas + radiance at the P-1 mid-points.  Radiance-net gradients are accumulated only if
     its parameters require grad (the fine-tune step freezes it, neus.py:455-456; reconstruction trains it).  g_acc [R]: a
@@ -381,7 +381,8 @@ def neus_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikonal
     with torch.no_grad():
         if s_val is None:
             s_val = float(model.forward_s())
-        sdf, nab, _ = hip.sdf_nabla_fwd(surf_blob, pts, 0.0, want_h7=False, precision=model.precision_id)
+        # state: (sdf, nablas, _) at the samples kept from pass 1 (same weights: identical values)
+        sdf, nab, _ = state if state is not None else hip.sdf_nabla_fwd(surf_blob, pts, 0.0, want_h7=False, precision=model.precision_id)
         _, nab_m, h7_m = hip.sdf_nabla_fwd(surf_blob, pts_m, 0.0, precision=model.precision_id)
         rgb_m, dump = hip.radiance_fwd_dump(rad_blob, model.view_tiles, pts_m, v_m, nab_m, h7_m)
         g_sdf, g_rad, g_s = hip.neus_composite_bwd(sdf.reshape(R, P), rgb_m.reshape(R, P - 1, 3), s_val, g_rgb.contiguous(), white_bkgd,

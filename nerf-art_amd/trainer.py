@@ -92,7 +92,7 @@ class Trainer(nn.Module):
 
     @torch.no_grad()
     def render_keep(self, rays_o, rays_d, **rk):
-        """Pass 1 of the native VolSDF fine-tune step, on the per-stage C-ABI entries in the fused renderer's order (sampler,
+        """Pass 1 of the native fine-tune step with state kept for pass 2.  VolSDF: on the per-stage C-ABI entries in the fused renderer's order (sampler,
         k_sdf_grad, radiance, composite), KEEPING every launch group's sample depths, sdf, nablas and layer-7 activations
         (1 KiB / point in HBM) for pass 2: the weights do not change between the passes and perturb=False is
         deterministic, so pass 2 would recompute exactly these.  Returns rgb [N, 3]; the state waits in self._kept."""
@@ -100,6 +100,25 @@ class Trainer(nn.Module):
         o = rays_o.reshape(-1, 3).float().contiguous()
         d_raw = rays_d.reshape(-1, 3).float().contiguous()
         surf_blob, rad_blob = m.packed()
+        if self.is_neus:
+            # NeuS: the fused renderer's detailed outputs already hold what pass 2 needs at the P samples (depths, sdf,
+            # nablas); the mid-point quantities are re-evaluated in pass 2
+            ni = rk.get("N_importance", 64)
+            P = rk.get("N_samples", 64) + ni
+            step = self._launch_rays(P)
+            s_val = float(m.forward_s().detach())
+            kept, rgbs = [], []
+            for i in range(0, o.shape[0], step):
+                oi, di = o[i:i + step], d_raw[i:i + step]
+                out = hip.neus_render(surf_blob, rad_blob, m.view_tiles, oi, di, obj_bounding_radius=rk.get("obj_bounding_radius", 1.0),
+                                      s=s_val, n_samples=rk.get("N_samples", 64), n_importance=ni,
+                                      n_upsample_iters=rk.get("N_upsample_iters", 4), white_bkgd=rk.get("white_bkgd", False),
+                                      calc_normal=False, detailed=True, precision=m.precision_id,
+                                      u_new=torch.rand(oi.shape[0], ni, device=o.device) if rk.get("perturb", False) else None)
+                kept.append((out["d_all"], out["implicit_surface"].reshape(-1), out["implicit_nablas"].reshape(-1, 3), None))
+                rgbs.append(out["rgb"])
+            self._kept = kept
+            return torch.cat(rgbs, 0) if rgbs else torch.zeros(0, 3, device=o.device)
         alpha, beta = m.forward_ab()
         ab = (float(alpha.detach()), float(beta.detach()))
         white = rk.get("white_bkgd", False)
@@ -166,7 +185,7 @@ class Trainer(nn.Module):
                         depths = self._samples(o, dn, d_raw, render_kwargs)
                 if self.is_neus:
                     eik = autodiff.neus_backward_samples_native(self.model, o, dn, depths, g, self.w_eikonal, self.use_eikonal, white,
-                                                                s_val=s_val, accum=accum, eik_group_rays=self.pass2_rays)
+                                                                s_val=s_val, accum=accum, eik_group_rays=self.pass2_rays, state=state)
                 else:
                     eik = autodiff.volsdf_backward_samples_native(self.model, o, dn, depths, g, self.w_eikonal, self.use_eikonal, white,
                                                                   ab=ab, accum=accum, state=state, eik_group_rays=self.pass2_rays)
@@ -333,7 +352,7 @@ class Trainer(nn.Module):
         loss on the full image and keeps its own rays' d loss / d rgb; pass 2 runs on its own rays; one flat
         all-reduce(SUM) of the gradients before the caller's optimizer.step()."""
         sharded = nd.world_size() > 1
-        keep = self.native and not self.is_neus           # pass 1 on the staged entries, its per-point state kept for pass 2
+        keep = self.native                                # pass 1 keeps its per-point state for pass 2 (render_keep)
         self._kept = None
         if sharded:
             kw = {k: v for k, v in render_kwargs.items() if k != "rayschunk"}

@@ -371,3 +371,39 @@ def test_neus_reconstruction_step_native_matches_autograd(with_mask):
     for name, ref in res[False][0].items():
         rel = float((res[True][0][name] - ref).norm() / (ref.norm() + 1e-12))
         assert rel < 3e-2, (name, rel)
+
+
+def test_neus_pass1_state_reuse_matches_recompute():
+    """NeuS: render_keep = the fused renderer with its per-sample outputs kept; pass 2 from them equals pass 2 that re-samples."""
+    from nerfart_amd import scene, rend_util
+    from nerfart_amd.trainer import Trainer
+    model, rk, render_fn = scene.build_model("NeuS", seed=0, beta=None, device=DEV, precision="bf16x3")
+    H, W = 9, 7
+    c2w, K = scene.camera(H, W)
+    o, d, _ = rend_util.get_rays(c2w[None].to(DEV), K[None].to(DEV), H, W)
+    g = torch.rand(H * W, 3, generator=torch.Generator().manual_seed(6)).to(DEV) * 1e-2
+    kw = {k: v for k, v in rk.items() if k != "rayschunk"}
+    with torch.no_grad():
+        ref_rgb, _, _ = render_fn(o, d, detailed_output=False, calc_normal=False, **kw)
+    res, eiks = {}, {}
+    for mode in ("recompute", "kept"):
+        tr = Trainer(model, pass2_rays=16, patches_per_launch=2)
+        model.zero_grad()
+        kept = None
+        if mode == "kept":
+            rgb = tr.render_keep(o[0], d[0], **kw)
+            np.testing.assert_allclose(rgb.cpu().numpy(), ref_rgb.reshape(-1, 3).cpu().numpy(), atol=1e-6, rtol=0)
+            kept = tr._kept
+            assert [k[0].shape[0] for k in kept] == [32, 31]
+        eiks[mode] = tr.backward_patches(o[0], d[0], g, kept=kept, **kw)
+        res[mode] = {n: (None if p.grad is None else p.grad.clone()) for n, p in model.named_parameters()}
+    assert abs(eiks["kept"] - eiks["recompute"]) <= 1e-5 * abs(eiks["recompute"]) + 1e-9
+    for name, ref in res["recompute"].items():
+        if ref is None:
+            assert res["kept"][name] is None
+            continue
+        rel = float((res["kept"][name] - ref).norm() / (ref.norm() + 1e-12))
+        assert rel < 2e-3, (name, rel)
+    # and the whole step runs on it
+    out = tr.finetune_step(render_fn, o, d, torch.rand(1, H * W, 3, device=DEV), H, lambda p, t: ((p - t) ** 2).mean(), **kw)
+    assert np.isfinite(out["loss"]) and np.isfinite(out["eikonal"])
