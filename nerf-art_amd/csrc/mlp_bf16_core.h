@@ -57,6 +57,24 @@ __device__ __forceinline__ f32x4 mfma3(const u32x4 ah, const u32x4 al, const u32
     return acc;
 }
 
+// Two accumulator chains interleaved: the triples of tiles T-1 and T (same B unit) issued alternately, so that no MFMA
+// depends on the one just before it.
+__device__ __forceinline__ void mfma6(const u32x4 ah0, const u32x4 al0, const u32x4 ah1, const u32x4 al1, const u32x4 bh,
+                                      const u32x4 bl, f32x4& a0, f32x4& a1) {
+#ifdef NERFART_ABLATE_MFMA
+    asm volatile("" :: "v"(ah0), "v"(al0), "v"(ah1), "v"(al1), "v"(bh), "v"(bl));
+    return;
+#endif
+    asm volatile("s_nop 1\n\t"
+                 "v_mfma_f32_16x16x32_bf16 %0, %2, %6, %0\n\t"
+                 "v_mfma_f32_16x16x32_bf16 %1, %4, %6, %1\n\t"
+                 "v_mfma_f32_16x16x32_bf16 %0, %2, %7, %0\n\t"
+                 "v_mfma_f32_16x16x32_bf16 %1, %4, %7, %1\n\t"
+                 "v_mfma_f32_16x16x32_bf16 %0, %3, %6, %0\n\t"
+                 "v_mfma_f32_16x16x32_bf16 %1, %5, %6, %1"
+                 : "+v"(a0), "+v"(a1) : "v"(ah0), "v"(al0), "v"(ah1), "v"(al1), "v"(bh), "v"(bl));
+}
+
 // ---------------------------------------------------------------------------------------
 // Weight stream: chunk c is consumed from LDS buffer pb while chunk c+1 is streamed into buffer pb^1 in
 // 1 KiB pieces issued BETWEEN the MFMAs of chunk c (stream_piece), not in a burst after the barrier.
@@ -288,7 +306,12 @@ __device__ __forceinline__ void d_load(GradCtx& gc, int idx, int buf) {
 // one epilogue slice (last 12 items of a hosting k-step).  LDS returns in order: with items it, it+1, it+2
 // outstanding (2 reads each) item it has landed at lgkmcnt(4) (cdna_hip_programming.md 5.7, form ii).
 // ---------------------------------------------------------------------------------------
-template <int NS> struct RingT { u32x4 h[NS], l[NS]; };   // AHEAD + 1 slots
+template <int NS> struct RingT { u32x4 h[NS], l[NS]; };   // AHEAD + 1 slots (+ RING_EXTRA)
+#ifdef NERFART_EXP_PAIR      // experiment: tiles are multiplied in pairs (mfma6); the fragments of item it-1 live one item longer
+constexpr int RING_EXTRA = 1;
+#else
+constexpr int RING_EXTRA = 0;
+#endif
 struct Ring3 { u32x4 h0, l0, h1, l1, h2, l2; };     // fixed 3-slot ring of the reverse-mode tail
 
 template <int OFF>
@@ -303,6 +326,10 @@ __device__ __forceinline__ void lds_read_pair(u32x4& fh, u32x4& fl, unsigned add
 template <int CNT>
 __device__ __forceinline__ void lds_wait_pair(u32x4& fh, u32x4& fl) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fh), "+v"(fl) : "i"(CNT));
+}
+template <int CNT>
+__device__ __forceinline__ void lds_wait_pair2(u32x4& fh0, u32x4& fl0, u32x4& fh1, u32x4& fl1) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fh0), "+v"(fl0), "+v"(fh1), "+v"(fl1) : "i"(CNT));
 }
 
 // Layer shape: NH input units come from the previous layer's accumulators P (k-steps 0..NH-1, built just in
@@ -326,11 +353,11 @@ struct Cfg {
 template <class L, int C, int NKC, int IT>
 struct Items {
     static __device__ __forceinline__ void run(const Acc& P, Acc& Q, Unit (&xb)[2], const Unit (&xs)[L::NXA], Unit& x0n, Work& w,
-                                               RingT<L::AHEAD + 1>& r, unsigned addr, const Stream& s, const EpiCtx& ec, GradCtx& gc) {
+                                               RingT<L::AHEAD + 1 + RING_EXTRA>& r, unsigned addr, const Stream& s, const EpiCtx& ec, GradCtx& gc) {
         constexpr int N = NKC * 16;
         if constexpr (IT < N) {
             constexpr int kk = IT >> 4, T = IT & 15, ks = CHUNK_KS * C + kk;
-            constexpr int AH = L::AHEAD, NS = AH + 1;
+            constexpr int AH = L::AHEAD, NS = AH + 1 + RING_EXTRA;
             constexpr int S = IT % NS, S2 = (IT + AH) % NS;
             constexpr int LEFT = N - 1 - IT;
             constexpr int PENDING = 2 * (LEFT < AH ? LEFT : AH);
@@ -338,8 +365,16 @@ struct Items {
             u32x4 bh, bl;
             if constexpr (ks < L::NH) { bh = xb[ks & 1].h; bl = xb[ks & 1].l; }
             else { bh = xs[ks - L::NH].h; bl = xs[ks - L::NH].l; }
+#ifdef NERFART_EXP_PAIR
+            if constexpr ((T & 1) != 0) {
+                constexpr int SP = (IT - 1) % NS;
+                lds_wait_pair2<PENDING>(r.h[SP], r.l[SP], r.h[S], r.l[S]);
+                mfma6(r.h[SP], r.l[SP], r.h[S], r.l[S], bh, bl, Q.t[T - 1], Q.t[T]);
+            }
+#else
             lds_wait_pair<PENDING>(r.h[S], r.l[S]);
             Q.t[T] = mfma3(r.h[S], r.l[S], bh, bl, Q.t[T]);
+#endif
             constexpr int HU = L::hosted(ks);
             constexpr int HM = L::mode_of(HU);
             if constexpr (T == 0) {
@@ -424,7 +459,7 @@ __device__ __forceinline__ void run_chunk(const Acc& P, Acc& Q, Unit (&xb)[2], c
         // everything the compiler itself has in flight on the LDS queue must be drained first: the counted
         // waits below assume only the ring's reads are outstanding
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        RingT<L::AHEAD + 1> r;
+        RingT<L::AHEAD + 1 + RING_EXTRA> r;
         lds_read_pair<0>(r.h[0], r.l[0], addr);
         lds_read_pair<2048>(r.h[1], r.l[1], addr);
         if constexpr (L::AHEAD >= 3) lds_read_pair<4096>(r.h[2], r.l[2], addr);

@@ -13,6 +13,8 @@ VARIANTS = {"full": [], "nodma": ["-DNERFART_ABLATE_DMA"], "noepi": ["-DNERFART_
 if os.environ.get("NERFART_ABLATE_SET") == "exp":      # scheduling experiments (results stay correct except where noted)
     VARIANTS = {"full": [], "prio_young": ["-DNERFART_EXP_PRIO_YOUNG"], "prio_old": ["-DNERFART_EXP_PRIO_OLD"],
                 "nosched": ["-DNERFART_EXP_NOSCHED"]}
+if os.environ.get("NERFART_ABLATE_SET") == "pair":     # tiles multiplied in pairs, accumulator chains interleaved (results correct)
+    VARIANTS = {"full": [], "pair": ["-DNERFART_EXP_PAIR"], "pair_mfma_only": ["-DNERFART_EXP_PAIR", "-DNERFART_ABLATE_DMA", "-DNERFART_ABLATE_EPI", "-DNERFART_ABLATE_LDSREAD"]}
 OUT = os.path.join(ROOT, "gpurun_ablate")
 
 def build():
