@@ -405,9 +405,22 @@ struct Items {
             }
             // LDS-DMA: the 8 pieces per wave of the next chunk go out during items 5..8 of each k-step (after the
             // first use of a softplus' unit in item 4: the compiler's wait for that load drains the VMEM queue)
-            if constexpr (T >= 5 && T < 9) {
-                if constexpr (NKC == 2) stream_piece<kk * 4 + T - 5>(s);
-                else { stream_piece<2 * (T - 5)>(s); stream_piece<2 * (T - 5) + 1>(s); }
+#if defined(NERFART_EXP_DMA_SPREAD)          // experiment: one piece every 4th item instead of 4 in a row
+            constexpr bool DMA_HERE = (T % 4) == NERFART_EXP_DMA_SPREAD;
+            constexpr int DMA_J = T / 4;
+#elif defined(NERFART_EXP_DMA_T0)            // experiment: the 4 pieces of a k-step start at another item
+            constexpr bool DMA_HERE = T >= NERFART_EXP_DMA_T0 && T < NERFART_EXP_DMA_T0 + 4;
+            constexpr int DMA_J = T - NERFART_EXP_DMA_T0;
+#else
+            // plain softplus layers (no unit loads / stores on the VMEM queue): items 0..3, which host no epilogue slice
+            // (-1.5 % on k_sdf_only_bf16); elsewhere after item 4, see above
+            constexpr int DMA_T0 = (L::MODE == 0 && L::MQ == 0) ? 0 : 5;
+            constexpr bool DMA_HERE = T >= DMA_T0 && T < DMA_T0 + 4;
+            constexpr int DMA_J = T - DMA_T0;
+#endif
+            if constexpr (DMA_HERE) {
+                if constexpr (NKC == 2) stream_piece<kk * 4 + DMA_J>(s);
+                else { stream_piece<2 * DMA_J>(s); stream_piece<2 * DMA_J + 1>(s); }
             }
             // epilogue slice hosted by this item
             if constexpr (HU >= 0 && T >= 4) {

@@ -15,6 +15,9 @@ if os.environ.get("NERFART_ABLATE_SET") == "exp":      # scheduling experiments 
                 "nosched": ["-DNERFART_EXP_NOSCHED"]}
 if os.environ.get("NERFART_ABLATE_SET") == "pair":     # tiles multiplied in pairs, accumulator chains interleaved (results correct)
     VARIANTS = {"full": [], "pair": ["-DNERFART_EXP_PAIR"], "pair_mfma_only": ["-DNERFART_EXP_PAIR", "-DNERFART_ABLATE_DMA", "-DNERFART_ABLATE_EPI", "-DNERFART_ABLATE_LDSREAD"]}
+if os.environ.get("NERFART_ABLATE_SET") == "dma":      # where the LDS-DMA pieces sit among the items (k_sdf_only: results correct)
+    VARIANTS = {"full": [], "t0_0": ["-DNERFART_EXP_DMA_T0=0"], "t0_2": ["-DNERFART_EXP_DMA_T0=2"], "t0_12": ["-DNERFART_EXP_DMA_T0=12"],
+                "spread0": ["-DNERFART_EXP_DMA_SPREAD=0"], "spread2": ["-DNERFART_EXP_DMA_SPREAD=2"]}
 OUT = os.path.join(ROOT, "gpurun_ablate")
 
 def build():
