@@ -24,6 +24,7 @@ constexpr int RAD_DUMP_PER_TILE = 5 * 8 * 8 * 1024;      // radiance: 5 activati
 struct Unit { u32x4 h, l; };                        // 32 feature slots: packed bf16 pairs, hi and lo terms
 struct Acc { f32x4 t[16]; };
 struct Work { float e0, e1, r0, r1, y0, y1; };      // values carried between the slices of one epilogue pair
+struct Work2 : Work { Work b; };                    // ... of two pairs in flight (plain softplus layers, see Items)
 struct EpiCtx {
     float floor_p, floor_q;                         // ReLU family: activation floor of the previous / this layer's output
     bool is_val;                                    // tangent kernels: this lane is a value column
@@ -352,7 +353,7 @@ struct Cfg {
 
 template <class L, int C, int NKC, int IT>
 struct Items {
-    static __device__ __forceinline__ void run(const Acc& P, Acc& Q, Unit (&xb)[2], const Unit (&xs)[L::NXA], Unit& x0n, Work& w,
+    static __device__ __forceinline__ void run(const Acc& P, Acc& Q, Unit (&xb)[2], const Unit (&xs)[L::NXA], Unit& x0n, Work2& w,
                                                RingT<L::AHEAD + 1 + RING_EXTRA>& r, unsigned addr, const Stream& s, const EpiCtx& ec, GradCtx& gc) {
         constexpr int N = NKC * 16;
         if constexpr (IT < N) {
@@ -423,6 +424,30 @@ struct Items {
                 else { stream_piece<2 * DMA_J>(s); stream_piece<2 * DMA_J + 1>(s); }
             }
             // epilogue slice hosted by this item
+#ifdef NERFART_EXP_EPI2      // experiment: plain softplus layers run TWO independent pairs per slice (items 4..9), ILP 2
+            constexpr bool EPI2 = (HU >= 0) && (HM == 0);
+#else
+            constexpr bool EPI2 = false;
+#endif
+            if constexpr (EPI2) {
+                if constexpr (T >= 4 && T < 10) {
+                    constexpr int ph = (T - 4) % 3, pq = (T - 4) / 3;
+                    constexpr int tile = (HU == 100 ? 0 : 2 * HU) + pq;
+                    unsigned hiA = 0, loA = 0, hiB = 0, loB = 0, dout = 0;
+                    if constexpr (HU == 100) {
+                        epi_phase<0, ph>(Q.t[tile][0], Q.t[tile][1], w, hiA, loA, ec.floor_q, ec.is_val, 0u, dout);
+                        epi_phase<0, ph>(Q.t[tile][2], Q.t[tile][3], w.b, hiB, loB, ec.floor_q, ec.is_val, 0u, dout);
+                        if constexpr (ph == 2) { x0n.h[2 * pq] = hiA; x0n.l[2 * pq] = loA; x0n.h[2 * pq + 1] = hiB; x0n.l[2 * pq + 1] = loB; }
+                    } else {
+                        epi_phase<0, ph>(P.t[tile][0], P.t[tile][1], w, hiA, loA, ec.floor_p, ec.is_val, 0u, dout);
+                        epi_phase<0, ph>(P.t[tile][2], P.t[tile][3], w.b, hiB, loB, ec.floor_p, ec.is_val, 0u, dout);
+                        if constexpr (ph == 2) {
+                            xb[HU & 1].h[2 * pq] = hiA; xb[HU & 1].l[2 * pq] = loA;
+                            xb[HU & 1].h[2 * pq + 1] = hiB; xb[HU & 1].l[2 * pq + 1] = loB;
+                        }
+                    }
+                }
+            } else
             if constexpr (HU >= 0 && T >= 4) {
                 constexpr int pr = (T - 4) / 3, ph = (T - 4) % 3;
                 constexpr int tile = (HU == 100 ? 0 : 2 * HU) + (pr >> 1), r0 = 2 * (pr & 1);
@@ -464,7 +489,7 @@ struct Items {
 
 template <class L, int C>
 __device__ __forceinline__ void run_chunk(const Acc& P, Acc& Q, Unit (&xb)[2], const Unit (&xs)[L::NXA], Unit& x0n,
-                                          Work& w, Stream& s, const EpiCtx& ec, GradCtx& gc) {
+                                          Work2& w, Stream& s, const EpiCtx& ec, GradCtx& gc) {
     constexpr int NKC = (L::NKS - CHUNK_KS * C) >= CHUNK_KS ? CHUNK_KS : (L::NKS - CHUNK_KS * C);
     if constexpr (NKC > 0) {
         const float* wp = stream_acquire(s) + lane_id() * 4;
@@ -500,7 +525,7 @@ __device__ __forceinline__ void layer(const Acc& P, Acc& Q, const Unit& x0, cons
             for (int r = 0; r < 4; ++r) Q.t[T][r] = ec.is_val ? b[r] : 0.f;
         }
     }
-    Work w = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    Work2 w = {};
     run_chunk<L, 0>(P, Q, xb, xs, x0n, w, s, ec, gc);
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");     // last MFMA result -> first VALU reader (see mfma3)
 }

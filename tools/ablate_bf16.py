@@ -18,6 +18,8 @@ if os.environ.get("NERFART_ABLATE_SET") == "pair":     # tiles multiplied in pai
 if os.environ.get("NERFART_ABLATE_SET") == "dma":      # where the LDS-DMA pieces sit among the items (k_sdf_only: results correct)
     VARIANTS = {"full": [], "t0_0": ["-DNERFART_EXP_DMA_T0=0"], "t0_2": ["-DNERFART_EXP_DMA_T0=2"], "t0_12": ["-DNERFART_EXP_DMA_T0=12"],
                 "spread0": ["-DNERFART_EXP_DMA_SPREAD=0"], "spread2": ["-DNERFART_EXP_DMA_SPREAD=2"]}
+if os.environ.get("NERFART_ABLATE_SET") == "epi2":     # two independent epilogue pairs per slice (results correct)
+    VARIANTS = {"full": [], "epi2": ["-DNERFART_EXP_EPI2"]}
 OUT = os.path.join(ROOT, "gpurun_ablate")
 
 def build():
