@@ -114,7 +114,11 @@ __device__ __forceinline__ void stream_piece(const Stream& s) {
     asm volatile("s_mov_b32 %0, m0\n\t"
                  "s_add_u32 m0, %3, %4\n\t"
                  "s_nop 0\n\t"
+#ifdef NERFART_EXP_DMA_NT     // experiment: non-temporal hint on the weight stream
+                 "global_load_lds_dwordx4 %1, %2 offset:%5 nt\n\t"
+#else
                  "global_load_lds_dwordx4 %1, %2 offset:%5\n\t"
+#endif
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(J < 4 ? s.voff_a : s.voff_b), "s"(s.iss_src), "s"(s.iss_dst), "i"((J & 4) * 1024), "i"((J & 3) * 1024)

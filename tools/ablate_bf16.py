@@ -20,6 +20,10 @@ if os.environ.get("NERFART_ABLATE_SET") == "dma":      # where the LDS-DMA piece
                 "spread0": ["-DNERFART_EXP_DMA_SPREAD=0"], "spread2": ["-DNERFART_EXP_DMA_SPREAD=2"]}
 if os.environ.get("NERFART_ABLATE_SET") == "epi2":     # two independent epilogue pairs per slice (results correct)
     VARIANTS = {"full": [], "epi2": ["-DNERFART_EXP_EPI2"]}
+if os.environ.get("NERFART_ABLATE_SET") == "iso":      # the non-MFMA stream in isolation, and a non-temporal weight stream
+    VARIANTS = {"full": [], "dma_nt": ["-DNERFART_EXP_DMA_NT"],
+                "nomfma_nodma": ["-DNERFART_ABLATE_MFMA", "-DNERFART_ABLATE_DMA"], "nomfma_noepi": ["-DNERFART_ABLATE_MFMA", "-DNERFART_ABLATE_EPI"],
+                "nomfma_noldsread": ["-DNERFART_ABLATE_MFMA", "-DNERFART_ABLATE_LDSREAD"], "dma_only": ["-DNERFART_ABLATE_MFMA", "-DNERFART_ABLATE_EPI", "-DNERFART_ABLATE_LDSREAD"]}
 OUT = os.path.join(ROOT, "gpurun_ablate")
 
 def build():
