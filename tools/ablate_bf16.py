@@ -24,6 +24,10 @@ if os.environ.get("NERFART_ABLATE_SET") == "iso":      # the non-MFMA stream in 
     VARIANTS = {"full": [], "dma_nt": ["-DNERFART_EXP_DMA_NT"],
                 "nomfma_nodma": ["-DNERFART_ABLATE_MFMA", "-DNERFART_ABLATE_DMA"], "nomfma_noepi": ["-DNERFART_ABLATE_MFMA", "-DNERFART_ABLATE_EPI"],
                 "nomfma_noldsread": ["-DNERFART_ABLATE_MFMA", "-DNERFART_ABLATE_LDSREAD"], "dma_only": ["-DNERFART_ABLATE_MFMA", "-DNERFART_ABLATE_EPI", "-DNERFART_ABLATE_LDSREAD"]}
+if os.environ.get("NERFART_ABLATE_SET") == "skel":     # what is left when every per-item component is compiled out
+    A = ["-DNERFART_ABLATE_MFMA", "-DNERFART_ABLATE_EPI", "-DNERFART_ABLATE_LDSREAD"]
+    VARIANTS = {"dma_only": A, "skeleton": A + ["-DNERFART_ABLATE_DMA"], "skeleton_nobarrier": A + ["-DNERFART_ABLATE_DMA", "-DNERFART_ABLATE_BARRIER"],
+                "skeleton_nobarrier_novmwait": A + ["-DNERFART_ABLATE_DMA", "-DNERFART_ABLATE_BARRIER", "-DNERFART_ABLATE_VMWAIT"]}
 OUT = os.path.join(ROOT, "gpurun_ablate")
 
 def build():
