@@ -76,6 +76,31 @@ __device__ __forceinline__ void mfma6(const u32x4 ah0, const u32x4 al0, const u3
                  : "+v"(a0), "+v"(a1) : "v"(ah0), "v"(al0), "v"(ah1), "v"(al1), "v"(bh), "v"(bl));
 }
 
+// Four accumulator chains interleaved (tiles T..T+3 against the same B unit): 12 MFMAs none of which depends on its three
+// predecessors, each chain still hh -> hl -> lh.  One wave can keep the matrix pipe busy alone with this block.
+__device__ __forceinline__ void mfma12(const u32x4 (&ah)[4], const u32x4 (&al)[4], const u32x4 bh, const u32x4 bl,
+                                       f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3) {
+#ifdef NERFART_ABLATE_MFMA
+    asm volatile("" :: "v"(ah[0]), "v"(al[0]), "v"(ah[1]), "v"(al[1]), "v"(ah[2]), "v"(al[2]), "v"(ah[3]), "v"(al[3]), "v"(bh), "v"(bl));
+    return;
+#endif
+    asm volatile("s_nop 1\n\t"
+                 "v_mfma_f32_16x16x32_bf16 %0, %4, %12, %0\n\t"
+                 "v_mfma_f32_16x16x32_bf16 %1, %5, %12, %1\n\t"
+                 "v_mfma_f32_16x16x32_bf16 %2, %6, %12, %2\n\t"
+                 "v_mfma_f32_16x16x32_bf16 %3, %7, %12, %3\n\t"
+                 "v_mfma_f32_16x16x32_bf16 %0, %4, %13, %0\n\t"
+                 "v_mfma_f32_16x16x32_bf16 %1, %5, %13, %1\n\t"
+                 "v_mfma_f32_16x16x32_bf16 %2, %6, %13, %2\n\t"
+                 "v_mfma_f32_16x16x32_bf16 %3, %7, %13, %3\n\t"
+                 "v_mfma_f32_16x16x32_bf16 %0, %8, %12, %0\n\t"
+                 "v_mfma_f32_16x16x32_bf16 %1, %9, %12, %1\n\t"
+                 "v_mfma_f32_16x16x32_bf16 %2, %10, %12, %2\n\t"
+                 "v_mfma_f32_16x16x32_bf16 %3, %11, %12, %3"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+                 : "v"(ah[0]), "v"(ah[1]), "v"(ah[2]), "v"(ah[3]), "v"(al[0]), "v"(al[1]), "v"(al[2]), "v"(al[3]), "v"(bh), "v"(bl));
+}
+
 // ---------------------------------------------------------------------------------------
 // Weight stream: chunk c is consumed from LDS buffer pb while chunk c+1 is streamed into buffer pb^1 in
 // 1 KiB pieces issued BETWEEN the MFMAs of chunk c (stream_piece), not in a burst after the barrier.
@@ -312,7 +337,7 @@ __device__ __forceinline__ void d_load(GradCtx& gc, int idx, int buf) {
 // outstanding (2 reads each) item it has landed at lgkmcnt(4) (cdna_hip_programming.md 5.7, form ii).
 // ---------------------------------------------------------------------------------------
 template <int NS> struct RingT { u32x4 h[NS], l[NS]; };   // AHEAD + 1 slots (+ RING_EXTRA)
-#ifdef NERFART_EXP_PAIR      // experiment: tiles are multiplied in pairs (mfma6); the fragments of item it-1 live one item longer
+#if defined(NERFART_EXP_PAIR) || defined(NERFART_EXP_SEG4)   // experiments: tiles multiplied in pairs (mfma6) / fours (mfma12)
 constexpr int RING_EXTRA = 1;
 #else
 constexpr int RING_EXTRA = 0;
@@ -331,6 +356,10 @@ __device__ __forceinline__ void lds_read_pair(u32x4& fh, u32x4& fl, unsigned add
 template <int CNT>
 __device__ __forceinline__ void lds_wait_pair(u32x4& fh, u32x4& fl) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fh), "+v"(fl) : "i"(CNT));
+}
+template <int NS>
+__device__ __forceinline__ void lds_wait_ring4(RingT<NS>& r) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.h[0]), "+v"(r.l[0]), "+v"(r.h[1]), "+v"(r.l[1]), "+v"(r.h[2]), "+v"(r.l[2]), "+v"(r.h[3]), "+v"(r.l[3]));
 }
 template <int CNT>
 __device__ __forceinline__ void lds_wait_pair2(u32x4& fh0, u32x4& fl0, u32x4& fh1, u32x4& fl1) {
@@ -366,11 +395,27 @@ struct Items {
             constexpr int S = IT % NS, S2 = (IT + AH) % NS;
             constexpr int LEFT = N - 1 - IT;
             constexpr int PENDING = 2 * (LEFT < AH ? LEFT : AH);
+#ifndef NERFART_EXP_SEG4
             if constexpr (IT + AH < N) lds_read_pair<(IT + AH) * 2048>(r.h[S2], r.l[S2], addr);
+#endif
             u32x4 bh, bl;
             if constexpr (ks < L::NH) { bh = xb[ks & 1].h; bl = xb[ks & 1].l; }
             else { bh = xs[ks - L::NH].h; bl = xs[ks - L::NH].l; }
-#ifdef NERFART_EXP_PAIR
+#if defined(NERFART_EXP_SEG4)
+            // segmented stream: items 4s..4s+3 are multiplied as ONE block of 12 independent MFMAs at item 4s, the fragments
+            // of the next four items are requested right behind it, and the fillers of the four items follow
+            static_assert(NS == 4, "segments of four items need a four-slot ring");
+            if constexpr ((T & 3) == 0) {
+                lds_wait_ring4(r);
+                mfma12(r.h, r.l, bh, bl, Q.t[T], Q.t[T + 1], Q.t[T + 2], Q.t[T + 3]);
+                if constexpr (IT + 4 < N) {
+                    lds_read_pair<(IT + 4) * 2048>(r.h[0], r.l[0], addr);
+                    lds_read_pair<(IT + 5) * 2048>(r.h[1], r.l[1], addr);
+                    lds_read_pair<(IT + 6) * 2048>(r.h[2], r.l[2], addr);
+                    lds_read_pair<(IT + 7) * 2048>(r.h[3], r.l[3], addr);
+                }
+            }
+#elif defined(NERFART_EXP_PAIR)
             if constexpr ((T & 1) != 0) {
                 constexpr int SP = (IT - 1) % NS;
                 lds_wait_pair2<PENDING>(r.h[SP], r.l[SP], r.h[S], r.l[S]);
@@ -504,7 +549,12 @@ __device__ __forceinline__ void run_chunk(const Acc& P, Acc& Q, Unit (&xb)[2], c
         RingT<L::AHEAD + 1 + RING_EXTRA> r;
         lds_read_pair<0>(r.h[0], r.l[0], addr);
         lds_read_pair<2048>(r.h[1], r.l[1], addr);
+#ifdef NERFART_EXP_SEG4
+        lds_read_pair<4096>(r.h[2], r.l[2], addr);
+        lds_read_pair<6144>(r.h[3], r.l[3], addr);
+#else
         if constexpr (L::AHEAD >= 3) lds_read_pair<4096>(r.h[2], r.l[2], addr);
+#endif
         Items<L, C, NKC, 0>::run(P, Q, xb, xs, x0n, w, r, addr, s, ec, gc);
         run_chunk<L, C + 1>(P, Q, xb, xs, x0n, w, s, ec, gc);
     }

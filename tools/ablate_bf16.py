@@ -28,6 +28,8 @@ if os.environ.get("NERFART_ABLATE_SET") == "skel":     # what is left when every
     A = ["-DNERFART_ABLATE_MFMA", "-DNERFART_ABLATE_EPI", "-DNERFART_ABLATE_LDSREAD"]
     VARIANTS = {"dma_only": A, "skeleton": A + ["-DNERFART_ABLATE_DMA"], "skeleton_nobarrier": A + ["-DNERFART_ABLATE_DMA", "-DNERFART_ABLATE_BARRIER"],
                 "skeleton_nobarrier_novmwait": A + ["-DNERFART_ABLATE_DMA", "-DNERFART_ABLATE_BARRIER", "-DNERFART_ABLATE_VMWAIT"]}
+if os.environ.get("NERFART_ABLATE_SET") == "seg4":     # segments of four tiles: 12 independent MFMAs, then the fillers (results correct)
+    VARIANTS = {"full": [], "seg4": ["-DNERFART_EXP_SEG4"]}
 OUT = os.path.join(ROOT, "gpurun_ablate")
 
 def build():
