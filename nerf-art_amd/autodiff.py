@@ -2,12 +2,15 @@
 that needs parameter gradients (reference Trainer.forward pass 2, models/frameworks/volsdf.py:753-770,
 neus.py:520-576).
 
-STATUS: this is the *library* path of row a19 - PyTorch autograd, GEMMs on rocBLAS
-through torch, including the double backward through the SDF net that the eikonal term and the normal input of
-the radiance net need.  Everything that does not need gradients in a training step (pass 1, and the sampling of
-pass 2: 512 x (1 + rounds) SDF evaluations per ray) runs on the hand-written HIP kernels.  The functions here
-follow the reference formulas line by line so that the hand-written backward kernels that replace them can be
-checked against them on the GPU at full size.
+Two formulations live here:
+* the NATIVE pass 2 (`volsdf_backward_samples_native` / `neus_backward_samples_native`, `GradAccumulator`,
+  `*_weight_grads_raw / _finish`): hand-written backward kernels (hip.radiance_fwd_dump / radiance_bwd / sdf_fwd2 /
+  sdf_bwd2 / *_composite_bwd) + plain library GEMMs over their point-major dumps, read in place; what `Trainer` runs
+  on split-bf16 models;
+* the AUTOGRAD formulation (`surface_forward*`, `radiance_forward`, `volsdf_render_samples`, `neus_render_samples`):
+  PyTorch autograd over rocBLAS GEMMs, including the double backward through the SDF net that the eikonal term and
+  the normal input of the radiance net need.  It follows the reference formulas line by line: the cross-check every
+  native piece is tested against at full size, and the path of the fp32-exact precision (`Trainer(native=False)`).
 """
 import numpy as np
 import torch
@@ -78,11 +81,6 @@ def radiance_forward(rad, x, view_dirs, normals, feat):
 
 # ---- radiance net on the hand-written kernels (forward with activation dumps, backward chain, GEMM operands) ----
 _PERMS = {}        # device -> (perm, inv) on that device: a host -> device copy per call would synchronise the stream
-
-
-def _unit_perm(device):
-    """column c = (unit * 4 + lane group) * 8 + e of a dumped matrix -> natural feature index."""
-    return _perms(device)[0]
 
 
 def _perms(device):
