@@ -342,6 +342,58 @@ class Trainer(nn.Module):
             out["loss_mask"] = float(loss_mask)
         return out
 
+    # ---- the reference's call shape (train.py:232) --------------------------------------------------------------
+    def forward(self, args, indices, model_input, ground_truth, render_kwargs_train: dict, it: int, optimizer=None, render_fn=None,
+                style_loss=None):
+        """`trainer.forward(args, indices, model_input, ground_truth, render_kwargs_train, it, optimizer=optimizer)` as train.py
+        calls it (volsdf.py:689-877, neus.py:458-627): rays of the batch's camera (all H x W in order when fine-tuning,
+        args.data.N_rays random ones otherwise), the targets gathered at them, then
+
+        * `args.training.is_finetune`: `finetune_step` - gradients are in `.grad` on return (the reference back-propagates
+          inside forward too) and `losses` is the style loss (a tensor);
+        * otherwise `reconstruction_step`.  train.py calls `optimizer.zero_grad(); losses['total'].backward()` AFTER forward, so
+          the native pass 2 is deferred into that backward call (`_DeferredBackward`): `losses` holds loss_img, loss_eikonal
+          (loss_mask), total as tensors, and `total.backward()` accumulates the gradients.
+
+        Returns OrderedDict(losses=..., extras={'scalars': {...}, 'select_inds': ...}).  `render_fn` / `style_loss` default to
+        the attributes `self.render_fn` / `self.style_loss` the caller set (the reference builds its losses in __init__)."""
+        from collections import OrderedDict
+        from . import rend_util
+        render_fn = render_fn if render_fn is not None else getattr(self, "render_fn", None)
+        style_loss = style_loss if style_loss is not None else getattr(self, "style_loss", None)
+        if render_fn is None:
+            raise ValueError("Trainer.forward: set trainer.render_fn (the render_fn get_model returned) or pass render_fn=")
+        dev = next(self.model.parameters()).device
+        intrinsics, c2w = model_input["intrinsics"].to(dev), model_input["c2w"].to(dev)
+        H, W = render_kwargs_train["H"], render_kwargs_train["W"]
+        finetune = bool(args.training.is_finetune)
+        rays_o, rays_d, select_inds = rend_util.get_rays(c2w, intrinsics, H, W, -1 if finetune else args.data.N_rays)
+        target_rgb = torch.gather(ground_truth["rgb"].to(dev), 1, torch.stack(3 * [select_inds], -1))
+        mask_ignore = torch.gather(model_input["mask_ignore"].to(dev), 1, select_inds) if "mask_ignore" in model_input else None
+        rk = {k: v for k, v in render_kwargs_train.items() if k not in ("H", "W")}
+        if finetune:
+            if style_loss is None:
+                raise ValueError("Trainer.forward (fine-tune): set trainer.style_loss (criteria.StyleLoss) or pass style_loss=")
+            self.w_eikonal, self.use_eikonal = args.finetune.w_eikonal, bool(args.finetune.use_eikonal)
+            out = self.finetune_step(render_fn, rays_o, rays_d, target_rgb, H, style_loss, optimizer=optimizer, **rk)
+            losses = torch.tensor(out["loss"], device=dev)
+        else:
+            kwargs = dict(w_eikonal=args.training.w_eikonal, mask_ignore=mask_ignore)
+            if self.is_neus:
+                if args.training.get("with_mask", False):
+                    kwargs.update(target_mask=torch.gather(model_input["object_mask"].to(dev), 1, select_inds), w_mask=args.training.w_mask)
+            else:
+                R = args.model.obj_bounding_radius
+                kwargs["eikonal_points"] = torch.empty(rays_o.shape[-2], 3, device=dev).uniform_(-R, R)       # volsdf.py:799-801
+            losses = _DeferredBackward.run(self, render_fn, rays_o, rays_d, target_rgb, kwargs, rk)
+        extras = {"select_inds": select_inds}
+        if self.is_neus:
+            extras["scalars"] = {"1/s": 1.0 / self.model.forward_s().data}
+        else:
+            alpha, beta = self.model.forward_ab()
+            extras["scalars"] = {"beta": beta.data, "alpha": alpha.data}
+        return OrderedDict([("losses", losses), ("extras", extras)])
+
     # ---- one fine-tune step ---------------------------------------------------------------------------
     def finetune_step(self, render_fn, rays_o, rays_d, target_rgb, H: int, style_loss, optimizer=None, tile: int = 2048,
                       **render_kwargs):
@@ -390,3 +442,39 @@ class Trainer(nn.Module):
             eik = self.backward_patches(rays_o, rays_d, gradient[0], depths_all=depths_all, kept=self._kept, **render_kwargs)
         self._kept = None
         return {"loss": float(loss.detach()), "eikonal": eik, "rgb": rgb.detach()}
+
+
+class _DeferredBackward(torch.autograd.Function):
+    """Hands the gradients of a reconstruction step to whoever back-propagates its total: the reference's train loop calls
+    `optimizer.zero_grad(); losses['total'].backward()` AFTER trainer.forward (train.py:240-242), so the step (render, losses,
+    native pass 2) runs once in `run`, its gradients are parked, and `total.backward()` adds them to `.grad`."""
+
+    @staticmethod
+    def run(trainer, render_fn, rays_o, rays_d, target_rgb, kwargs, rk):
+        from collections import OrderedDict
+        params = [p for p in trainer.model.parameters()]
+        before = [p.grad for p in params]
+        for p in params:
+            p.grad = None
+        parts = trainer.reconstruction_step(render_fn, rays_o, rays_d, target_rgb, **kwargs, **rk)
+        step = [p.grad for p in params]
+        for p, g in zip(params, before):                           # forward leaves .grad as it found it
+            p.grad = g
+        dev = rays_o.device
+        hook = torch.zeros((), device=dev, requires_grad=True)
+        total = _DeferredBackward.apply(hook, torch.tensor(parts["total"], device=dev), params, step)
+        losses = OrderedDict((k, torch.tensor(v, device=dev)) for k, v in parts.items() if k != "total")
+        losses["total"] = total
+        return losses
+
+    @staticmethod
+    def forward(ctx, hook, value, params, step):
+        ctx.params, ctx.step = params, step
+        return value.clone()
+
+    @staticmethod
+    def backward(ctx, g_total):
+        for p, g in zip(ctx.params, ctx.step):
+            if g is not None:
+                p.grad = g * g_total if p.grad is None else p.grad + g * g_total
+        return None, None, None, None

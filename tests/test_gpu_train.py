@@ -407,3 +407,54 @@ def test_neus_pass1_state_reuse_matches_recompute():
     # and the whole step runs on it
     out = tr.finetune_step(render_fn, o, d, torch.rand(1, H * W, 3, device=DEV), H, lambda p, t: ((p - t) ** 2).mean(), **kw)
     assert np.isfinite(out["loss"]) and np.isfinite(out["eikonal"])
+
+
+def test_trainer_forward_with_the_reference_call_shape(tmp_path):
+    """`trainer.forward(args, indices, model_input, ground_truth, render_kwargs_train, it, optimizer=...)` exactly as
+    train.py:232 calls it, fed from the scene-folder dataset through a DataLoader: the fine-tune branch leaves gradients in
+    .grad; the reconstruction branch hands them over when the caller back-propagates losses['total'] after its own
+    optimizer.zero_grad() (train.py:240-242)."""
+    import os
+    from PIL import Image
+    from nerfart_amd import scene, dataio
+    from nerfart_amd.config import ConfigDict
+    from nerfart_amd.trainer import Trainer
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "campath_golden.npz"))
+    os.makedirs(tmp_path / "images"); os.makedirs(tmp_path / "matte")
+    rng = np.random.default_rng(1)
+    cams = {}
+    for i in range(2):
+        Image.fromarray(rng.integers(0, 256, size=(96, 54, 3), dtype=np.uint8)).save(tmp_path / "images" / f"{i:06d}.png")
+        Image.fromarray(np.full((96, 54, 3), 255, np.uint8)).save(tmp_path / "matte" / f"{i:06d}.png")
+        cams[f"world_mat_{i}"], cams[f"scale_mat_{i}"] = z[f"C2_world_mat_{i}"], z[f"C2_scale_mat_{i}"]
+    np.savez(tmp_path / "cameras.npz", **cams)
+    ds = dataio.SceneDataset(False, str(tmp_path), downscale=8, scale_radius=3.0)                 # 12 x 7 (rounded) images
+    dl = torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False, collate_fn=ds.collate_fn)
+    indices, model_input, ground_truth = next(iter(dl))
+    model, rk, render_fn = scene.build_model("VolSDF", seed=0, beta=0.01, device=DEV, precision="bf16x3")
+    rkt = dict({k: v for k, v in rk.items() if k != "rayschunk"}, H=ds.H, W=ds.W)
+    args = ConfigDict({"training": ConfigDict({"is_finetune": True, "w_eikonal": 0.1}), "data": ConfigDict({"N_rays": 40}),
+                       "model": ConfigDict({"obj_bounding_radius": 3.0}), "finetune": ConfigDict({"w_eikonal": 0.1, "use_eikonal": True})})
+    tr = Trainer(model, pass2_rays=30)
+    tr.render_fn = render_fn
+    tr.style_loss = lambda pred, gt: ((pred - gt) ** 2).mean()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    ret = tr(args, indices, model_input, ground_truth, rkt, 0, optimizer=opt)
+    assert list(ret.keys()) == ["losses", "extras"] and ret["losses"].ndim == 0 and torch.isfinite(ret["losses"])
+    assert set(ret["extras"]["scalars"]) == {"beta", "alpha"} and ret["extras"]["select_inds"].shape == (1, ds.H * ds.W)
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    opt.step()
+    # reconstruction: the reference's loop zeroes the gradients AFTER forward and back-propagates the total itself
+    args.training.is_finetune = False
+    torch.manual_seed(0)
+    ret = tr(args, indices, model_input, ground_truth, rkt, 1, optimizer=opt)
+    losses = ret["losses"]
+    assert list(losses.keys()) == ["loss_img", "loss_eikonal", "total"] and ret["extras"]["select_inds"].shape == (1, 40)
+    for k, v in losses.items():
+        losses[k] = torch.mean(v)
+    opt.zero_grad()
+    assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in model.parameters())
+    losses["total"].backward()
+    gn = sum(float(p.grad.norm()) for p in model.parameters() if p.grad is not None)
+    assert np.isfinite(gn) and gn > 0
+    opt.step()
