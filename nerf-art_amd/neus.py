@@ -97,4 +97,9 @@ def get_model(args, render_target=None):
     render_kwargs_test = copy.deepcopy(render_kwargs_train)
     render_kwargs_test["rayschunk"] = args.data.val_rayschunk
     render_kwargs_test["perturb"] = False
-    return model, None, render_kwargs_train, render_kwargs_test, SingleRenderer(model)
+    from .trainer import Trainer
+    renderer = SingleRenderer(model)
+    # neus.py:455-456: the radiance net is frozen when fine-tuning, trained otherwise
+    trainer = Trainer(model, freeze_radiance=bool(t.get("is_finetune", False)))
+    trainer.render_fn = renderer
+    return model, trainer, render_kwargs_train, render_kwargs_test, renderer

@@ -86,8 +86,9 @@ class SingleRenderer(nn.Module):
 
 def get_model(args, render_target=None):
     """(volsdf.py:943-994) args: the YAML config as an attribute dict (nerf-art_amd/config.py).
-    Returns (model, trainer=None, render_kwargs_train, render_kwargs_test, render_fn).  The Trainer
-    (two-pass CLIP fine-tune step) is SURVEY.md row a19 and lives in nerf-art_amd/trainer.py when built."""
+    Returns (model, trainer, render_kwargs_train, render_kwargs_test, render_fn).  trainer = trainer.Trainer with
+    `render_fn` set; its `style_loss` (criteria.StyleLoss: needs the CLIP / VGG checkpoints and tokenizer) is the caller's to
+    set before fine-tuning - the reference loads them inside Trainer.__init__ (volsdf.py:638-645)."""
     m, t = args.model, args.training
     model_config = {
         "use_nerfplusplus": m.setdefault("outside_scene", "builtin") == "nerf++",
@@ -122,4 +123,7 @@ def get_model(args, render_target=None):
     render_kwargs_test["rayschunk"] = args.data.val_rayschunk
     render_kwargs_test["perturb"] = False
     renderer = SingleRenderer(model)
-    return model, None, render_kwargs_train, render_kwargs_test, renderer
+    from .trainer import Trainer
+    trainer = Trainer(model)
+    trainer.render_fn = renderer
+    return model, trainer, render_kwargs_train, render_kwargs_test, renderer
