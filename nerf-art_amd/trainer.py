@@ -35,7 +35,8 @@ class Trainer(nn.Module):
         self.w_eikonal, self.use_eikonal, self.pass2_rays = w_eikonal, use_eikonal, pass2_rays
         # native: pass 2 entirely on the hand-written kernels + GEMMs (VolSDF, split-bf16 blobs); otherwise autograd over
         # the per-sample networks with the native compositing / radiance kernels where available
-        self.native = (model.precision == "bf16x3") if native is None else native
+        # (None: decided by the model's precision at the time of the step - set_precision may be called after get_model)
+        self._native = native
         # native pass 2: this many of the reference's pass2_rays-ray patches share one set of kernel launches (the per-patch
         # eikonal means are kept); bounded by the kernels' 2^21 points per launch
         self.patches_per_launch = patches_per_launch
@@ -45,6 +46,10 @@ class Trainer(nn.Module):
         if self.is_neus if freeze_radiance is None else freeze_radiance:
             for p in model.radiance_net.parameters():
                 p.requires_grad_(False)
+
+    @property
+    def native(self) -> bool:
+        return (self.model.precision == "bf16x3") if self._native is None else self._native
 
     # ---- pass 1 ---------------------------------------------------------------------------------------
     @torch.no_grad()
