@@ -22,7 +22,6 @@ PyTorch port of the reference algorithm; kind "port") on a strided subset of the
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time

@@ -12,7 +12,6 @@ library (csrc/mlp_chain.hip) on packed weights.  There is no eager-PyTorch compu
 """
 from __future__ import annotations
 
-import math
 
 import numpy as np
 import torch

@@ -7,7 +7,6 @@ independent), so the oracle renders all rays in chunks of its own choosing.
 """
 from collections import OrderedDict
 
-import numpy as np
 import torch
 import torch.nn.functional as F
 

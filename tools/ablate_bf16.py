@@ -2,7 +2,7 @@
 """Timing ablation of k_sdf_only_bf16: builds variant libraries with one component compiled out
 (weight DMA / epilogue / MFMA) and times nerfart_sdf_fwd on 4M points with each.  Results are WRONG by
 construction - this only attributes time.   build:  python tools/ablate_bf16.py build ;  run (GPU): ... run"""
-import os, subprocess, sys, time
+import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "nerf-art_amd", "csrc")
 VARIANTS = {"full": [], "nodma": ["-DNERFART_ABLATE_DMA"], "noepi": ["-DNERFART_ABLATE_EPI"], "nomfma": ["-DNERFART_ABLATE_MFMA"],
