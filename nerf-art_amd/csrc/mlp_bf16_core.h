@@ -336,6 +336,9 @@ __device__ __forceinline__ void d_load(GradCtx& gc, int idx, int buf) {
 // one epilogue slice (last 12 items of a hosting k-step).  LDS returns in order: with items it, it+1, it+2
 // outstanding (2 reads each) item it has landed at lgkmcnt(4) (cdna_hip_programming.md 5.7, form ii).
 // ---------------------------------------------------------------------------------------
+#ifndef NERFART_AHEAD        // A-fragment prefetch distance in items (2; 3 measured slower in round 1, re-measured by tools/ablate_bf16.py)
+#define NERFART_AHEAD 2
+#endif
 template <int NS> struct RingT { u32x4 h[NS], l[NS]; };   // AHEAD + 1 slots (+ RING_EXTRA)
 #if defined(NERFART_EXP_PAIR) || defined(NERFART_EXP_SEG4)   // experiments: tiles multiplied in pairs (mfma6) / fours (mfma12)
 constexpr int RING_EXTRA = 1;
@@ -372,7 +375,7 @@ __device__ __forceinline__ void lds_wait_pair2(u32x4& fh0, u32x4& fl0, u32x4& fh
 // epilogue MQ.  ZINIT: accumulators start at 0 instead of the bias.  PEND_IN / LOADNEXT (reverse-mode kernel): a
 // softplus' unit of the previous layer is waiting to be stored / the following layer's first unit needs its load.
 template <int MODE_, int MQ_, int NH_, int NX_, bool NEXT0_, bool ZINIT_ = false, bool PEND_IN_ = false, bool LOADNEXT_ = false,
-          int AHEAD_ = 2>
+          int AHEAD_ = NERFART_AHEAD>
 struct Cfg {
     static constexpr int MODE = MODE_, MQ = MQ_, NH = NH_, NX = NX_, NXA = NX_ > 0 ? NX_ : 1, NKS = NH_ + NX_;
     static constexpr int AHEAD = AHEAD_;      // A fragments are read this many items ahead of their MFMAs (2 or 3)

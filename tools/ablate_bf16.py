@@ -30,6 +30,8 @@ if os.environ.get("NERFART_ABLATE_SET") == "skel":     # what is left when every
                 "skeleton_nobarrier_novmwait": A + ["-DNERFART_ABLATE_DMA", "-DNERFART_ABLATE_BARRIER", "-DNERFART_ABLATE_VMWAIT"]}
 if os.environ.get("NERFART_ABLATE_SET") == "seg4":     # segments of four tiles: 12 independent MFMAs, then the fillers (results correct)
     VARIANTS = {"full": [], "seg4": ["-DNERFART_EXP_SEG4"]}
+if os.environ.get("NERFART_ABLATE_SET") == "ahead":    # fragment prefetch distance (results correct)
+    VARIANTS = {"full": [], "ahead3": ["-DNERFART_AHEAD=3"]}
 OUT = os.path.join(ROOT, "gpurun_ablate")
 
 def build():
