@@ -54,7 +54,11 @@ __device__ __forceinline__ f32x4 mfma3(const u32x4 ah, const u32x4 al, const u32
                  "v_mfma_f32_16x16x32_bf16 %0, %1, %3, %0\n\t"
                  "v_mfma_f32_16x16x32_bf16 %0, %1, %4, %0\n\t"
                  "v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0"
+#ifdef NERFART_EXP_AGPR      // experiment: accumulators in the ACC register file
+                 : "+a"(acc) : "v"(ah), "v"(al), "v"(bh), "v"(bl));
+#else
                  : "+v"(acc) : "v"(ah), "v"(al), "v"(bh), "v"(bl));
+#endif
     return acc;
 }
 

@@ -32,6 +32,8 @@ if os.environ.get("NERFART_ABLATE_SET") == "seg4":     # segments of four tiles:
     VARIANTS = {"full": [], "seg4": ["-DNERFART_EXP_SEG4"]}
 if os.environ.get("NERFART_ABLATE_SET") == "ahead":    # fragment prefetch distance (results correct)
     VARIANTS = {"full": [], "ahead3": ["-DNERFART_AHEAD=3"]}
+if os.environ.get("NERFART_ABLATE_SET") == "agpr":     # accumulators in AGPRs (results correct)
+    VARIANTS = {"full": [], "agpr": ["-DNERFART_EXP_AGPR"]}
 OUT = os.path.join(ROOT, "gpurun_ablate")
 
 def build():
