@@ -34,6 +34,8 @@ if os.environ.get("NERFART_ABLATE_SET") == "ahead":    # fragment prefetch dista
     VARIANTS = {"full": [], "ahead3": ["-DNERFART_AHEAD=3"]}
 if os.environ.get("NERFART_ABLATE_SET") == "agpr":     # accumulators in AGPRs (results correct)
     VARIANTS = {"full": [], "agpr": ["-DNERFART_EXP_AGPR"]}
+if os.environ.get("NERFART_ABLATE_SET") == "one":      # just the current sources (compare with a previous run's "full")
+    VARIANTS = {"full": []}
 OUT = os.path.join(ROOT, "gpurun_ablate")
 
 def build():
