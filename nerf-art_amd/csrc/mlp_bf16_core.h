@@ -475,6 +475,11 @@ struct Items {
             constexpr bool DMA_HERE = T >= DMA_T0 && T < DMA_T0 + 4;
             constexpr int DMA_J = T - DMA_T0;
 #endif
+#ifdef NERFART_EXP_DMA_EARLY      // experiment: all 8 pieces in the first k-step of a two-k-step chunk (items 0..7)
+            if constexpr (NKC == 2) {
+                if constexpr (kk == 0 && T < 8) stream_piece<T>(s);
+            } else
+#endif
             if constexpr (DMA_HERE) {
                 if constexpr (NKC == 2) stream_piece<kk * 4 + DMA_J>(s);
                 else { stream_piece<2 * DMA_J>(s); stream_piece<2 * DMA_J + 1>(s); }

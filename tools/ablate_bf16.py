@@ -36,6 +36,8 @@ if os.environ.get("NERFART_ABLATE_SET") == "agpr":     # accumulators in AGPRs (
     VARIANTS = {"full": [], "agpr": ["-DNERFART_EXP_AGPR"]}
 if os.environ.get("NERFART_ABLATE_SET") == "one":      # just the current sources (compare with a previous run's "full")
     VARIANTS = {"full": []}
+if os.environ.get("NERFART_ABLATE_SET") == "early":    # all DMA pieces of a chunk in its first k-step (results correct)
+    VARIANTS = {"full": [], "dma_early": ["-DNERFART_EXP_DMA_EARLY"]}
 OUT = os.path.join(ROOT, "gpurun_ablate")
 
 def build():
