@@ -50,10 +50,21 @@ def my_ray_indices(n_rays: int, tile: int, rank_: int, world: int, device=None) 
     return torch.cat(parts) if parts else torch.zeros(0, dtype=torch.long, device=device)
 
 
+def _host_staged(t: torch.Tensor) -> bool:
+    """gloo has no all_gather for device tensors: stage through the host (tests that run several ranks on ONE GPU; the
+    production backend is RCCL, which moves device memory directly)."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
 def all_gather_tiles(t: torch.Tensor):
     """all_gather of equally shaped [n, C] tensors -> list ordered by rank (one RCCL call)."""
     if world_size() == 1:
         return [t]
+    if _host_staged(t):
+        h = t.detach().cpu().contiguous()
+        out = [torch.empty_like(h) for _ in range(world_size())]
+        dist.all_gather(out, h)
+        return [o.to(t.device) for o in out]
     out = [torch.empty_like(t) for _ in range(world_size())]
     dist.all_gather(out, t.contiguous())
     return out
@@ -82,7 +93,8 @@ def render_sharded(render_fn, rays_o: torch.Tensor, rays_d: torch.Tensor, keys=(
     if w == 1:
         return {k: (c[None] if c.shape[1] > 1 else c[None, :, 0]) for k, c in zip(keys, cols)}
     # widths must agree across ranks even if a rank had no rays: exchange them
-    wt = torch.tensor([x if x is not None else 0 for x in widths], device=dev, dtype=torch.long)
+    wt = torch.tensor([x if x is not None else 0 for x in widths], dtype=torch.long)
+    wt = wt if dist.get_backend() == "gloo" else wt.to(dev)
     dist.all_reduce(wt, op=dist.ReduceOp.MAX)
     widths = wt.tolist()
     n_max = max(len(my_ray_indices(N, tile, q, w)) for q in range(w))
@@ -111,7 +123,12 @@ def allreduce_gradients(params, average: bool = False):
     if not grads:
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if _host_staged(flat):
+        h = flat.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        flat = h.to(flat.device)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     if average:
         flat /= world_size()
     o = 0
