@@ -1,4 +1,4 @@
-"""The ray-sharded fine-tune step with two ranks on ONE GPU (gloo for the collectives, staged through the host; the
+"""The ray-sharded render and fine-tune step with two ranks on ONE GPU (gloo for the collectives, staged through the host; the
 production backend is RCCL with one GPU per rank): the gradients after the all-reduce equal the single-process step's."""
 import os
 import socket
@@ -24,6 +24,8 @@ def _worker(rank, world, port, out_dir):
         target = (torch.rand(1, H * W, 3, generator=torch.Generator().manual_seed(2)) * 0.2 + 0.6).to(dev)
         loss_fn = lambda pred, gt: ((pred - gt) ** 2).mean()
         kw = {k: v for k, v in rk.items() if k != "rayschunk"}
+        keys = ("rgb", "depth_volume", "mask_volume", "normals_volume")
+        frame = nd.render_sharded(render_fn, o, d, keys=keys, tile=16, detailed_output=False, require_nablas=True, calc_normal=True, **kw)
         tr = Trainer(model, pass2_rays=8, patches_per_launch=2)
         model.zero_grad()
         out = tr.finetune_step(render_fn, o, d, target, H, loss_fn, tile=16, **kw)          # 70 rays: tiles of 16 dealt 3 + 2
@@ -33,6 +35,10 @@ def _worker(rank, world, port, out_dir):
         dist.barrier()
         dist.destroy_process_group()
         if rank == 0:
+            with torch.no_grad():
+                _, _, ex = render_fn(o, d, detailed_output=False, require_nablas=True, calc_normal=True, **kw)
+            for k in keys:                                            # the sharded frame is the single-process frame, ray for ray
+                np.testing.assert_array_equal(frame[k].cpu().numpy(), ex[k].cpu().numpy(), err_msg=k)
             model.zero_grad()
             ref = Trainer(model, pass2_rays=8, patches_per_launch=2).finetune_step(render_fn, o, d, target, H, loss_fn, **kw)
             np.testing.assert_allclose(rgb_sharded.cpu().numpy(), ref["rgb"].cpu().numpy(), atol=1e-6)
