@@ -56,8 +56,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # NERFART_BENCH_BACKEND=gloo: functional check of the N > 1 path on a box with fewer GPUs than ranks (every rank on
+        # a visible device, collectives staged through the host by nerfart_amd.dist); the measured configuration is RCCL
+        backend = os.environ.get("NERFART_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            local = local % torch.cuda.device_count()
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend)
     else:
         dist = None
         torch.cuda.set_device(local)
@@ -103,7 +111,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = hip.profile_end()
     if dist is not None:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
 
