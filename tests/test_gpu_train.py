@@ -505,3 +505,44 @@ def test_reconstruction_branch_matches_the_reference_trainer(fw):
         assert abs(float(p.grad.norm()) - gold_n) <= 2e-2 * gold_n + 1e-7, (name, float(p.grad.norm()), gold_n)
         rel = float((got - head).norm() / (head.norm() + 1e-12))
         assert rel < 5e-2 or float(head.norm()) < 1e-3 * gold_n, (name, rel)
+
+
+@pytest.mark.parametrize("fw", ["VolSDF", "NeuS"])
+def test_finetune_branch_matches_the_reference_trainer(fw):
+    """`trainer.forward(...)` with is_finetune True against the reference Trainer.forward's fine-tune branch (volsdf.py:719-783,
+    neus.py:520-576) with a pixel MSE in place of the CLIP / VGG heads (tests/golden/make_golden_finetune.py): the style loss
+    of pass 1's image and, after pass 2, the gradient of every trainable parameter (NeuS: radiance net frozen)."""
+    import json
+    import os
+    from conftest import state_checksum
+    from nerfart_amd import scene
+    from nerfart_amd.config import ConfigDict
+    from nerfart_amd.trainer import Trainer
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "finetune_golden.npz"))
+    tag = f"F_{fw}_"
+    model, _, render_fn = scene.build_model(fw, seed=0, beta=0.01 if fw == "VolSDF" else None, device=DEV, precision="bf16x3")
+    assert state_checksum({k: v.detach().cpu() for k, v in model.state_dict().items()}) == str(z[tag + "state_sha256"])
+    rk = json.loads(str(z[tag + "render_kwargs"]))
+    args = ConfigDict({"training": ConfigDict({"is_finetune": True}), "finetune": ConfigDict({"w_eikonal": 0.1, "use_eikonal": True})})
+    tr = Trainer(model)                                            # NeuS: freezes the radiance net, as neus.py:455-456
+    tr.render_fn = render_fn
+    tr.style_loss = lambda pred, gt: ((pred - gt) ** 2).mean()
+    opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=0.0)
+    model_input = {"intrinsics": torch.from_numpy(z["F_K"])[None], "c2w": torch.from_numpy(z["F_c2w"])[None]}
+    ground_truth = {"rgb": torch.from_numpy(z["F_target"])[None]}
+    ret = tr(args, torch.tensor([0]), model_input, ground_truth, rk, 0, optimizer=opt)
+    np.testing.assert_allclose(float(ret["losses"]), float(z[tag + "loss"]), rtol=2e-3)
+    n = 0
+    for name, p in model.named_parameters():
+        key = tag + "gradnorm_" + name
+        if key not in z.files:
+            assert p.grad is None, name
+            continue
+        n += 1
+        gold_n = float(z[key])
+        head = torch.from_numpy(z[tag + "gradhead_" + name]).to(DEV)
+        got = p.grad.reshape(-1)[: head.numel()]
+        assert abs(float(p.grad.norm()) - gold_n) <= 2e-2 * gold_n + 1e-8, (name, float(p.grad.norm()), gold_n)
+        rel = float((got - head).norm() / (head.norm() + 1e-12))
+        assert rel < 5e-2 or float(head.norm()) < 1e-3 * gold_n, (name, rel)
+    assert n == (43 if fw == "VolSDF" else 28)
