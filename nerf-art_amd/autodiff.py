@@ -320,6 +320,12 @@ def _eikonal_terms(nab, R: int, P: int, w_eikonal: float, group_rays):
     return eik, (coef * err / nn_)[:, None] * nab
 
 
+def _need_split_bf16(model, who: str):
+    """The native backward entry points take no precision argument and read split-bf16 blobs only."""
+    if getattr(model, "precision", None) != "bf16x3":
+        raise RuntimeError(f"{who}: native pass 2 needs model.set_precision('bf16x3') (model is at {getattr(model, 'precision', None)!r})")
+
+
 def volsdf_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikonal=0.1, use_eikonal=True, white_bkgd=False, ab=None,
                                    nbar_extra=None, accum=None, state=None, eik_group_rays=None):
     """Pass 2 of the fine-tune step for one patch, entirely on the hand-written kernels + GEMMs: accumulates into .grad what
@@ -331,6 +337,7 @@ def volsdf_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikon
     eik_group_rays: the rays are several `eik_group_rays`-ray patches of the reference in one launch (the eikonal mean is
     per patch); the returned loss is then the SUM over those patches."""
     from . import hip
+    _need_split_bf16(model, "volsdf_backward_samples_native")
     R, P = d_all.shape
     pts = (rays_o[:, None, :] + rays_dn[:, None, :] * d_all[:, :, None]).reshape(-1, 3).contiguous()
     v = rays_dn[:, None, :].expand(R, P, 3).reshape(-1, 3).contiguous()
@@ -370,6 +377,7 @@ def neus_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikonal
     its parameters require grad (the fine-tune step freezes it, neus.py:455-456; reconstruction trains it).  g_acc [R]: a
     cotangent of the opacity mask_volume (the mask BCE of the reconstruction objective).  Returns the eikonal loss (0-d)."""
     from . import hip
+    _need_split_bf16(model, "neus_backward_samples_native")
     R, P = d_all.shape
     pts = (rays_o[:, None, :] + rays_dn[:, None, :] * d_all[:, :, None]).reshape(-1, 3).contiguous()
     d_mid = 0.5 * (d_all[..., 1:] + d_all[..., :-1])

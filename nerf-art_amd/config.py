@@ -82,9 +82,19 @@ def load_yaml(path, default_path=None) -> ConfigDict:
     if default_path is not None and path != default_path:
         with open(default_path, encoding="utf8") as f:
             main = ConfigDict(**yaml.load(f, Loader=yaml.FullLoader))
-        main.update(config)
-        config = main
+        config = merge_nested(main, config)
     return config
+
+
+def merge_nested(base: ConfigDict, override) -> ConfigDict:
+    """`base` updated by `override` key by key, recursing where both sides hold a mapping (what addict's Dict.update does in
+    the reference, io_util.py:201-212): a user yaml that sets `training: {lr: ...}` keeps the base file's other training keys."""
+    for k, v in dict(override).items():
+        if isinstance(v, dict) and isinstance(base.get(k), dict):
+            merge_nested(base[k], v)
+        else:
+            base[k] = v
+    return base
 
 
 def save_config(datadict: ConfigDict, path: str):

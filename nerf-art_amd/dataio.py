@@ -6,8 +6,8 @@ load_rgb / load_mask, `utils/rend_util.py:8-25` load_K_Rt_from_P) - same names, 
 values, so `render.py` / `train.py` style callers run unchanged.  The reference leans on cv2, imageio and skimage for
 three things; none of them is in this image, so they are restated on numpy / scipy / PIL / torch:
 
-* `cv2.decomposeProjectionMatrix` -> RQ decomposition with cv2's conventions (positive diagonal of K, camera centre =
-  null vector of P).  PARITY UNPINNED against cv2 itself (absent); pinned by properties on the reference's own
+* `cv2.decomposeProjectionMatrix` -> RQ decomposition (one batched QR over all views) with cv2's conventions (positive
+  diagonal of K, proper rotation, camera centre = null vector of P).  PARITY UNPINNED against cv2 itself (absent); pinned by properties on the reference's own
   `data/fangzhou_nature/cameras.npz` cameras (tests/test_dataio.py: K [R | -R c] reproduces P, R orthonormal).
 * `imageio.imread` -> PIL; `skimage.img_as_float32` -> / 255.
 * `skimage.transform.rescale(img, 1 / downscale, anti_aliasing=False)` (order 1, half-pixel centres) ->
@@ -58,110 +58,121 @@ def load_mask(path, downscale=1):
     return alpha > 127.5
 
 
+def decompose_projections(P):
+    """All cameras at once: P [n, 3, 4] = s K [R | -R c]  ->  (K [n, 4, 4] float64 normalised to K[2,2] = 1 with a positive
+    diagonal, c2w [n, 4, 4] float32 = [R^T | c]).  What `cv2.decomposeProjectionMatrix` + the reference's
+    load_K_Rt_from_P (rend_util.py:8-25) give per view.
+
+    RQ through one batched QR: with J the row-reversal, (J M)^T = Q U  =>  M = (J U^T J)(J Q^T), J U^T J upper triangular.
+    A projection matrix is defined up to sign; det(M) < 0 would make R a reflection, so P is negated first (cv2 returns
+    a proper rotation in that case too)."""
+    P = np.asarray(P, dtype=np.float64).reshape(-1, 3, 4)
+    P = P * np.where(np.linalg.det(P[:, :, :3]) < 0, -1.0, 1.0)[:, None, None]
+    M = P[:, :, :3]
+    Q, U = np.linalg.qr(np.swapaxes(M[:, ::-1, :], 1, 2))
+    K = np.swapaxes(U, 1, 2)[:, ::-1, ::-1]
+    R = np.swapaxes(Q, 1, 2)[:, ::-1, :]
+    sgn = np.where(np.diagonal(K, axis1=1, axis2=2) < 0, -1.0, 1.0)           # K diag(s) . diag(s) R = K R
+    K, R = K * sgn[:, None, :], R * sgn[:, :, None]
+    centre = -np.linalg.solve(M, P[:, :, 3:4])[:, :, 0]
+    K4 = np.tile(np.eye(4), (P.shape[0], 1, 1))
+    K4[:, :3, :3] = K / K[:, 2:3, 2:3]
+    c2w = np.tile(np.eye(4, dtype=np.float32), (P.shape[0], 1, 1))
+    c2w[:, :3, :3] = np.swapaxes(R, 1, 2)
+    c2w[:, :3, 3] = centre
+    return K4, c2w
+
+
 def load_K_Rt_from_P(P):
-    """P [3, 4] = K [R | t] -> (intrinsics [4, 4] float64 with K / K[2,2], pose [4, 4] float32 = camera-to-world)
-    (rend_util.py:8-25).  K upper triangular with a positive diagonal, R = K^-1 P[:, :3], centre c = -P[:, :3]^-1 P[:, 3]."""
-    from scipy.linalg import rq
-    P = np.asarray(P, dtype=np.float64)
-    M = P[:3, :3]
-    K, R = rq(M)
-    D = np.diag(np.where(np.diag(K) < 0, -1.0, 1.0))
-    K, R = K @ D, D @ R                                   # (K D)(D R) = K R: flips columns of K / rows of R
-    c = -np.linalg.solve(M, P[:3, 3])
-    intrinsics = np.eye(4)
-    intrinsics[:3, :3] = K / K[2, 2]
-    pose = np.eye(4, dtype=np.float32)
-    pose[:3, :3] = R.transpose()
-    pose[:3, 3] = c
-    return intrinsics, pose
+    """One camera: P [3, 4] -> (intrinsics [4, 4] float64, pose [4, 4] float32 camera-to-world)  (rend_util.py:8-25)."""
+    K4, c2w = decompose_projections(np.asarray(P)[None, :3, :4])
+    return K4[0], c2w[0]
+
+
+def _stack_cameras(cam_file, n, scaled=True):
+    """world_mat_i (@ scale_mat_i) of the first n views of a cameras.npz as one [n, 3, 4] float32 array (one file read)."""
+    with np.load(cam_file) as z:
+        world = np.stack([z["world_mat_%d" % i] for i in range(n)]).astype(np.float32)
+        if not scaled:
+            return world[:, :3, :4]
+        scale = np.stack([z["scale_mat_%d" % i] for i in range(n)]).astype(np.float32)
+    return (world @ scale)[:, :3, :4]
 
 
 class SceneDataset(torch.utils.data.Dataset):
-    """dataio/DTU.py:11-155: one item per image - (idx, {"object_mask" [H W] bool, "intrinsics" [4,4], "c2w" [4,4]},
-    {"rgb" [H W, 3]}); cameras are scaled so that the farthest sits at scale_radius / 1.1 (DTU.py:68-71)."""
+    """IDR-style scene folder -> per-view items with the reference dataset's contract (dataio/DTU.py:11-155):
+    `ds[i] = (i, {"object_mask" [H W] bool, "intrinsics" [4,4], "c2w" [4,4]}, {"rgb" [H W, 3]})`, attributes `n_images, H, W,
+    downscale, instance_dir, cam_file, train_cameras, intrinsics_all, c2w_all, rgb_images, object_masks` (the per-view
+    containers are stacked tensors here; indexing and iteration give the reference's per-view tensors).
+
+    Cameras are decomposed for all views in one batched call; the intrinsics' focal lengths and principal point are
+    divided by `downscale` (the skew, a ratio, is not: DTU.py:58-63) and, with scale_radius > 0, camera centres are
+    scaled so that the farthest one sits at scale_radius / 1.1 (DTU.py:68-71)."""
 
     def __init__(self, train_cameras, data_dir, downscale=1., cam_file=None, scale_radius=-1):
         assert os.path.exists(data_dir), f"Data directory {data_dir} is empty"
-        self.instance_dir = data_dir
-        self.train_cameras = train_cameras
-        image_paths = sorted(glob_imgs("{0}/images".format(self.instance_dir)))
-        mask_paths = sorted(glob_imgs("{0}/matte".format(self.instance_dir)))       # only the NeuS + mask setting uses them
-        self.n_images = len(image_paths)
-        self.downscale = downscale
-        _, self.H, self.W = load_rgb(image_paths[0], downscale).shape
-        self.cam_file = "{0}/cameras.npz".format(self.instance_dir)
-        if cam_file is not None:
-            self.cam_file = "{0}/{1}".format(self.instance_dir, cam_file)
-        camera_dict = np.load(self.cam_file)
-        scale_mats = [camera_dict["scale_mat_%d" % idx].astype(np.float32) for idx in range(self.n_images)]
-        world_mats = [camera_dict["world_mat_%d" % idx].astype(np.float32) for idx in range(self.n_images)]
-        self.intrinsics_all, self.c2w_all, cam_center_norms = [], [], []
-        for scale_mat, world_mat in zip(scale_mats, world_mats):
-            intrinsics, pose = load_K_Rt_from_P((world_mat @ scale_mat)[:3, :4])
-            cam_center_norms.append(np.linalg.norm(pose[:3, 3]))
-            intrinsics[0, 2] /= downscale
-            intrinsics[1, 2] /= downscale
-            intrinsics[0, 0] /= downscale
-            intrinsics[1, 1] /= downscale                 # the skew is a ratio and is not scaled (DTU.py:63)
-            self.intrinsics_all.append(torch.from_numpy(intrinsics).float())
-            self.c2w_all.append(torch.from_numpy(pose).float())
-        max_cam_norm = max(cam_center_norms)
+        self.instance_dir, self.train_cameras, self.downscale = data_dir, train_cameras, downscale
+        frames = sorted(glob_imgs(os.path.join(data_dir, "images")))
+        mattes = sorted(glob_imgs(os.path.join(data_dir, "matte")))            # only the NeuS + mask objective reads them
+        self.n_images = len(frames)
+        self.cam_file = os.path.join(data_dir, cam_file if cam_file is not None else "cameras.npz")
+
+        K4, c2w = decompose_projections(_stack_cameras(self.cam_file, self.n_images))
+        K4[:, [0, 1, 0, 1], [0, 1, 2, 2]] /= downscale
         if scale_radius > 0:
-            for i in range(len(self.c2w_all)):
-                self.c2w_all[i][:3, 3] *= (scale_radius / max_cam_norm / 1.1)
-        self.rgb_images = []
-        for path in image_paths:
-            rgb = load_rgb(path, downscale).reshape(3, -1).transpose(1, 0)
-            self.rgb_images.append(torch.from_numpy(np.ascontiguousarray(rgb)).float())
-        self.object_masks = []
-        for path in mask_paths:
-            self.object_masks.append(torch.from_numpy(load_mask(path, downscale).reshape(-1)).to(dtype=torch.bool))
+            c2w[:, :3, 3] *= scale_radius / np.linalg.norm(c2w[:, :3, 3], axis=1).max() / 1.1
+        self.intrinsics_all = torch.from_numpy(K4).float()
+        self.c2w_all = torch.from_numpy(c2w).float()
+
+        pixels = np.stack([load_rgb(f, downscale) for f in frames])           # [n, 3, H, W]
+        self.H, self.W = pixels.shape[-2:]
+        self.rgb_images = torch.from_numpy(np.ascontiguousarray(pixels.reshape(self.n_images, 3, -1).transpose(0, 2, 1))).float()
+        if mattes:
+            self.object_masks = torch.from_numpy(np.stack([load_mask(m, downscale).reshape(-1) for m in mattes])).bool()
+        else:                                                                   # no matte folder: everything is object
+            self.object_masks = torch.ones(self.n_images, self.H * self.W, dtype=torch.bool)
 
     def __len__(self):
         return self.n_images
 
     def __getitem__(self, idx):
         sample = {"object_mask": self.object_masks[idx], "intrinsics": self.intrinsics_all[idx]}
-        ground_truth = {"rgb": self.rgb_images[idx]}
         if not self.train_cameras:
             sample["c2w"] = self.c2w_all[idx]
-        return idx, sample, ground_truth
+        return idx, sample, {"rgb": self.rgb_images[idx]}
 
-    def collate_fn(self, batch_list):
-        """list of (idx, dict, dict) -> (LongTensor, stacked dict, stacked dict)  (DTU.py:111-127)."""
-        all_parsed = []
-        for entry in zip(*batch_list):
-            if type(entry[0]) is dict:
-                all_parsed.append({k: torch.stack([obj[k] for obj in entry]) for k in entry[0].keys()})
-            else:
-                all_parsed.append(torch.LongTensor(entry))
-        return tuple(all_parsed)
+    @staticmethod
+    def collate_fn(batch):
+        """[(idx, sample, truth), ...] -> (LongTensor [b], {key: [b, ...]}, {key: [b, ...]}) - the DataLoader hook train.py
+        installs (DTU.py:111-127)."""
+        idx, samples, truths = zip(*batch)
+
+        def stacked(dicts):
+            return {k: torch.stack([d[k] for d in dicts]) for k in dicts[0]}
+        return torch.LongTensor(idx), stacked(samples), stacked(truths)
 
     def get_scale_mat(self):
-        return np.load(self.cam_file)["scale_mat_0"]
+        with np.load(self.cam_file) as z:
+            return z["scale_mat_0"]
 
     def get_gt_pose(self, scaled=True):
-        """[n, 4, 4] camera-to-world without the scale_radius normalisation (DTU.py:132-147)."""
-        camera_dict = np.load(self.cam_file)
-        c2w_all = []
-        for idx in range(self.n_images):
-            P = camera_dict["world_mat_%d" % idx].astype(np.float32)
-            if scaled:
-                P = P @ camera_dict["scale_mat_%d" % idx].astype(np.float32)
-            c2w_all.append(torch.from_numpy(load_K_Rt_from_P(P[:3, :4])[1]).float())
-        return torch.stack(c2w_all, 0)
+        """[n, 4, 4] camera-to-world WITHOUT the scale_radius normalisation (DTU.py:132-147)."""
+        return torch.from_numpy(decompose_projections(_stack_cameras(self.cam_file, self.n_images, scaled))[1]).float()
+
+
+_LAYOUTS = {"DTU": SceneDataset}           # the folder layout every reference config uses; 'custom' / 'BlendedMVS' are out of scope
 
 
 def get_data(args, return_val=False, val_downscale=4.0, **overwrite_cfgs):
-    """dataio/__init__.py:1-26 for the 'DTU' layout every reference config uses."""
-    dataset_type = args.data.get("type", "DTU")
-    if dataset_type != "DTU":
-        raise NotImplementedError(f"dataset type {dataset_type!r}: only the DTU / IDR folder layout of the reference's configs is built")
-    cfgs = {"scale_radius": args.data.get("scale_radius", -1), "downscale": args.data.downscale, "data_dir": args.data.data_dir,
-            "train_cameras": False, "cam_file": args.data.get("cam_file", None)}
-    cfgs.update(overwrite_cfgs)
-    dataset = SceneDataset(**cfgs)
+    """Dataset(s) of a config (`dataio.get_data`, dataio/__init__.py:1-26): the training set and, with return_val, a second
+    instance at `val_downscale`."""
+    layout = args.data.get("type", "DTU")
+    if layout not in _LAYOUTS:
+        raise NotImplementedError(f"dataset type {layout!r}: only the DTU / IDR folder layout of the reference's configs is built")
+    kw = dict(train_cameras=False, data_dir=args.data.data_dir, downscale=args.data.downscale,
+              scale_radius=args.data.get("scale_radius", -1), cam_file=args.data.get("cam_file", None))
+    kw.update(overwrite_cfgs)
+    sets = [_LAYOUTS[layout](**kw)]
     if return_val:
-        cfgs["downscale"] = val_downscale
-        return dataset, SceneDataset(**cfgs)
-    return dataset
+        sets.append(_LAYOUTS[layout](**{**kw, "downscale": val_downscale}))
+    return tuple(sets) if return_val else sets[0]

@@ -143,12 +143,27 @@ class _PackedModel(nn.Module):
         if r.embed_multires != -1 or r.embed_multires_view not in (-1, 4):
             raise NotImplementedError("radiance embed_multires must be -1 and embed_multires_view in (-1, 4)")
         self.view_tiles = 1 if r.embed_multires_view == -1 else 3
-        import weakref
-        object.__setattr__(s, "_owner", weakref.ref(self))      # not a submodule: the surface net queries through this model's blob
+        self._bind_owner()
         self._plans = {}
         self._blobs = None
         self._blob_key = None
         self.precision = "fp32"
+
+    def _bind_owner(self):
+        import weakref
+        # not a submodule: the surface net queries through this model's blob
+        object.__setattr__(self.implicit_surface, "_owner", weakref.ref(self))
+
+    def __deepcopy__(self, memo):
+        """copy.deepcopy treats the weakref as atomic: a copied surface net would keep querying the ORIGINAL model's weights.
+        Copy everything else, then point the copy's surface net at the copy; packed blobs are rebuilt on first use."""
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = None if k in ("_blobs", "_blob_key") else copy.deepcopy(v, memo)
+        new._bind_owner()
+        return new
 
     def set_precision(self, precision: str):
         """'fp32'  : v_mfma_f32_16x16x4_f32, exact fp32 FMA chains (157 TFLOP/s peak);

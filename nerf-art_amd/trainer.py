@@ -49,7 +49,16 @@ class Trainer(nn.Module):
 
     @property
     def native(self) -> bool:
-        return (self.model.precision == "bf16x3") if self._native is None else self._native
+        """Pass 2 on the hand-written kernels.  Those entry points (radiance_fwd_dump / radiance_bwd / sdf_fwd2 / sdf_bwd2 and
+        the state render_keep hands them) read split-bf16 blobs only: forcing native=True on another precision would feed them
+        an fp32-layout blob, so that combination is an error, checked every time the flag is read (set_precision may be
+        called after the trainer is built)."""
+        if self._native is None:
+            return self.model.precision == "bf16x3"
+        if self._native and self.model.precision != "bf16x3":
+            raise RuntimeError(f"Trainer(native=True) needs model.set_precision('bf16x3'); the model is at {self.model.precision!r} "
+                               "(use native=False / native=None for the autograd formulation)")
+        return self._native
 
     # ---- pass 1 ---------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -102,6 +111,8 @@ class Trainer(nn.Module):
         (1 KiB / point in HBM) for pass 2: the weights do not change between the passes and perturb=False is
         deterministic, so pass 2 would recompute exactly these.  Returns rgb [N, 3]; the state waits in self._kept."""
         m = self.model
+        if m.precision != "bf16x3":
+            raise RuntimeError("render_keep keeps split-bf16 pass-1 state for the native pass 2: set_precision('bf16x3') first")
         o = rays_o.reshape(-1, 3).float().contiguous()
         d_raw = rays_d.reshape(-1, 3).float().contiguous()
         surf_blob, rad_blob = m.packed()

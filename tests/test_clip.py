@@ -1,6 +1,8 @@
 """Rows a20-a23 (CLIP ViT-B/32 + loss heads), CPU.  PARITY UNPINNED against the OpenAI weights (no checkpoint, no
 network): the architecture is pinned against `transformers.CLIPModel` (random weights, default config = ViT-B/32)
 through the OpenAI -> HF parameter-name map of SURVEY.md 8c; the loss heads against closed-form restatements."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -68,7 +70,7 @@ def test_image_encoder_backward_reaches_pixels():
 @pytest.fixture(scope="module")
 def feats():
     from nerfart_amd import clip_vit, criteria
-    return criteria.ClipFeatures(model=clip_vit.build_clip("cpu", seed=0), device="cpu")
+    return criteria.ClipFeatures(model=clip_vit.build_clip("cpu", seed=0), device="cpu", synthetic=True)
 
 
 def test_preprocess_shapes_and_quirks(feats):
@@ -127,3 +129,16 @@ def test_create_fine_neg_texts(tmp_path):
     assert criteria.create_fine_neg_texts("painting, oil on canvas", str(p)) == ["a zombie", "a photo", "a cat"]
     assert criteria.create_fine_neg_texts("a Zombie face", str(p)) == ["a portrait", "a selfie", "a photo", "a cat"]
     assert len(criteria.create_fine_neg_texts("cubism", str(p))) == 5
+
+
+def test_create_fine_neg_texts_matches_reference_golden(golden):
+    """G13: the list the reference's Trainer.create_fine_neg_texts built from its own criteria/neg_text.txt (a data file of the
+    reference, read where it lies - build container only)."""
+    from nerfart_amd import criteria
+    path = "/root/reference/criteria/neg_text.txt"
+    if not os.path.exists(path):
+        pytest.skip("reference data file not present on this box")
+    got = criteria.create_fine_neg_texts("painting, oil on canvas, Vincent van gogh self-portrait style", path)
+    assert got == [str(t) for t in golden["G13_neg_texts"]]
+    assert criteria.prompt_family("Pixlar") == "disney" and criteria.prompt_family("a sketch of a wolf") == "wolf"
+    assert criteria.prompt_family("cubism") is None

@@ -41,3 +41,15 @@ def test_reference_yamls_load_unchanged():
         assert type(m).__name__ == fw
         if c.get("finetune"):
             assert c.finetune.target_text.startswith("painting")
+
+
+def test_base_yaml_merges_nested_sections(tmp_path):
+    """load_yaml(path, default_path): the user file overrides the base file key by key INSIDE nested sections (addict's
+    recursive update in the reference, io_util.py:201-212) - a shallow update would drop the base's other training keys."""
+    from nerfart_amd import config
+    (tmp_path / "base.yaml").write_text("expname: base\ntraining:\n  lr: 1.0e-3\n  num_iters: 100\n  scheduler:\n    type: multistep\n    gamma: 0.5\nmodel:\n  W: 256\n")
+    (tmp_path / "user.yaml").write_text("expname: mine\ntraining:\n  lr: 5.0e-4\n  scheduler:\n    gamma: 0.1\ndata:\n  downscale: 2\n")
+    c = config.load_yaml(str(tmp_path / "user.yaml"), default_path=str(tmp_path / "base.yaml"))
+    assert c.expname == "mine" and c.training.lr == 5.0e-4 and c.training.num_iters == 100
+    assert c.training.scheduler.type == "multistep" and c.training.scheduler.gamma == 0.1
+    assert c.model.W == 256 and c.data.downscale == 2

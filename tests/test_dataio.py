@@ -45,6 +45,20 @@ def test_load_K_Rt_from_P_properties(cg):
     np.testing.assert_allclose(pose[:3, 3], ct, atol=1e-6)
 
 
+def test_projection_sign_and_batch(cg):
+    """A projection matrix is defined up to sign: -P decomposes to the same proper rotation; the batched
+    decomposition equals the per-camera one."""
+    from nerfart_amd.dataio import load_K_Rt_from_P, decompose_projections
+    Ps = np.stack([(cg[f"C2_world_mat_{i}"] @ cg[f"C2_scale_mat_{i}"])[:3, :4] for i in range(6)]).astype(np.float64)
+    Kb, cb = decompose_projections(Ps)
+    for i in range(6):
+        K1, c1 = load_K_Rt_from_P(Ps[i])
+        Kn, cn = load_K_Rt_from_P(-Ps[i])
+        np.testing.assert_array_equal(K1, Kb[i]); np.testing.assert_array_equal(c1, cb[i])
+        np.testing.assert_allclose(Kn, K1, rtol=1e-12, atol=1e-12); np.testing.assert_allclose(cn, c1, atol=1e-6)
+        assert np.linalg.det(cn[:3, :3].astype(np.float64)) > 0.999
+
+
 def _make_scene(tmp_path, n=3, H=12, W=8):
     from PIL import Image
     z = np.load(GOLD)

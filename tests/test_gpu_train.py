@@ -264,7 +264,7 @@ def test_clip_heads_fp16_match_fp32_on_gpu():
         model = clip_vit.build_clip(DEV, seed=0)
         if prec == "fp32":
             model = model.float()
-        feats = criteria.ClipFeatures(model=model, device=DEV,
+        feats = criteria.ClipFeatures(model=model, device=DEV, synthetic=True, native=False,
                                       templates=["a photo of a {}.", "a sketch of a {}.", "art of the {}.", "a {} in a video game."])
         p = pred.clone().requires_grad_(True)
         l1 = criteria.CLIPLoss(feats)(gt, "photo", p, "painting")

@@ -28,7 +28,7 @@ def main():
     H, W = args.H, args.W
     c2w, K = scene.camera(H, W)
     o, d, _ = rend_util.get_rays(c2w[None].to(dev), K[None].to(dev), H, W)
-    feats = criteria.ClipFeatures(model=clip_vit.build_clip(dev, seed=0), device=dev)
+    feats = criteria.ClipFeatures(model=clip_vit.build_clip(dev, seed=0), device=dev, synthetic=True)
     style = criteria.StyleLoss(feats, (H, W), neg_texts=[f"negative prompt {i}" for i in range(16)],
                                perceptual=None if args.no_vgg else vgg.VGGPerceptualLoss().to(dev))
     with torch.no_grad():
