@@ -12,6 +12,10 @@ own view per step (views of a camera orbit round-robin over ranks - how the refe
 shards) and the rendered tiles are all-gathered over RCCL: weak scaling, value = all rays of all ranks /
 max-over-ranks time.
 
+With N > 1 the same run ALSO times the strong-scaling mode (`"strong"` in the JSON; --shard tiles makes it the
+primary line): ONE frame per step cut into 2,048-ray tiles dealt round-robin over the ranks (nerfart_amd.dist.render_sharded,
+how a single 960 x 540 frame of cfg 5 is sharded) + one all_gather, value = rays of that one frame / max-over-ranks time.
+
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (fused encode + SDF MLP): achieved =
 algorithmic flops per launch (F_sdf = 1,049,088 per point) / average launch duration from HIP
 events recorded on the launching stream during the timed steps.  --precision bf16x3 (default): k_sdf_only_bf16,
@@ -34,6 +38,9 @@ if ROOT not in sys.path:
 
 F_SDF, F_NABLA, F_RAD = 1049088, 918016, 530432          # algorithmic flops / point
 H, W, N_SAMPLES, N_IMPORTANCE = 480, 270, 128, 64
+# MACs per point the matrix cores actually execute in k_sdf_only[_bf16]: 8 hidden layers with k padded to whole 32-slot units
+# (layer 0: 2 encoding units, skip layer 4: 7 + 2 units), the 257-row last layer is a 1-row VALU dot (not MFMA work)
+MFMA_MAC_SDF = 256 * (64 + 3 * 256 + 288 + 3 * 256)
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0
 
@@ -46,8 +53,12 @@ def main():
     ap.add_argument("--beta", type=float, default=0.01)
     ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="bf16x3",
                     help="fp32: exact v_mfma_f32_16x16x4_f32; bf16x3: split-bf16 operands on v_mfma_f32_16x16x32_bf16")
+    ap.add_argument("--shard", choices=["views", "tiles"], default="views",
+                    help="N > 1: views = one view per rank per step (weak scaling, the primary line); tiles = one frame per step "
+                         "sharded over the ranks in 2,048-ray tiles (strong scaling).  The other mode is reported as a secondary object.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rays", type=int, default=768)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (fp32 mode, the other sharding mode)")
+    ap.add_argument("--cpu-rays", type=int, default=2048)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -94,29 +105,70 @@ def main():
             nd.all_gather_tiles(tile)
         return rgb, ex
 
-    for s in range(args.warmup):
-        step(s)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    hip.profile_begin()
-    t0 = time.perf_counter()
-    for s in range(args.warmup, args.warmup + args.steps):
-        step(s)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    prof = hip.profile_end()
-    if dist is not None:
-        tmax = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax)
+    shared = []                                      # strong mode: every rank holds the SAME frame's rays (rank 0's views)
+    for s_ in range(n_views):
+        c2w, K = scene.camera(H, W, angle=angles[(s_ * world) % len(angles)])
+        o_, d_, _ = rend_util.get_rays(c2w[None].to(dev), K[None].to(dev), H, W)
+        shared.append((o_, d_))
 
-    rays_per_step = H * W * world
+    def step_tiles(s, detailed=False):
+        o, d = shared[s]
+        return nd.render_sharded(render_fn, o, d, tile=2048, require_nablas=True, calc_normal=True, detailed_output=False, **kw)
+
+    def timed(fn, profile=False):
+        """W warm-up calls, then exactly K timed ones between barrier + synchronize pairs; max over ranks."""
+        for s_ in range(args.warmup):
+            fn(s_)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        if profile:
+            hip.profile_begin()
+        t0 = time.perf_counter()
+        for s_ in range(args.warmup, args.warmup + args.steps):
+            fn(s_)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt_ = time.perf_counter() - t0
+        prof_ = hip.profile_end() if profile else None
+        if dist is not None:
+            tmax = torch.tensor([dt_], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt_ = float(tmax)
+        return dt_, prof_
+
+    primary_tiles = args.shard == "tiles" and world > 1
+    dt, prof = timed(step_tiles if primary_tiles else step, profile=True)
+
+    rays_per_step = H * W * (1 if primary_tiles else world)
     value = rays_per_step * args.steps / dt
+
+    # secondary measurements (never the primary `value`): the other sharding mode at N > 1; the exact-fp32 mode at N = 1
+    secondary = {}
+    if world > 1 and not args.no_secondary:
+        dt2, _ = timed(step if primary_tiles else step_tiles)
+        r2 = H * W * (world if primary_tiles else 1)
+        secondary["weak_views" if primary_tiles else "strong_tiles"] = {
+            "value": round(r2 * args.steps / dt2, 1), "unit": "rays/s", "ms_per_step": round(dt2 / args.steps * 1e3, 2),
+            "scaling": "weak" if primary_tiles else "strong",
+            "what": ("one view per rank per step" if primary_tiles else
+                     "ONE 480x270 frame per step, 2,048-ray tiles round-robin over the ranks (dist.render_sharded) + one all_gather")}
+    if world == 1 and not args.no_secondary and args.precision == "bf16x3":
+        m32, _, f32 = scene.build_model("VolSDF", seed=0, beta=args.beta, device=dev, precision="fp32")
+        m32.packed()
+        o_, d_ = rays[0]
+        f32(o_, d_, require_nablas=True, calc_normal=True, detailed_output=False, **kw)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        f32(*rays[min(1, len(rays) - 1)], require_nablas=True, calc_normal=True, detailed_output=False, **kw)
+        torch.cuda.synchronize()
+        t32 = time.perf_counter() - t1
+        secondary["fp32_exact"] = {"value": round(H * W / t32, 1), "unit": "rays/s", "ms_per_step": round(t32 * 1e3, 2), "steps": 1,
+                                   "what": "same frame with --precision fp32 (v_mfma_f32_16x16x4_f32, exact fp32 products)"}
+        del m32, f32
 
     # algorithmic work of one of this rank's frames (uses the iter_usage the renderer reports)
     _, ex = step(args.warmup, detailed=True)
@@ -142,19 +194,25 @@ def main():
                     "points_per_launch": int(points / launches),
                     "flops_per_point": F_SDF}
         if args.precision == "bf16x3":
-            # every algorithmic product is three bf16 MFMAs (hi.hi + hi.lo + lo.hi): the matrix cores do 3x `achieved`
-            roofline["mfma_hw_frac"] = round(3.0 * achieved / peak, 4)
-        # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-        # separate runs; (2*FETCH + WRITE) KiB with the gfx950 FETCH_SIZE correction) - bench.py itself cannot
-        # read hardware counters.
+            # what the matrix pipe executes: MFMA_MAC_SDF multiply-adds per point, each as `mfma_per_product` bf16 MFMAs
+            # (hi.hi + hi.lo + lo.hi), as a fraction of the dense bf16 peak
+            roofline["mfma_per_product"] = 3
+            roofline["mfma_executed_frac"] = round(3 * 2.0 * MFMA_MAC_SDF * (points / launches) / avg_s / 1e12 / peak, 4)
+        # HBM traffic per launch is a PROFILED figure, not measured in this run (bench.py cannot read hardware counters): it
+        # comes from the newest committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs; (2*FETCH +
+        # WRITE) KiB with the gfx950 FETCH_SIZE correction) and is reported as `traffic` only if that profile was taken on
+        # the kernel sources this run executes (source hash recorded by tools/pmc_summary.py); otherwise it is marked stale.
         import glob
         pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
         if pm:
             try:
-                kk = json.load(open(pm[-1]))["kernels"][kname]
-                roofline["traffic"] = int(kk["hbm_bytes_corrected_per_launch"])
-                roofline["traffic_source"] = os.path.basename(pm[-1])
-                roofline["mfma_util_pmc"] = round(kk.get("mfma_util", 0.0), 4)
+                js = json.load(open(pm[-1]))
+                kk = js["kernels"][kname]
+                fresh = js.get("csrc_sha256") == hip.csrc_sha256()
+                roofline["traffic_profiled"] = {"bytes_per_launch": int(kk["hbm_bytes_corrected_per_launch"]), "source": os.path.basename(pm[-1]),
+                                                "profile_csrc_sha256": js.get("csrc_sha256"), "matches_this_build": fresh,
+                                                "mfma_busy_pmc": round(kk.get("mfma_util", 0.0), 4)}
+                roofline["traffic"] = int(kk["hbm_bytes_corrected_per_launch"]) if fresh else None
             except Exception:
                 pass
     kernels_ms = {k: round(v[0] / args.steps, 3) for k, v in prof.items()}
@@ -162,39 +220,57 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import render as orender
+        try:
+            import psutil
+            cores = psutil.cpu_count(logical=False) or os.cpu_count()
+        except Exception:
+            cores = os.cpu_count()
+        torch.set_num_threads(int(cores))             # one thread per PHYSICAL core (SMT siblings only oversubscribe the GEMMs)
+        cpu_model = next((ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")), "unknown")
         sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-        n_cpu = args.cpu_rays
-        sel = torch.arange(0, H * W, (H * W) // n_cpu)[:n_cpu]
         o, d = rays[args.warmup]
-        oc, dc = o[0, sel].cpu(), d[0, sel].cpu()
-        cores = torch.get_num_threads()
-        with torch.no_grad():
-            t1 = time.perf_counter()
-            orender.volsdf_render(sd, oc, dc, near=0.0, far=6.0, obj_bounding_radius=3.0, N_samples=N_SAMPLES,
-                                  N_importance=N_IMPORTANCE, max_upsample_steps=kw["max_upsample_steps"], chunk=256)
-            tc = time.perf_counter() - t1
-        cpu = {"value": round(n_cpu / tc, 1), "unit": "rays/s", "cores": cores, "kind": "port",
-               "sample": f"{n_cpu} rays strided over the same 480x270 frame, {N_SAMPLES}+{N_IMPORTANCE} spp, "
-                         f"oracle/render.py volsdf_render on torch-CPU fp32, {tc:.1f} s"}
+
+        def cpu_run(n):                               # n rays strided over the frame, ONE chunk (>= 2,048-ray chunks once calibrated)
+            sel = torch.arange(0, H * W, (H * W) // n)[:n]
+            oc, dc = o[0, sel].cpu(), d[0, sel].cpu()
+            with torch.no_grad():
+                t1 = time.perf_counter()
+                orender.volsdf_render(sd, oc, dc, near=0.0, far=6.0, obj_bounding_radius=3.0, N_samples=N_SAMPLES,
+                                      N_importance=N_IMPORTANCE, max_upsample_steps=kw["max_upsample_steps"], chunk=max(n, 2048))
+                return time.perf_counter() - t1
+        t_cal = cpu_run(256)                          # calibration (also warms the allocator / thread pool)
+        n_cpu = int(min(max(20.0 * 256 / t_cal, 512), args.cpu_rays * 2) // 256 * 256)      # about 20 s of CPU work
+        tc = cpu_run(n_cpu)
+        cpu = {"value": round(n_cpu / tc, 1), "unit": "rays/s", "cores": int(cores), "kind": "port", "cpu_model": cpu_model,
+               "sample": f"{n_cpu} rays strided over the same 480x270 frame in one chunk, {N_SAMPLES}+{N_IMPORTANCE} spp, "
+                         f"oracle/render.py volsdf_render on torch-CPU fp32, {int(cores)} threads, {tc:.1f} s",
+               "reference_in_survey_container": {"value": 93.0, "unit": "rays/s", "cores": 8, "cpu_model": "Intel Xeon @ 2.10GHz",
+                                                 "what": "the reference's own render_fn at 128 spp, timed once in the survey "
+                                                         "container (BASELINE.md section 2: 86-107 rays/s); cannot be re-run on the GPU box"}}
 
     if rank == 0:
         out = {
             "metric": "rays/sec at 480x270x128spp VolSDF render",
             "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong" if primary_tiles else "weak",
             "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16x3 (f32 split into 2 bf16 terms, f32 accumulate)", "data": "synthetic",
             "config": {"workload": "configs[1]: volsdf_fangzhou_nature.yaml dims, 480x270 rays/frame, 128 coarse + 64 fine "
                                    "spp, pure renderer (no CLIP), synthetic random-weight scene beta=%g" % args.beta,
                        "rays_per_step_per_gpu": H * W, "samples_per_ray": N_SAMPLES + N_IMPORTANCE,
-                       "parallelism": f"views round-robin over {world} rank(s), all_gather of [rays,7] tiles" if world > 1 else "1 GPU",
+                       "parallelism": ("1 GPU" if world == 1 else
+                                       f"one frame per step in 2,048-ray tiles round-robin over {world} ranks, one all_gather" if primary_tiles else
+                                       f"views round-robin over {world} rank(s), all_gather of [rays,7] tiles"),
+                       "rayschunk": "the configured val_rayschunk (%s) is NOT used: the whole frame is one 65,536-ray-chunked call "
+                                    "(results are bit-identical for any chunking: tests/test_gpu_parity.py)" % rk.get("rayschunk"),
                        "samples_per_sec": round(value * (N_SAMPLES + N_IMPORTANCE), 1),
                        "iter_usage_hist": hist,
                        "algorithmic_tflop_per_frame": round(flops_frame / 1e12, 2),
-                       "end_to_end_tflops": round(flops_frame * world * args.steps / dt / 1e12, 2),
+                       "end_to_end_tflops": round(flops_frame * (1 if primary_tiles else world) * args.steps / dt / 1e12, 2),
                        "mlp_kernel_ms_per_step": kernels_ms,
                        "ref_3090_rays_per_s": 6480},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "secondary": secondary or None,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -22,6 +22,19 @@ if not os.path.exists(LIB_PATH):
 
 lib = C.CDLL(LIB_PATH)
 
+
+def csrc_sha256() -> str:
+    """SHA-256 over the kernel sources (csrc/*.hip, *.h, *.cpp, sorted by name): stamps profiles so that a bench line can say
+    whether a committed PMC summary was taken on the code it runs."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h"))
+                    + glob.glob(os.path.join(_HERE, "csrc", "*.cpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
 _p, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 _SIGS = {
     "nerfart_abi_version": (_i, []),

@@ -411,7 +411,7 @@ class Trainer(nn.Module):
         return OrderedDict([("losses", losses), ("extras", extras)])
 
     # ---- one fine-tune step ---------------------------------------------------------------------------
-    def finetune_step(self, render_fn, rays_o, rays_d, target_rgb, H: int, style_loss, optimizer=None, tile: int = 2048,
+    def finetune_step(self, render_fn, rays_o, rays_d, target_rgb, H: int, style_loss, optimizer=None, tile: int = None,
                       **render_kwargs):
         """style_loss(rgb_pred [B,3,H,W], rgb_gt [B,3,H,W]) -> scalar.  Returns dict(loss, eikonal, rgb).
 

@@ -28,8 +28,8 @@ def _worker(rank, world, port, out_dir):
         frame = nd.render_sharded(render_fn, o, d, keys=keys, tile=16, detailed_output=False, require_nablas=True, calc_normal=True, **kw)
         tr = Trainer(model, pass2_rays=8, patches_per_launch=2)
         model.zero_grad()
-        out = tr.finetune_step(render_fn, o, d, target, H, loss_fn, tile=16, **kw)          # 70 rays: tiles of 16 dealt 3 + 2
-        assert nd.world_size() == 2 and len(nd.my_ray_indices(H * W, 16, rank, world)) in (38, 32)
+        out = tr.finetune_step(render_fn, o, d, target, H, loss_fn, **kw)       # 70 rays: 8-ray patches dealt 5 (38 rays) + 4 (32)
+        assert nd.world_size() == 2 and len(nd.my_ray_indices(H * W, 8, rank, world)) in (38, 32)
         sharded = {n: p.grad.clone() for n, p in model.named_parameters()}
         rgb_sharded = out["rgb"].clone()
         dist.barrier()
@@ -45,9 +45,9 @@ def _worker(rank, world, port, out_dir):
             assert abs(out["loss"] - ref["loss"]) < 1e-7
             for n, p in model.named_parameters():
                 rel = float((sharded[n] - p.grad).norm() / (p.grad.norm() + 1e-12))
-                # the eikonal means are per 8-ray patch in both; the patches differ (per-rank tiles), so only the rgb part is
-                # identical: compare with the eikonal term's tolerance
-                assert rel < 5e-2, (n, rel)
+                # ranks own whole patches of the single-process patch grid (tile = pass2_rays): same per-patch eikonal means,
+                # same per-point operands - only the summation order of the weight-gradient GEMMs / the all-reduce differs
+                assert rel < 1e-4, (n, rel)
         open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
     except Exception as e:                                            # surfaced by the parent
         import traceback

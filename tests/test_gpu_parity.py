@@ -49,6 +49,8 @@ def close(name, a, b, atol, rtol=0.0, frac=1.0):
         return
     err = report(name, a, b)
     ok = (err <= atol + rtol * b.abs()) | (a == b)
+    if frac < 1.0:
+        print(f"    [{name}] fraction within tol: {ok.double().mean().item():.5f} (required {frac})")
     assert ok.double().mean().item() >= frac, f"{name}: {(~ok).sum().item()} / {ok.numel()} outside tol, max {err.max().item():.3e}"
 
 
@@ -182,7 +184,7 @@ def test_fine_sample_matches_oracle_and_golden(golden, beta):
     u_ref = golden[f"G8_{tag}_iter_usage"]
     same = usage.cpu().numpy() == u_ref
     print(f"  iter_usage agreement {same.mean():.3f}; hip {np.unique(usage.cpu().numpy(), return_counts=True)} ref {np.unique(u_ref, return_counts=True)}")
-    assert same.mean() >= 0.95, "iter_usage differs on more rays than threshold-straddling can explain"
+    assert same.all(), "fp32 path: iter_usage is identical to the reference's on every golden ray (measured 1.000 in round 1)"
     m = torch.from_numpy(same)
     conv = m & (usage.cpu() >= 0)
     unconv = m & (usage.cpu() < 0)
@@ -212,7 +214,7 @@ def test_volsdf_render_matches_reference_golden(golden, beta, ns):
                                "radiance", "alpha", "p_i", "visibility_weights", "d_vals", "sigma", "beta_map", "iter_usage"]
     same = (ex["iter_usage"][0].cpu().numpy() == golden[tag + "iter_usage"])
     print(f"  rays with identical iter_usage: {same.mean():.3f}")
-    assert same.mean() >= 0.95
+    assert same.all(), "fp32 path: every golden ray takes the reference's number of up-sampling rounds (measured 1.000 in round 1)"
     m = torch.from_numpy(same)
     tol = {"rgb": (1e-4, 0), "depth_volume": (1e-3, 0), "mask_volume": (1e-4, 0), "normals_volume": (1e-3, 0),
            "implicit_surface": (3e-5, 0), "implicit_nablas": (3e-4, 3e-4), "radiance": (1e-4, 0), "alpha": (2e-4, 0),
@@ -413,3 +415,24 @@ def test_dataset_to_frames(tmp_path):
         img = (rgb.cpu().reshape(H, W, 3).numpy() * 255.0).astype(np.uint8)
         assert img.shape == (24, 16, 3) and torch.isfinite(rgb).all() and torch.isfinite(depth).all()
         assert ex["normals_volume"].shape[-2:] == (H * W, 3)
+
+
+def test_batchify_query_over_the_hip_point_query(pts):
+    """Row a10: `batchify_query(model.forward, pts[(B),R,P,3], view_dirs, chunk=netchunk, dim_batchify=1, return_nablas=True)` -
+    the reference's call at volsdf.py:506-513 - on the HIP-backed model equals the oracle's point query, for any chunk."""
+    from oracle import nets
+    from nerfart_amd.train_util import batchify_query
+    model, _, _ = _model()
+    sd, _ = scene_state("VolSDF", 0.01)
+    p, v = pts
+    x, vd = p[:960].reshape(1, 40, 24, 3).to(DEV), v[:960].reshape(1, 40, 24, 3).to(DEV)
+    rad, sdf, nab = batchify_query(model.forward, x, vd, chunk=333, dim_batchify=1, return_nablas=True)
+    assert rad.shape == (1, 40, 24, 3) and sdf.shape == (1, 40, 24) and nab.shape == (1, 40, 24, 3)
+    r_ref, s_ref, n_ref = nets.volsdf_forward(sd, p[:960], v[:960])
+    close("batchify sdf", sdf.reshape(-1), s_ref, 2e-5)
+    close("batchify nabla", nab.reshape(-1, 3), n_ref, 2e-4, 2e-4)
+    close("batchify radiance", rad.reshape(-1, 3), r_ref, 1e-4)
+    rad1, sdf1, nab1 = batchify_query(model.forward, x, vd, chunk=1 << 20, dim_batchify=1, return_nablas=True)
+    assert torch.equal(rad, rad1) and torch.equal(sdf, sdf1) and torch.equal(nab, nab1), "results do not depend on netchunk"
+    sdf_only = batchify_query(lambda q, return_nablas: model.forward_surface(q)[0], x, chunk=500, dim_batchify=1, return_nablas=False)
+    close("batchify forward_surface", sdf_only.reshape(-1), s_ref, 2e-5)

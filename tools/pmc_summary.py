@@ -29,7 +29,14 @@ def main():
     note = ("rocprofv3 --pmc passes of `python bench.py --steps 1 --warmup 1` (1x MI355X); averages per dispatch. "
             "FETCH_SIZE/WRITE_SIZE in KiB as reported; hbm_bytes_corrected = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
             "(gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md).")
-    json.dump({"kernels": kern, "note": note}, open(out, "w"), indent=1, sort_keys=True)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        from nerfart_amd import hip
+        sha = hip.csrc_sha256()
+    except Exception:
+        sha = None
+    json.dump({"kernels": kern, "note": note, "csrc_sha256": sha}, open(out, "w"), indent=1, sort_keys=True)
     print(out, len(kern), "kernels")
 
 
