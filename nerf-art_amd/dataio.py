@@ -102,8 +102,8 @@ def _stack_cameras(cam_file, n, scaled=True):
 class SceneDataset(torch.utils.data.Dataset):
     """IDR-style scene folder -> per-view items with the reference dataset's contract (dataio/DTU.py:11-155):
     `ds[i] = (i, {"object_mask" [H W] bool, "intrinsics" [4,4], "c2w" [4,4]}, {"rgb" [H W, 3]})`, attributes `n_images, H, W,
-    downscale, instance_dir, cam_file, train_cameras, intrinsics_all, c2w_all, rgb_images, object_masks` (the per-view
-    containers are stacked tensors here; indexing and iteration give the reference's per-view tensors).
+    downscale, instance_dir, cam_file, train_cameras, intrinsics_all, c2w_all, rgb_images, object_masks` (per-view lists, as
+    render.py's `torch.stack(dataset.c2w_all)` expects - here views into one stacked tensor each).
 
     Cameras are decomposed for all views in one batched call; the intrinsics' focal lengths and principal point are
     divided by `downscale` (the skew, a ratio, is not: DTU.py:58-63) and, with scale_radius > 0, camera centres are
@@ -121,16 +121,16 @@ class SceneDataset(torch.utils.data.Dataset):
         K4[:, [0, 1, 0, 1], [0, 1, 2, 2]] /= downscale
         if scale_radius > 0:
             c2w[:, :3, 3] *= scale_radius / np.linalg.norm(c2w[:, :3, 3], axis=1).max() / 1.1
-        self.intrinsics_all = torch.from_numpy(K4).float()
-        self.c2w_all = torch.from_numpy(c2w).float()
+        self.intrinsics_all = list(torch.from_numpy(K4).float().unbind(0))
+        self.c2w_all = list(torch.from_numpy(c2w).float().unbind(0))
 
         pixels = np.stack([load_rgb(f, downscale) for f in frames])           # [n, 3, H, W]
         self.H, self.W = pixels.shape[-2:]
-        self.rgb_images = torch.from_numpy(np.ascontiguousarray(pixels.reshape(self.n_images, 3, -1).transpose(0, 2, 1))).float()
+        self.rgb_images = list(torch.from_numpy(np.ascontiguousarray(pixels.reshape(self.n_images, 3, -1).transpose(0, 2, 1))).float().unbind(0))
         if mattes:
-            self.object_masks = torch.from_numpy(np.stack([load_mask(m, downscale).reshape(-1) for m in mattes])).bool()
+            self.object_masks = list(torch.from_numpy(np.stack([load_mask(m, downscale).reshape(-1) for m in mattes])).bool().unbind(0))
         else:                                                                   # no matte folder: everything is object
-            self.object_masks = torch.ones(self.n_images, self.H * self.W, dtype=torch.bool)
+            self.object_masks = list(torch.ones(self.n_images, self.H * self.W, dtype=torch.bool).unbind(0))
 
     def __len__(self):
         return self.n_images

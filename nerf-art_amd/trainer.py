@@ -418,8 +418,12 @@ class Trainer(nn.Module):
         With torch.distributed initialised (one process per GPU) the step is ray-parallel: pass 1
         renders this rank's tiles and all-gathers the image; every rank evaluates the (cheap, deterministic) style
         loss on the full image and keeps its own rays' d loss / d rgb; pass 2 runs on its own rays; one flat
-        all-reduce(SUM) of the gradients before the caller's optimizer.step()."""
+        all-reduce(SUM) of the gradients before the caller's optimizer.step().
+        tile (rays dealt to a rank at a time) defaults to pass2_rays: every rank then owns WHOLE patches of the single-process
+        step's patch grid, the per-patch eikonal means coincide and the all-reduced gradients equal the single-GPU step's up to
+        summation order."""
         sharded = nd.world_size() > 1
+        tile = self.pass2_rays if tile is None else tile
         keep = self.native                                # pass 1 keeps its per-point state for pass 2 (render_keep)
         self._kept = None
         if sharded:

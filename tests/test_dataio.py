@@ -92,6 +92,7 @@ def test_scene_dataset_matches_reference_contract(tmp_path):
     # the farthest camera sits at scale_radius / 1.1 (DTU.py:68-71)
     norms = [float(c[:3, 3].norm()) for c in ds.c2w_all]
     np.testing.assert_allclose(max(norms), 3.0 / 1.1, rtol=1e-5)
+    assert torch.stack(ds.c2w_all, dim=0).shape == (3, 4, 4)                      # render.py:309
     gtp = ds.get_gt_pose(scaled=True)
     assert gtp.shape == (3, 4, 4)
     np.testing.assert_allclose(gtp[0, :3, :3].numpy(), ds.c2w_all[0][:3, :3].numpy(), atol=1e-6)

@@ -70,16 +70,16 @@ def test_volsdf_render_bf16x3_vs_reference_golden(golden, beta, ns):
     tag = f"G9_b{beta}_n{ns}_"
     same = (ex["iter_usage"][0].cpu().numpy() == golden[tag + "iter_usage"])
     print(f"  rays with identical iter_usage: {same.mean():.3f}")
-    assert same.mean() >= 0.95
+    assert same.all(), "measured 1.000 on the golden rays at all three beta (round 2)"
     m = torch.from_numpy(same)
     close("rgb (1e-3, every ray with equal rounds)", ex["rgb"][0].cpu()[m], tt(golden[tag + "rgb"])[m], 1e-3)
-    close("rgb (tight, 95%)", ex["rgb"][0].cpu()[m], tt(golden[tag + "rgb"])[m], 2e-4, frac=0.95)
+    close("rgb (tight, 98%)", ex["rgb"][0].cpu()[m], tt(golden[tag + "rgb"])[m], 2e-4, frac=0.98)       # measured >= 0.9896
     close("mask", ex["mask_volume"][0].cpu()[m], tt(golden[tag + "mask_volume"])[m], 1e-3)
     close("depth", ex["depth_volume"][0].cpu()[m], tt(golden[tag + "depth_volume"])[m], 1e-2)
     close("normals", ex["normals_volume"][0].cpu()[m], tt(golden[tag + "normals_volume"])[m], 5e-3)
     # rays that took a different number of rounds are still valid renderings of the same field: bounded loosely
     report("rgb (all rays)", ex["rgb"][0].cpu(), tt(golden[tag + "rgb"]))
-    close("rgb (all rays, 2e-2)", ex["rgb"][0].cpu(), tt(golden[tag + "rgb"]), 2e-2)
+    close("rgb (all rays, 1e-3)", ex["rgb"][0].cpu(), tt(golden[tag + "rgb"]), 1e-3)                   # north-star bound, every golden ray
 
 
 def test_neus_render_bf16x3_vs_reference_golden(golden):
@@ -112,7 +112,7 @@ def test_full_frame_bf16x3_vs_fp32():
     err = (a - b).abs()
     print(f"  fp32 vs bf16x3 full frame: identical rounds on {same:.4f} of rays; rgb max {err.max().item():.2e}, "
           f"99.9 pct {err.flatten().kthvalue(int(0.999 * err.numel())).values.item():.2e}, PSNR {psnr:.1f} dB")
-    assert same >= 0.99 and psnr >= 60.0
+    assert same >= 0.995 and psnr >= 80.0                   # measured 0.9967 / 87.9 dB
 
 
 @pytest.mark.parametrize("M", [1, 127, 128, 1500])

@@ -222,7 +222,9 @@ def test_volsdf_render_matches_reference_golden(golden, beta, ns):
            "beta_map": (1e-6, 0.2), "iter_usage": (0, 0)}
     for k in keys:
         a, r = tol[k]
-        close(k, ex[k][0].cpu()[m], tt(golden[tag + k])[m], a, r, frac=0.95)
+        # measured (round 2, gpurun_out/r02a_pytest.log): 1.000 on every key at beta 0.1, >= 0.995 at beta 0.002 / 0.01 n128; the
+        # beta 0.01 n32 case has ONE ray of 64 whose bisection takes another branch (0.967 .. 0.985 of its entries differ)
+        close(k, ex[k][0].cpu()[m], tt(golden[tag + k])[m], a, r, frac=0.96)
     # the pixel bound of north_star holds for EVERY ray
     close("rgb (all rays, 1e-3)", ex["rgb"][0].cpu()[m], tt(golden[tag + "rgb"])[m], 1e-3)
     close("mask (all rays, 1e-3)", ex["mask_volume"][0].cpu()[m], tt(golden[tag + "mask_volume"])[m], 1e-3)
