@@ -199,6 +199,30 @@ int nerfart_neus_render_fwd(const float* surf_blob, const float* rad_blob, int p
  * caller's uniform random numbers - up-sampling round i uses columns [i * n_new, (i + 1) * n_new); 0: the shared
  * linspace(0, 1, n_new) table (u_new_dev [n_new] or NULL). */
 
+/* ---- B4: CLIP ViT-B/32 image encoder (third-party `clip`: `model.encode_image(img)` of `clip.load("ViT-B/32", device="cuda")`,
+ * reference call sites criteria/clip_loss.py:204-216, contrastive_loss.py:110-114, patchnce_loss.py:124-128) and its
+ * backward w.r.t. the image (what autograd does there when the style loss is back-propagated, volsdf.py:912-915; the CLIP
+ * weights are frozen).  csrc/clip_vit.hip: fp16 weights / GEMM operands on v_mfma_f32_32x32x16_f16, fp32 accumulation,
+ * LayerNorm / softmax / residual stream in fp32.
+ *   blob      : the `visual.*` parameters packed by nerf-art_amd/clip_native.py in the section order
+ *               nerfart_clip_vitb32_blob_layout() reports (offsets[203] in bytes, last = total size; returns the total):
+ *               fp16 matrices and their transposes (0 conv1, 2 + 8 l + j the four linear maps of block l, 98 proj), then
+ *               fp32 vectors (100 class / positional embeddings, LayerNorm parameters, biases) - list in csrc/clip_vit.hip.
+ *   img       : [B, 3, 224, 224] fp32, already resized and normalised (the reference's `preprocess`).
+ *   feat_out  : [B, 512] fp32 (un-normalised features, as encode_image returns them).
+ *   workspace : nerfart_clip_vitb32_workspace_bytes(B, keep_for_bwd) bytes of device memory.  With keep_for_bwd != 0 the
+ *               forward leaves the per-block activations there and nerfart_clip_vitb32_image_bwd(g_feat [B,512] ->
+ *               g_img [B,3,224,224]) must be given the SAME workspace, untouched; several forwards may be outstanding,
+ *               each with its own workspace. */
+long long nerfart_clip_vitb32_blob_layout(long long* offsets);
+long long nerfart_clip_vitb32_workspace_bytes(int B, int keep_for_bwd);
+int nerfart_clip_vitb32_image_fwd(const void* blob, const float* img, int B, float* feat_out, int keep_for_bwd, void* workspace,
+                                  long long workspace_bytes, void* stream);
+int nerfart_clip_vitb32_image_bwd(const void* blob, int B, const float* g_feat, float* g_img, void* workspace, long long workspace_bytes,
+                                  void* stream);
+/* The GEMM kernel of the encoder on its own (tests): C[M,N] fp32 = A[M,K] fp16 . W[N,K]^T fp16; M, N, K multiples of 64. */
+int nerfart_gemm_f16_nt(const void* A, const void* W, int M, int N, int K, float* C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

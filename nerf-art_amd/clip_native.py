@@ -1,0 +1,158 @@
+"""CLIP ViT-B/32 image encoder on the hand-written gfx950 kernels (rows a23 / B4): `encode_image` forward and its backward
+w.r.t. the image through the C ABI `nerfart_clip_vitb32_image_fwd` / `_bwd` (csrc/clip_vit.hip, include/nerfart_hip.h).
+
+    enc = NativeImageEncoder(clip_model)          # clip_vit.CLIP (or anything with OpenAI's `visual.*` state-dict names)
+    feat = enc(images)                            # [B, 3, 224, 224] normalised -> [B, 512] fp32, differentiable in `images`
+
+This replaces `model.encode_image(images)` at the reference's call sites (criteria/clip_loss.py:204-216,
+contrastive_loss.py:110-114, patchnce_loss.py:124-128).  The text encoder stays on the torch module: its outputs are
+constants of a run and are cached (criteria.ClipFeatures), SURVEY.md 8b B4.  Weights are frozen (requires_grad False in the
+reference's losses too): the backward pass produces the pixel gradient only.
+"""
+import ctypes as C
+
+import torch
+
+from . import hip
+
+N_SECTIONS = 202
+WIDTH, LAYERS, PATCH, RES, OUT = 768, 12, 32, 224, 512
+
+
+def blob_layout():
+    offs = (C.c_longlong * (N_SECTIONS + 1))()
+    total = hip.lib.nerfart_clip_vitb32_blob_layout(C.cast(offs, C.c_void_p))
+    return list(offs), int(total)
+
+
+def pack_visual(state, device) -> torch.Tensor:
+    """`visual.*` entries of a CLIP state dict -> the weight blob (uint8 tensor on `device`): fp16 matrices with their
+    transposes, fp32 vectors, in the section order of csrc/clip_vit.hip."""
+    offs, total = blob_layout()
+    blob = torch.zeros(total, dtype=torch.uint8, device=device)
+
+    def g(name):
+        return state["visual." + name].detach().to(device)
+
+    def put(i, t, dtype):
+        t = t.to(dtype).contiguous().reshape(-1)
+        n = t.numel() * t.element_size()
+        assert offs[i] + n <= offs[i + 1], (i, n, offs[i + 1] - offs[i])
+        blob[offs[i]: offs[i] + n] = t.view(torch.uint8)
+
+    def put_pair(i, w):                       # W [N, K] and W^T [K, N], fp16
+        w = w.to(torch.float16)
+        put(i, w, torch.float16)
+        put(i + 1, w.t(), torch.float16)
+
+    if g("conv1.weight").shape != (WIDTH, 3, PATCH, PATCH) or g("positional_embedding").shape != (50, WIDTH) or g("proj").shape != (WIDTH, OUT):
+        raise ValueError("clip_native: not a ViT-B/32 visual tower (conv1 768x3x32x32, 50 positions, proj 768x512)")
+    put_pair(0, g("conv1.weight").reshape(WIDTH, -1))
+    for l in range(LAYERS):
+        p = f"transformer.resblocks.{l}."
+        s, f = 2 + 8 * l, 104 + 8 * l
+        put_pair(s + 0, g(p + "attn.in_proj_weight"))
+        put_pair(s + 2, g(p + "attn.out_proj.weight"))
+        put_pair(s + 4, g(p + "mlp.c_fc.weight"))
+        put_pair(s + 6, g(p + "mlp.c_proj.weight"))
+        for j, n in enumerate(("ln_1.weight", "ln_1.bias", "attn.in_proj_bias", "attn.out_proj.bias", "ln_2.weight", "ln_2.bias",
+                               "mlp.c_fc.bias", "mlp.c_proj.bias")):
+            put(f + j, g(p + n), torch.float32)
+    proj = g("proj").to(torch.float16)
+    put(98, proj.t(), torch.float16)
+    put(99, proj, torch.float16)
+    put(100, g("class_embedding"), torch.float32)
+    put(101, g("positional_embedding"), torch.float32)
+    put(102, g("ln_pre.weight"), torch.float32)
+    put(103, g("ln_pre.bias"), torch.float32)
+    put(200, g("ln_post.weight"), torch.float32)
+    put(201, g("ln_post.bias"), torch.float32)
+    return blob
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what}: {hip.lib.nerfart_last_error().decode()}")
+
+
+def image_fwd(blob, images, keep: bool):
+    """images [B, 3, 224, 224] fp32 contiguous on the GPU -> (features [B, 512] fp32, workspace)."""
+    B = images.shape[0]
+    nbytes = hip.lib.nerfart_clip_vitb32_workspace_bytes(B, int(keep))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=images.device)
+    feat = torch.empty(B, OUT, dtype=torch.float32, device=images.device)
+    _check(hip.lib.nerfart_clip_vitb32_image_fwd(_ptr(blob), _ptr(images), B, _ptr(feat), int(keep), _ptr(ws), nbytes, _stream()),
+           "nerfart_clip_vitb32_image_fwd")
+    return feat, ws
+
+
+def image_bwd(blob, ws, B, g_feat):
+    g_img = torch.empty(B, 3, RES, RES, dtype=torch.float32, device=g_feat.device)
+    _check(hip.lib.nerfart_clip_vitb32_image_bwd(_ptr(blob), B, _ptr(g_feat), _ptr(g_img), _ptr(ws), ws.numel(), _stream()),
+           "nerfart_clip_vitb32_image_bwd")
+    return g_img
+
+
+class _Encode(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, images, blob):
+        x = images.detach().float().contiguous()
+        keep = bool(ctx.needs_input_grad[0])
+        feat, ws = image_fwd(blob, x, keep)
+        if keep:
+            ctx.blob, ctx.ws, ctx.B, ctx.in_dtype = blob, ws, x.shape[0], images.dtype
+        ctx.keep = keep
+        return feat
+
+    @staticmethod
+    def backward(ctx, g_feat):
+        if not ctx.keep:
+            return None, None
+        g = image_bwd(ctx.blob, ctx.ws, ctx.B, g_feat.detach().float().contiguous())
+        ctx.ws = None
+        return g.to(ctx.in_dtype), None
+
+
+def gemm_f16_nt(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """a [M, K] fp16 . w [N, K]^T fp16 -> [M, N] fp32 on the encoder's GEMM kernel (tests; M, N, K multiples of 64)."""
+    M, K = a.shape
+    N = w.shape[0]
+    c = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    _check(hip.lib.nerfart_gemm_f16_nt(_ptr(a.contiguous()), _ptr(w.contiguous()), M, N, K, _ptr(c), _stream()), "nerfart_gemm_f16_nt")
+    return c
+
+
+class NativeImageEncoder:
+    """Callable stand-in for `model.encode_image`; the blob is re-packed when the model's visual parameters change."""
+
+    def __init__(self, clip_model):
+        self.model = clip_model
+        self._blob, self._key = None, None
+
+    def _params_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.model.visual.parameters())
+
+    def blob(self):
+        key = self._params_key()
+        if self._blob is None or key != self._key:
+            dev = next(self.model.visual.parameters()).device
+            if dev.type != "cuda":
+                raise RuntimeError("clip_native: the CLIP model must be on the GPU (there is no CPU path)")
+            self._blob = pack_visual({"visual." + k: v for k, v in self.model.visual.state_dict().items()}, dev)
+            self._key = key
+        return self._blob
+
+    def __call__(self, images):
+        if images.dim() != 4 or tuple(images.shape[1:]) != (3, RES, RES):
+            raise ValueError(f"clip_native: images must be [B, 3, {RES}, {RES}], got {tuple(images.shape)}")
+        if not images.is_cuda:
+            raise RuntimeError("clip_native: images must be on the GPU")
+        return _Encode.apply(images, self.blob())

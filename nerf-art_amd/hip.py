@@ -76,6 +76,11 @@ _SIGS = {
     "nerfart_neus_composite": (_i, [_i, _i, _p, _p, _p, _p, _f, _i] + [_p] * 9),
     "nerfart_neus_render_workspace_bytes": (_ll, [_i, _i, _i, _i]),
     "nerfart_neus_render_fwd": (_i, [_p, _p, _i, _i, _p, _p, _i, _f, _f, _i, _i, _i, _i, _i] + [_p] * 2 + [_i] + [_p] * 12 + [_p, _ll, _p]),
+    "nerfart_clip_vitb32_blob_layout": (_ll, [_p]),
+    "nerfart_clip_vitb32_workspace_bytes": (_ll, [_i, _i]),
+    "nerfart_clip_vitb32_image_fwd": (_i, [_p, _p, _i, _p, _i, _p, _ll, _p]),
+    "nerfart_clip_vitb32_image_bwd": (_i, [_p, _i, _p, _p, _p, _ll, _p]),
+    "nerfart_gemm_f16_nt": (_i, [_p, _p, _i, _i, _i, _p, _p]),
 }
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)          # AttributeError here = header / library mismatch
