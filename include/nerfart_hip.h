@@ -220,6 +220,30 @@ int nerfart_clip_vitb32_image_fwd(const void* blob, const float* img, int B, flo
                                   long long workspace_bytes, void* stream);
 int nerfart_clip_vitb32_image_bwd(const void* blob, int B, const float* g_feat, float* g_img, void* workspace, long long workspace_bytes,
                                   void* stream);
+/* ---- image side of the style losses (rows a20-a22; csrc/style_heads.hip).
+ * nerfart_resample_fwd: one stage of the reference's torchvision `preprocess` chains (criteria/clip_loss.py:166-168,
+ * contrastive_loss.py:98-101, patchnce_loss.py:98-117, :184-215) as a gather: the source image(s) src [n_src, C, Hs, Ws] (n_src = 1:
+ * shared by all outputs, else N) sit at (pad_t, pad_l) inside a zero canvas Hp x Wp (ZeroPad2d), the canvas is resampled to
+ * Hr x Wr (mode 1 = bicubic A = -0.75, 0 = bilinear; align_corners = False, no antialias), output image n [C, Ho, Wo] is the
+ * window of it at crop_yx[n] = (y0, x0) (int32 [N, 2] on the device; NULL = (0, 0)), then v * affine[c] + affine[C + c]
+ * (affine NULL = identity: (x + 1) / 2 and Normalize(mean, std) fold into it).  src_win (int32 [N, 4] = y, x, h, w on the device, or
+ * NULL): output n resamples only that sub-window of its source, taps clamping at the window's edges - crop-then-resize, the
+ * 112 x 112 -> 224 x 224 patches of patchnce_loss.py:213-215 (the canvas is then the window: no padding, Hp / Wp ignored).
+ * nerfart_resample_bwd accumulates J^T g_dst into g_src (fp32 atomics; zero it first). */
+int nerfart_resample_fwd(const float* src, int n_src, int C, int Hs, int Ws, int pad_t, int pad_l, int Hp, int Wp, int Hr, int Wr, int mode,
+                         const int* crop_yx, const int* src_win, const float* affine, float* dst, int N, int Ho, int Wo, void* stream);
+int nerfart_resample_bwd(const float* g_dst, int n_src, int C, int Hs, int Ws, int pad_t, int pad_l, int Hp, int Wp, int Hr, int Wr, int mode,
+                         const int* crop_yx, const int* src_win, const float* affine, float* g_src, int N, int Ho, int Wo, void* stream);
+/* The three CLIP heads from image features feats [4 + P, 512] (rows: 0 directional prediction, 1 directional source, 2 contrastive
+ * prediction, 3 contrastive source, 4.. PatchNCE crops) and cached unit text features: text_dir [512] (clip_loss.py:234-246),
+ * t_tgt / t_con [T, 512] (templates of the target / of the contrastive negative prompt), t_neg [S, T, 512]:
+ *   out4 = {w_dir L_dir + w_con L_con + w_nce L_nce, L_dir (clip_loss.py:244-254), L_con (contrastive_loss.py:146-153, margin),
+ *           L_nce (patchnce_loss.py:153-173, temperature tau, summed over the P crops)},  g_feats [4 + P, 512] = d out4[0] / d feats
+ * (rows 1 and 3 are constants of the loss: zero). */
+int nerfart_clip_style_heads(const float* feats, int n_patches, const float* text_dir, const float* t_tgt, const float* t_con, const float* t_neg,
+                             int n_neg, int n_templates, float w_dir, float w_con, float w_nce, float margin, float tau, float* out4,
+                             float* g_feats, void* stream);
+
 /* The GEMM kernel of the encoder on its own (tests): C[M,N] fp32 = A[M,K] fp16 . W[N,K]^T fp16; M, N, K multiples of 64. */
 int nerfart_gemm_f16_nt(const void* A, const void* W, int M, int N, int K, float* C, void* stream);
 

@@ -81,6 +81,9 @@ _SIGS = {
     "nerfart_clip_vitb32_image_fwd": (_i, [_p, _p, _i, _p, _i, _p, _ll, _p]),
     "nerfart_clip_vitb32_image_bwd": (_i, [_p, _i, _p, _p, _p, _ll, _p]),
     "nerfart_gemm_f16_nt": (_i, [_p, _p, _i, _i, _i, _p, _p]),
+    "nerfart_resample_fwd": (_i, [_p] + [_i] * 11 + [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "nerfart_resample_bwd": (_i, [_p] + [_i] * 11 + [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "nerfart_clip_style_heads": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _p, _p, _p]),
 }
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)          # AttributeError here = header / library mismatch
