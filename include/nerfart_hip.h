@@ -244,6 +244,22 @@ int nerfart_clip_style_heads(const float* feats, int n_patches, const float* tex
                              int n_neg, int n_templates, float w_dir, float w_con, float w_nce, float margin, float tau, float* out4,
                              float* g_feats, void* stream);
 
+/* ---- surface renderer (models/ray_casting.py): per-ray stages around the SDF query B3 (the marching and
+ * refinement points are evaluated with nerfart_sdf_fwd_rays).  Masks are uint8 [R].
+ * nerfart_first_crossing: root_finding_surface_points' analysis of the marched values val [R, n_steps] at depths depth [R, n_steps]
+ *   (ray_casting.py:79-126): mask = first sign change of (val - tau) exists & goes outside -> inside & the ray starts outside;
+ *   bracket [R, 4] = (d_low, f_low, d_high, f_high) around it; d_pred = first secant estimate (1 where mask is false).
+ * nerfart_secant_update: one run_secant_method iteration (ray_casting.py:15-29) given f_mid [R] = sdf at the current d_pred.
+ * nerfart_root_finish: depth / point outputs with the reference's fill values (ray_casting.py:137-152): inf (fill_inf) or far where
+ *   nothing was hit, 0 where the ray starts inside, pt = 1 where mask is false.
+ * nerfart_sphere_trace_step: one iteration of sphere_tracing_surface_points (ray_casting.py:175-180). */
+int nerfart_first_crossing(const float* val, const float* depth, int n_rays, int n_steps, float logit_tau, unsigned char* mask,
+                           unsigned char* mask_sign_change, unsigned char* mask_start_outside, float* bracket, float* d_pred, void* stream);
+int nerfart_secant_update(const float* f_mid, int n_rays, float logit_tau, const unsigned char* mask, float* bracket, float* d_pred, void* stream);
+int nerfart_root_finish(const float* rays_o, const float* rays_dn, int n_rays, const unsigned char* mask, const unsigned char* mask_start_outside,
+                        const float* d_pred, const float* far, float far_s, int fill_inf, float* d_out, float* pt_out, void* stream);
+int nerfart_sphere_trace_step(const float* sdf, int n_rays, const float* far, float far_s, float* d, unsigned char* mask, void* stream);
+
 /* The GEMM kernel of the encoder on its own (tests): C[M,N] fp32 = A[M,K] fp16 . W[N,K]^T fp16; M, N, K multiples of 64. */
 int nerfart_gemm_f16_nt(const void* A, const void* W, int M, int N, int K, float* C, void* stream);
 

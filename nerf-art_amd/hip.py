@@ -81,6 +81,10 @@ _SIGS = {
     "nerfart_clip_vitb32_image_fwd": (_i, [_p, _p, _i, _p, _i, _p, _ll, _p]),
     "nerfart_clip_vitb32_image_bwd": (_i, [_p, _i, _p, _p, _p, _ll, _p]),
     "nerfart_gemm_f16_nt": (_i, [_p, _p, _i, _i, _i, _p, _p]),
+    "nerfart_first_crossing": (_i, [_p, _p, _i, _i, _f, _p, _p, _p, _p, _p, _p]),
+    "nerfart_secant_update": (_i, [_p, _i, _f, _p, _p, _p, _p]),
+    "nerfart_root_finish": (_i, [_p, _p, _i, _p, _p, _p, _p, _f, _i, _p, _p, _p]),
+    "nerfart_sphere_trace_step": (_i, [_p, _i, _p, _f, _p, _p, _p]),
     "nerfart_resample_fwd": (_i, [_p] + [_i] * 11 + [_p, _p, _p, _p, _i, _i, _i, _p]),
     "nerfart_resample_bwd": (_i, [_p] + [_i] * 11 + [_p, _p, _p, _p, _i, _i, _i, _p]),
     "nerfart_clip_style_heads": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _p, _p, _p]),

@@ -1,0 +1,57 @@
+"""SDF volume for mesh extraction (reference utils/mesh_util.py:82-112): the N^3 grid sweep of
+`extract_mesh`, a pure consumer of the SDF kernel K2.
+
+`sdf_volume` evaluates `implicit_surface.forward` (no sphere clamp, as :110) on the regular grid over
+[-volume_size / 2, volume_size / 2]^3, x slowest / z fastest, returned as [N, N, N] - the array the reference hands to
+`skimage.measure.marching_cubes` in convert_sigma_samples_to_ply.  Two deliberate differences:
+  * the reference builds grid indices with true division (`(overall_index / N) % N`, inherited from Python-2-era code), which
+    shears the y and x coordinates by up to one voxel, and calls `np.int` (removed from numpy 1.24 - the function no longer
+    runs); the regular grid is evaluated here; `reference_shear=True` reproduces the sheared coordinates;
+  * grid points are generated on the GPU and evaluated in chunks of millions of points (the reference: 16 K).
+`extract_mesh` itself needs skimage (marching cubes) and plyfile, both third-party and absent here: it is provided only if
+they import.
+"""
+import numpy as np
+import torch
+
+
+def grid_points(N: int, volume_size: float, device, start: int = 0, stop: int = None, reference_shear: bool = False):
+    """Points start..stop of the flattened N^3 grid [M, 3] (float32 on `device`)."""
+    stop = N ** 3 if stop is None else stop
+    idx = torch.arange(start, stop, device=device, dtype=torch.int64)
+    step = volume_size / (N - 1)
+    org = -volume_size / 2.0
+    if reference_shear:
+        f = idx.double()
+        iz, iy, ix = f % N, (f / N) % N, ((f / N) / N) % N
+    else:
+        iz, iy, ix = (idx % N).double(), ((idx // N) % N).double(), ((idx // (N * N)) % N).double()
+    return torch.stack([ix * step + org, iy * step + org, iz * step + org], dim=-1).float()
+
+
+@torch.no_grad()
+def sdf_volume(implicit_surface, volume_size: float = 2.0, N: int = 512, chunk: int = 1 << 24, reference_shear: bool = False):
+    """[N, N, N] float32 (on the GPU): sdf at the grid points (mesh_util.py:82-111)."""
+    dev = next(implicit_surface.parameters()).device
+    out = torch.empty(N ** 3, dtype=torch.float32, device=dev)
+    for s in range(0, N ** 3, chunk):
+        e = min(s + chunk, N ** 3)
+        out[s:e] = implicit_surface.forward(grid_points(N, volume_size, dev, s, e, reference_shear))
+    return out.reshape(N, N, N)
+
+
+def extract_mesh(implicit_surface, volume_size=2.0, level=0.0, N=512, filepath="./surface.ply", show_progress=True, chunk=1 << 24):
+    """mesh_util.extract_mesh: SDF volume -> marching cubes -> .ply (needs skimage and plyfile)."""
+    try:
+        from skimage import measure
+        import plyfile
+    except ImportError as e:                                        # pragma: no cover - third-party, absent in this image
+        raise ImportError("extract_mesh needs scikit-image (marching cubes) and plyfile; sdf_volume() returns the SDF grid without them") from e
+    vol = sdf_volume(implicit_surface, volume_size, N, chunk).cpu().numpy()
+    spacing = volume_size / N                                        # the reference passes volume_size / N (not / (N - 1)), mesh_util.py:112
+    verts, faces, _, _ = measure.marching_cubes(vol, level=level, spacing=[spacing] * 3)
+    verts = verts + np.array([-volume_size / 2.0] * 3)
+    v = np.array([tuple(p) for p in verts], dtype=[("x", "f4"), ("y", "f4"), ("z", "f4")])
+    f = np.array([(list(t),) for t in faces], dtype=[("vertex_indices", "i4", (3,))])
+    plyfile.PlyData([plyfile.PlyElement.describe(v, "vertex"), plyfile.PlyElement.describe(f, "face")]).write(filepath)
+    return filepath
