@@ -260,6 +260,21 @@ int nerfart_root_finish(const float* rays_o, const float* rays_dn, int n_rays, c
                         const float* d_pred, const float* far, float far_s, int fill_inf, float* d_out, float* pt_out, void* stream);
 int nerfart_sphere_trace_step(const float* sdf, int n_rays, const float* far, float far_s, float* d, unsigned char* mask, void* stream);
 
+/* ---- VGG16 perceptual term (criteria/perp_loss.py:9-57): torchvision vgg16.features[:16] (through relu3_3) as
+ * implicit-GEMM 3 x 3 convolutions on v_mfma_f32_32x32x16_f16 (csrc/vgg_conv.hip), L1 between prediction and target features.
+ *   blob : nerfart_vgg16_blob_layout() sections (offsets[22] bytes; packed by nerf-art_amd/vgg.py): per conv l = 0..6 forward
+ *          weights, backward (tap-flipped, channel-transposed) weights, bias.
+ *   img2 : [2, 3, H, W] fp32 = the ImageNet-normalised, resized prediction then target (perp_loss.py:41-45); H, W multiples of 4,
+ *          H W / 16 a multiple of 64 (224 x 224 in the reference).
+ * nerfart_vgg16_l1_fwd writes loss_out[0] (device) = mean |relu3_3(pred) - relu3_3(target)|; with keep_for_bwd the workspace
+ * (nerfart_vgg16_workspace_bytes) keeps the activations and nerfart_vgg16_l1_bwd turns upstream[0] (device scalar, NULL = 1)
+ * into g_img [1, 3, H, W] = d loss / d img2[0]. */
+long long nerfart_vgg16_blob_layout(long long* offsets);
+long long nerfart_vgg16_workspace_bytes(int H, int W, int keep_for_bwd);
+int nerfart_vgg16_l1_fwd(const void* blob, const float* img2, int H, int W, float* loss_out, int keep_for_bwd, void* workspace,
+                         long long workspace_bytes, void* stream);
+int nerfart_vgg16_l1_bwd(const void* blob, int H, int W, const float* upstream, float* g_img, void* workspace, long long workspace_bytes, void* stream);
+
 /* The GEMM kernel of the encoder on its own (tests): C[M,N] fp32 = A[M,K] fp16 . W[N,K]^T fp16; M, N, K multiples of 64. */
 int nerfart_gemm_f16_nt(const void* A, const void* W, int M, int N, int K, float* C, void* stream);
 

@@ -23,19 +23,15 @@
 //                        dS = P o (dP - rowsum(P o dP)) / 8, dQ = dS K, dK = dS^T Q, dV = P^T dO - five 64^3 products on MFMA.
 //   k_ln_fwd / k_ln_bwd  one wave per token row (768 = 64 lanes x 3 float4), statistics in fp32; backward recomputes them.
 //   k_patchify / k_unpatchify, k_embed_lnpre / k_lnpre_bwd, k_lnpost / k_lnpost_bwd, k_gscale: the ends of the chain.
-#include "nerfart_common.h"
+#include "gemm_f16.h"
 #include <cmath>
 
 namespace nerfart {
 namespace clip {
 
-typedef _Float16 half_t;
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+using namespace nerfart::gemm16;
 
 constexpr int D = 768, L = 50, NH = 12, HD = 64, DM = 3072, NL = 12, DOUT = 512, NP = 49, PK = 3072, IMG = 224, PS = 32;
-constexpr int LS = 72;                  // LDS row stride of a 64-column fp16 tile, in halfs
 constexpr float LN_EPS = 1e-5f;
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -79,104 +75,6 @@ struct Blob {
     const half_t* h(int i) const { return reinterpret_cast<const half_t*>(base + off[i]); }
     const float* f(int i) const { return reinterpret_cast<const float*>(base + off[i]); }
 };
-
-// ---------------------------------------------------------------------------------------------------------------
-// GEMM
-// ---------------------------------------------------------------------------------------------------------------
-enum { EPI_F32 = 0, EPI_F16 = 1, EPI_BIAS_F16 = 2, EPI_BIAS_RESID_F32 = 3, EPI_BIAS_GELU_F16 = 4, EPI_GELUBWD_F16 = 5 };
-struct Epi {
-    const float* bias;      // [N]
-    const float* resid;     // [M, ldo] fp32 (EPI_BIAS_RESID_F32)
-    float* out_f32;
-    half_t* out_f16;
-    half_t* out2_f16;       // EPI_BIAS_GELU_F16: the activation (out_f16 holds the pre-activation)
-    const half_t* aux_f16;  // EPI_GELUBWD_F16: pre-activation
-    int ldo;                // row stride of every output / aux / resid matrix
-    int m_valid;            // rows >= m_valid are computed (padding) but never stored
-};
-
-__device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
-__device__ __forceinline__ float quick_gelu_grad(float x) {
-    const float s = 1.0f / (1.0f + __expf(-1.702f * x));
-    return s * (1.0f + 1.702f * x * (1.0f - s));
-}
-
-template <int EPI, bool A_F32>
-__global__ __launch_bounds__(256) void k_gemm(const void* __restrict__ Av, int lda, const half_t* __restrict__ W, int K, Epi e) {
-    __shared__ __attribute__((aligned(16))) half_t As[2][64][LS];
-    __shared__ __attribute__((aligned(16))) half_t Bs[2][64][LS];
-    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
-    const int bm = blockIdx.y * 64, bn = blockIdx.x * 64;
-    const int lr = tid >> 2, lc = (tid & 3) * 16;           // this thread stages 16 halfs of row lr at column lc of each tile
-    half8 ra0, ra1, rb0, rb1;
-    auto fetch = [&](int k0) {
-        if constexpr (A_F32) {
-            const float* p = reinterpret_cast<const float*>(Av) + (size_t)(bm + lr) * lda + k0 + lc;
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(p), v1 = *reinterpret_cast<const f32x4*>(p + 4);
-            const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + 8), v3 = *reinterpret_cast<const f32x4*>(p + 12);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ra0[i] = (half_t)v0[i]; ra0[4 + i] = (half_t)v1[i];
-                ra1[i] = (half_t)v2[i]; ra1[4 + i] = (half_t)v3[i];
-            }
-        } else {
-            const half_t* p = reinterpret_cast<const half_t*>(Av) + (size_t)(bm + lr) * lda + k0 + lc;
-            ra0 = *reinterpret_cast<const half8*>(p);
-            ra1 = *reinterpret_cast<const half8*>(p + 8);
-        }
-        const half_t* q = W + (size_t)(bn + lr) * K + k0 + lc;
-        rb0 = *reinterpret_cast<const half8*>(q);
-        rb1 = *reinterpret_cast<const half8*>(q + 8);
-    };
-    auto stage = [&](int buf) {
-        *reinterpret_cast<half8*>(&As[buf][lr][lc]) = ra0;
-        *reinterpret_cast<half8*>(&As[buf][lr][lc + 8]) = ra1;
-        *reinterpret_cast<half8*>(&Bs[buf][lr][lc]) = rb0;
-        *reinterpret_cast<half8*>(&Bs[buf][lr][lc + 8]) = rb1;
-    };
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    const int wm = (w >> 1) * 32, wn = (w & 1) * 32, r = l & 31, h8 = (l >> 5) * 8;
-    const int nk = K / 64;
-    fetch(0);
-    stage(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) fetch((kt + 1) * 64);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const half8 a = *reinterpret_cast<const half8*>(&As[buf][wm + r][16 * s + h8]);
-            const half8 b = *reinterpret_cast<const half8*>(&Bs[buf][wn + r][16 * s + h8]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
-        }
-        if (kt + 1 < nk) stage(buf ^ 1);
-        __syncthreads();
-    }
-    // C layout: lane (col = l & 31, half = l >> 5), reg i -> row (i & 3) + 8 (i >> 2) + 4 half
-    const int col = bn + wn + r;
-    float bias = 0.f;
-    if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_RESID_F32 || EPI == EPI_BIAS_GELU_F16) bias = e.bias[col];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int row = bm + wm + (i & 3) + 8 * (i >> 2) + 4 * (l >> 5);
-        if (row >= e.m_valid) continue;
-        const size_t o = (size_t)row * e.ldo + col;
-        const float v = acc[i] + bias;
-        if constexpr (EPI == EPI_F32) e.out_f32[o] = v;
-        else if constexpr (EPI == EPI_F16 || EPI == EPI_BIAS_F16) e.out_f16[o] = (half_t)v;
-        else if constexpr (EPI == EPI_BIAS_RESID_F32) e.out_f32[o] = e.resid[o] + v;
-        else if constexpr (EPI == EPI_BIAS_GELU_F16) { e.out_f16[o] = (half_t)v; e.out2_f16[o] = (half_t)quick_gelu(v); }
-        else e.out_f16[o] = (half_t)(v * quick_gelu_grad((float)e.aux_f16[o]));
-    }
-}
-
-template <int EPI, bool A_F32>
-static int gemm(hipStream_t st, const void* A, int lda, const half_t* W, int Mp, int N, int K, const Epi& e) {
-    hipLaunchKernelGGL((k_gemm<EPI, A_F32>), dim3(N / 64, Mp / 64), dim3(256), 0, st, A, lda, W, K, e);
-    return check_hip(hipGetLastError(), "k_gemm launch");
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row; lane holds float4 at columns 4 lane + 256 j, j < 3.
@@ -537,7 +435,7 @@ int nerfart_gemm_f16_nt(const void* A, const void* W, int M, int N, int K, float
     if ((M | N | K) & 63) { set_last_error("nerfart_gemm_f16_nt: M, N, K must be multiples of 64"); return 1; }
     Epi e{};
     e.out_f32 = C; e.ldo = N; e.m_valid = M;
-    return gemm<EPI_F32, false>((hipStream_t)stream, A, K, (const half_t*)W, M, N, K, e);
+    return gemm<EPI_F32, A_F16>((hipStream_t)stream, A, K, (const half_t*)W, M, N, K, e);
 }
 
 int nerfart_clip_vitb32_image_fwd(const void* blob, const float* img, int B, float* feat_out, int keep_for_bwd, void* workspace,
@@ -563,7 +461,7 @@ int nerfart_clip_vitb32_image_fwd(const void* blob, const float* img, int B, flo
 
     hipLaunchKernelGGL(k_patchify, dim3(B * NP), dim3(256), 0, st, img, patches, B);
     { Epi e{}; e.out_f32 = pe; e.ldo = D; e.m_valid = B * NP;
-      if (gemm<EPI_F32, false>(st, patches, PK, bl.h(0), w.Pp, D, PK, e)) return 1; }
+      if (gemm<EPI_F32, A_F16>(st, patches, PK, bl.h(0), w.Pp, D, PK, e)) return 1; }
     auto layer_base = [&](int l) { return ws + w.o_saved + (keep_for_bwd ? (long long)l * w.layer_bytes : 0); };
     float* x_alt = (float*)(ws + w.o_saved + w.layer_bytes);     // !keep only: second residual buffer
     float* xin = (float*)(layer_base(0) + w.o_xin);
@@ -577,20 +475,20 @@ int nerfart_clip_vitb32_image_fwd(const void* blob, const float* img, int B, flo
         const int s = 2 + 8 * l, f = 104 + 8 * l;
         hipLaunchKernelGGL(k_ln_fwd, dim3(rows4), dim3(256), 0, st, xin, bl.f(f + 0), bl.f(f + 1), y, M);
         { Epi e{}; e.bias = bl.f(f + 2); e.out_f16 = qkv; e.ldo = 3 * D; e.m_valid = M;
-          if (gemm<EPI_BIAS_F16, false>(st, y, D, bl.h(s + 0), Mp, 3 * D, D, e)) return 1; }
+          if (gemm<EPI_BIAS_F16, A_F16>(st, y, D, bl.h(s + 0), Mp, 3 * D, D, e)) return 1; }
         hipLaunchKernelGGL(k_attn_fwd, dim3(B * NH), dim3(256), 0, st, qkv, att);
         { Epi e{}; e.bias = bl.f(f + 3); e.resid = xin; e.out_f32 = xmid; e.ldo = D; e.m_valid = M;
-          if (gemm<EPI_BIAS_RESID_F32, false>(st, att, D, bl.h(s + 2), Mp, D, D, e)) return 1; }
+          if (gemm<EPI_BIAS_RESID_F32, A_F16>(st, att, D, bl.h(s + 2), Mp, D, D, e)) return 1; }
         hipLaunchKernelGGL(k_ln_fwd, dim3(rows4), dim3(256), 0, st, xmid, bl.f(f + 4), bl.f(f + 5), y, M);
         { Epi e{}; e.bias = bl.f(f + 6); e.out_f16 = pre; e.out2_f16 = act; e.ldo = DM; e.m_valid = M;
-          if (gemm<EPI_BIAS_GELU_F16, false>(st, y, D, bl.h(s + 4), Mp, DM, D, e)) return 1; }
+          if (gemm<EPI_BIAS_GELU_F16, A_F16>(st, y, D, bl.h(s + 4), Mp, DM, D, e)) return 1; }
         { Epi e{}; e.bias = bl.f(f + 7); e.resid = xmid; e.out_f32 = xnext; e.ldo = D; e.m_valid = M;
-          if (gemm<EPI_BIAS_RESID_F32, false>(st, act, DM, bl.h(s + 6), Mp, D, DM, e)) return 1; }
+          if (gemm<EPI_BIAS_RESID_F32, A_F16>(st, act, DM, bl.h(s + 6), Mp, D, DM, e)) return 1; }
         xin = xnext;
     }
     hipLaunchKernelGGL(k_lnpost, dim3((B + 3) / 4), dim3(256), 0, st, xfin, bl.f(200), bl.f(201), x0, B);
     { Epi e{}; e.out_f32 = feat_out; e.ldo = DOUT; e.m_valid = B;
-      if (gemm<EPI_F32, false>(st, x0, D, bl.h(98), w.Bp, DOUT, D, e)) return 1; }
+      if (gemm<EPI_F32, A_F16>(st, x0, D, bl.h(98), w.Bp, DOUT, D, e)) return 1; }
     NERFART_HIP(hipGetLastError());
     return 0;
 }
@@ -627,7 +525,7 @@ int nerfart_clip_vitb32_image_bwd(const void* blob, int B, const float* g_feat, 
     NERFART_HIP(hipMemsetAsync(dqkv, 0, (size_t)2 * Mp * 3 * D, st));
     hipLaunchKernelGGL(k_gscale, dim3(1), dim3(1024), 0, st, g_feat, B * DOUT, scale, g16);
     { Epi e{}; e.out_f32 = t0; e.ldo = D; e.m_valid = B;
-      if (gemm<EPI_F32, false>(st, g16, DOUT, bl.h(99), w.Bp, D, DOUT, e)) return 1; }
+      if (gemm<EPI_F32, A_F16>(st, g16, DOUT, bl.h(99), w.Bp, D, DOUT, e)) return 1; }
     hipLaunchKernelGGL(k_lnpost_bwd, dim3((B + 3) / 4), dim3(256), 0, st, t0, xfin, bl.f(200), dx, B);
     for (int l = NL - 1; l >= 0; --l) {
         char* lb = ws + w.o_saved + (long long)l * w.layer_bytes;
@@ -638,22 +536,22 @@ int nerfart_clip_vitb32_image_bwd(const void* blob, int B, const float* g_feat, 
         const int s = 2 + 8 * l, f = 104 + 8 * l;
         // MLP branch: d act = dx W2 -> x gelu'(pre) -> d ln_2 out = . W1 -> dx += LN'
         { Epi e{}; e.out_f16 = act; e.aux_f16 = pre; e.ldo = DM; e.m_valid = M;
-          if (gemm<EPI_GELUBWD_F16, true>(st, dx, D, bl.h(s + 7), Mp, DM, D, e)) return 1; }
+          if (gemm<EPI_GELUBWD_F16, A_F32>(st, dx, D, bl.h(s + 7), Mp, DM, D, e)) return 1; }
         { Epi e{}; e.out_f32 = t; e.ldo = D; e.m_valid = M;
-          if (gemm<EPI_F32, false>(st, act, DM, bl.h(s + 5), Mp, D, DM, e)) return 1; }
+          if (gemm<EPI_F32, A_F16>(st, act, DM, bl.h(s + 5), Mp, D, DM, e)) return 1; }
         hipLaunchKernelGGL(k_ln_bwd, dim3(rows4), dim3(256), 0, st, t, xmid, bl.f(f + 4), dx, M);
         // attention branch: d attn = dx Wo -> attention backward -> d ln_1 out = dqkv Wqkv -> dx += LN'
         { Epi e{}; e.out_f16 = att; e.ldo = D; e.m_valid = M;
-          if (gemm<EPI_F16, true>(st, dx, D, bl.h(s + 3), Mp, D, D, e)) return 1; }
+          if (gemm<EPI_F16, A_F32>(st, dx, D, bl.h(s + 3), Mp, D, D, e)) return 1; }
         hipLaunchKernelGGL(k_attn_bwd, dim3(B * NH), dim3(256), ATTN_BWD_LDS, st, qkv, att, dqkv);
         { Epi e{}; e.out_f32 = t; e.ldo = D; e.m_valid = M;
-          if (gemm<EPI_F32, false>(st, dqkv, 3 * D, bl.h(s + 1), Mp, D, 3 * D, e)) return 1; }
+          if (gemm<EPI_F32, A_F16>(st, dqkv, 3 * D, bl.h(s + 1), Mp, D, 3 * D, e)) return 1; }
         hipLaunchKernelGGL(k_ln_bwd, dim3(rows4), dim3(256), 0, st, t, xin, bl.f(f + 0), dx, M);
     }
     NERFART_HIP(hipMemsetAsync(y, 0, (size_t)2 * Mp * D, st));
     hipLaunchKernelGGL(k_lnpre_bwd, dim3(rows4), dim3(256), 0, st, dx, xemb, bl.f(102), y, M);
     { Epi e{}; e.out_f32 = dpatch; e.ldo = PK; e.m_valid = B * NP;
-      if (gemm<EPI_F32, false>(st, y, D, bl.h(1), w.Pp, PK, D, e)) return 1; }
+      if (gemm<EPI_F32, A_F16>(st, y, D, bl.h(1), w.Pp, PK, D, e)) return 1; }
     hipLaunchKernelGGL(k_unpatchify, dim3(B * NP), dim3(256), 0, st, dpatch, scale, g_img, B);
     NERFART_HIP(hipGetLastError());
     return 0;

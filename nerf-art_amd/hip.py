@@ -81,6 +81,10 @@ _SIGS = {
     "nerfart_clip_vitb32_image_fwd": (_i, [_p, _p, _i, _p, _i, _p, _ll, _p]),
     "nerfart_clip_vitb32_image_bwd": (_i, [_p, _i, _p, _p, _p, _ll, _p]),
     "nerfart_gemm_f16_nt": (_i, [_p, _p, _i, _i, _i, _p, _p]),
+    "nerfart_vgg16_blob_layout": (_ll, [_p]),
+    "nerfart_vgg16_workspace_bytes": (_ll, [_i, _i, _i]),
+    "nerfart_vgg16_l1_fwd": (_i, [_p, _p, _i, _i, _p, _i, _p, _ll, _p]),
+    "nerfart_vgg16_l1_bwd": (_i, [_p, _i, _i, _p, _p, _p, _ll, _p]),
     "nerfart_first_crossing": (_i, [_p, _p, _i, _i, _f, _p, _p, _p, _p, _p, _p]),
     "nerfart_secant_update": (_i, [_p, _i, _f, _p, _p, _p, _p]),
     "nerfart_root_finish": (_i, [_p, _p, _i, _p, _p, _p, _p, _f, _i, _p, _p, _p]),

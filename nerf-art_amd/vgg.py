@@ -4,9 +4,10 @@
 The reference runs torchvision's `vgg16(pretrained=True).features` in four slices ([:4], [4:9], [9:16], [16:23]) on the
 ImageNet-normalised, bilinearly 224 x 224-resized prediction and target and takes the L1 distance of the THIRD slice's
 output only (relu3_3; `if i == 2`, perp_loss.py:51) - the fourth slice is computed and dropped, so it is not built here.
-The seven 3 x 3 convolutions are im2col (`F.unfold`) + one library GEMM each: the GEMM formulation never goes through
-MIOpen, whose first use of a new convolution shape compiles kernels for minutes on a fresh GPU box.  Prediction and
-target go through the net as one batch of two.
+On the GPU the conv stack, the L1 and the backward pass to the prediction's pixels run on the hand-written kernels of
+csrc/vgg_conv.hip (implicit-GEMM convolutions on the fp16 matrix cores behind `nerfart_vgg16_l1_fwd / _bwd`); the ImageNet
+normalisation + bilinear resize in front is one `nerfart_resample_fwd` gather.  The torch formulation below (im2col via
+`F.unfold` + matmul, prediction and target as one batch of two) is the CPU path the tests compare against.
 
 Weights: pass torchvision's `vgg16` state dict (`features.N.weight / bias`; N = 0, 2, 5, 7, 10, 12, 14 are read).  No
 ImageNet checkpoint exists offline, so PARITY IS UNPINNED against the pretrained network; the default is torchvision's
@@ -68,9 +69,50 @@ class VGGPerceptualLoss(nn.Module):
         self.register_buffer("std", torch.tensor(IMAGENET_STD).view(1, 3, 1, 1))
         self.resize = resize
 
+    # ---- hand-written path (GPU) ------------------------------------------------------------------------------
+    def packed(self):
+        """The conv weights as the kernels read them (section order of csrc/vgg_conv.hip), re-packed when they change."""
+        import ctypes as C
+        from . import hip
+        key = tuple((p.data_ptr(), p._version) for p in self.net.parameters())
+        if getattr(self, "_blob_key", None) != key:
+            offs = (C.c_longlong * 22)()
+            total = hip.lib.nerfart_vgg16_blob_layout(C.cast(offs, C.c_void_p))
+            dev = self.mean.device
+            blob = torch.zeros(total, dtype=torch.uint8, device=dev)
+
+            def put(i, t, dtype):
+                t = t.detach().to(dev).to(dtype).contiguous().reshape(-1)
+                blob[offs[i]: offs[i] + t.numel() * t.element_size()] = t.view(torch.uint8)
+            for l, (idx, cin, cout, _) in enumerate(_CONVS):
+                w, b = self.net.features[str(idx)].weight.detach().float(), self.net.features[str(idx)].bias
+                if l == 0:
+                    wf = torch.zeros(64, 64)
+                    wf[:, :27] = w.reshape(64, 27).cpu()                      # column c 9 + ky 3 + kx
+                    put(0, wf, torch.float16)
+                    put(1, wf.t(), torch.float16)                             # row k = W[:, k]
+                else:
+                    put(3 * l, w.permute(0, 2, 3, 1).reshape(cout, 9 * cin), torch.float16)                       # (ky, kx, c)
+                    put(3 * l + 1, w.flip(2, 3).permute(1, 2, 3, 0).reshape(cin, 9 * cout), torch.float16)        # W[o, c, 2-ky', 2-kx']
+                put(3 * l + 2, b, torch.float32)
+            self._blob, self._blob_key = blob, key
+        return self._blob
+
+    def _native(self, input, target):
+        from . import style_native as sn
+        dev = input.device
+        a = torch.stack([1.0 / self.std.reshape(3), -self.mean.reshape(3) / self.std.reshape(3)]).float().contiguous().to(dev)
+        H, W = (224, 224) if self.resize else input.shape[-2:]
+        x = sn.resample(input, (H, W), mode="bilinear", affine=a)              # (x - mean) / std commutes with the interpolation
+        with torch.no_grad():
+            y = sn.resample(target.to(input.dtype), (H, W), mode="bilinear", affine=a)
+        return _VGGL1.apply(x, y, self.packed())
+
     def forward(self, input, target):
         if input.shape[1] != 3:
             input, target = input.repeat(1, 3, 1, 1), target.repeat(1, 3, 1, 1)
+        if input.is_cuda and input.shape[0] == 1 and getattr(self, "native", True):
+            return self._native(input, target)
         xy = torch.cat([input, target.to(input.dtype)], dim=0)
         xy = (xy - self.mean) / self.std
         if self.resize:
@@ -78,3 +120,42 @@ class VGGPerceptualLoss(nn.Module):
         f = self.net(xy)
         n = input.shape[0]
         return F.l1_loss(f[:n], f[n:])
+
+
+class _VGGL1(torch.autograd.Function):
+    """mean |relu3_3(x) - relu3_3(y)| on the hand-written kernels; gradient w.r.t. x (the prediction) only."""
+
+    @staticmethod
+    def forward(ctx, x, y, blob):
+        import ctypes as C
+        from . import hip
+        H, W = x.shape[-2:]
+        img2 = torch.cat([x.detach(), y.detach()], dim=0).float().contiguous()
+        keep = bool(ctx.needs_input_grad[0])
+        nbytes = hip.lib.nerfart_vgg16_workspace_bytes(H, W, int(keep))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rc = hip.lib.nerfart_vgg16_l1_fwd(C.c_void_p(blob.data_ptr()), C.c_void_p(img2.data_ptr()), H, W, C.c_void_p(loss.data_ptr()), int(keep),
+                                          C.c_void_p(ws.data_ptr()), nbytes, st)
+        if rc != 0:
+            raise RuntimeError("nerfart_vgg16_l1_fwd: " + hip.lib.nerfart_last_error().decode())
+        ctx.keep, ctx.ws, ctx.blob, ctx.hw, ctx.dtype = keep, ws if keep else None, blob, (H, W), x.dtype
+        return loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes as C
+        from . import hip
+        if not ctx.keep:
+            return None, None, None
+        H, W = ctx.hw
+        up = g.detach().float().reshape(1).contiguous()
+        gi = torch.empty(1, 3, H, W, dtype=torch.float32, device=up.device)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rc = hip.lib.nerfart_vgg16_l1_bwd(C.c_void_p(ctx.blob.data_ptr()), H, W, C.c_void_p(up.data_ptr()), C.c_void_p(gi.data_ptr()),
+                                          C.c_void_p(ctx.ws.data_ptr()), ctx.ws.numel(), st)
+        if rc != 0:
+            raise RuntimeError("nerfart_vgg16_l1_bwd: " + hip.lib.nerfart_last_error().decode())
+        ctx.ws = None
+        return gi.to(ctx.dtype), None, None

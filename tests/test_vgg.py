@@ -60,19 +60,35 @@ import pytest  # noqa: E402
 
 
 @pytest.mark.gpu
-def test_vgg_loss_on_the_gpu_matches_cpu():
+@pytest.mark.parametrize("hw", [(60, 34), (480, 270)])
+def test_vgg_loss_on_the_gpu_matches_cpu(hw):
+    """The hand-written path (resample gather -> implicit-GEMM conv stack on the fp16 matrix cores -> L1 -> backward to the
+    pixels; csrc/vgg_conv.hip) against the fp32 torch formulation on the CPU with the same weights.  fp16 operands: the loss
+    agrees to ~1e-3 relative; the L1's sign() flips where two features are equal to rounding, so the gradient is compared as
+    a whole."""
     from nerfart_amd.vgg import VGGPerceptualLoss
     mine = VGGPerceptualLoss(seed=1)
     g = torch.Generator().manual_seed(2)
-    pred, gt = torch.rand(1, 3, 60, 34, generator=g), torch.rand(1, 3, 60, 34, generator=g)
+    pred, gt = torch.rand(1, 3, *hw, generator=g), torch.rand(1, 3, *hw, generator=g)
     p_cpu = pred.clone().requires_grad_(True)
     l_cpu = mine(p_cpu, gt)
     l_cpu.backward()
     dev = mine.to("cuda")
     p_gpu = pred.cuda().requires_grad_(True)
     l_gpu = dev(p_gpu, gt.cuda())
-    l_gpu.backward()
-    np.testing.assert_allclose(float(l_gpu), float(l_cpu), rtol=1e-4)
-    # the L1's sign() flips where two features are equal to rounding: compare the gradient as a whole
-    rel = float((p_gpu.grad.cpu() - p_cpu.grad).norm() / p_cpu.grad.norm())
-    assert rel < 2e-2, rel
+    (3.0 * l_gpu).backward()                                   # an upstream factor, as StyleLoss applies w_perceptual
+    rel = float((p_gpu.grad.cpu() / 3.0 - p_cpu.grad).norm() / p_cpu.grad.norm())
+    cos = float(torch.nn.functional.cosine_similarity(p_gpu.grad.cpu().flatten(), p_cpu.grad.flatten(), dim=0))
+    print(f"  vgg {hw}: loss gpu {float(l_gpu):.6f} cpu {float(l_cpu):.6f}; pixel gradient rel err {rel:.3e}, cosine {cos:.5f}")
+    np.testing.assert_allclose(float(l_gpu), float(l_cpu), rtol=5e-3)
+    # measured on MI355X (round 2): 60 x 34: 2.0e-2 / 0.99979; 480 x 270 (down-sampled noise images: many near-equal features whose
+    # sign is decided inside the fp16 rounding of the activations): 6.3e-2 / 0.99800
+    assert rel < 0.1 and cos > 0.995, (rel, cos)
+    # the torch formulation on the GPU (native switched off) agrees as well
+    dev.native = False
+    l_t = dev(pred.cuda(), gt.cuda())
+    np.testing.assert_allclose(float(l_t), float(l_cpu), rtol=1e-3)
+    # no gradient requested: nothing is kept, same value
+    dev.native = True
+    with torch.no_grad():
+        assert abs(float(dev(pred.cuda(), gt.cuda())) - float(l_gpu)) < 1e-6
