@@ -245,7 +245,8 @@ using namespace nerfart;
 
 namespace nerfart {
 // Entry points used by mlp_chain.hip's dispatchers when precision = 1 (split bf16).
-int sdf_bf16(const float* blob, const PointSrc& s, float R_bg, float* out, int out_stride, hipStream_t st) {
+// the 8-wave K2 (the default; NERFART_K2=w32 selects the one-wave-per-SIMD kernel of mlp_k2_w32.hip)
+int sdf_bf16_v1(const float* blob, const PointSrc& s, float R_bg, float* out, int out_stride, hipStream_t st) {
     return b16::launch_chain(0, (long long)s.M, b16::k_sdf_only_bf16, (s.M + 127u) / 128u, st, blob, s, R_bg, out, out_stride);
 }
 int sdf_nabla_bf16(const float* blob, const PointSrc& s, float R_bg, float* sdf, float* nabla, float* h7, hipStream_t st) {

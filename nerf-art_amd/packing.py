@@ -399,6 +399,56 @@ def _kstep_mul_index(flat, name, row, ks, kfeat_fn, ntiles=16):
     return idx.reshape(-1)
 
 
+# ---- one-wave-per-SIMD K2 (csrc/mlp_k2_w32.hip): v_mfma_f32_32x32x16_bf16 layouts ---------------------------------------------
+# A: lane l holds 8 k-slots of row l & 31 (half h = l >> 5: slots of k-step sub-block h); B: lane (col = l & 31, h) holds 8
+# k-slots of its column; C: reg r of tile T <-> row 32 T + 8 (r >> 2) + 4 h + (r & 3).  The 16 registers of output tile T become
+# units (16-deep k-steps) 2 T (regs 0..7) and 2 T + 1 (regs 8..15) of the next layer.
+W32_CHUNK_KS = 4          # 16-deep k-steps per 64 KiB chunk: 4 x 8 output tiles x (hi, lo) x 1 KiB
+
+
+def w32_feature_hidden(ks: int, h: int, e: int) -> int:
+    return 16 * ks + 8 * (e >> 2) + 4 * h + (e & 3)
+
+
+def w32_feature_enc(q: int, h: int, e: int) -> int:
+    """Slot (unit q < 3, half h, element e) of the 3 positional-encoding units -> reference feature (0..38) or -1.  Half 0 holds
+    x, y, z and the (sin, cos) pairs of bands k = 0..2, half 1 the pairs of bands k = 3..5: a lane evaluates 9 sincos."""
+    m = 8 * q + e
+    if h == 0:
+        if m < 3:
+            return m
+        m -= 3
+    if m >= 18:
+        return -1
+    kc, is_cos = divmod(m, 2)
+    k, c = divmod(kc, 3)
+    return 3 + 6 * (k + 3 * h) + 3 * is_cos + c
+
+
+def _item_index_w32(flat, name, out_dim, T, ks, cols_fn):
+    """Index array [lane=64][e=8] of item (output tile T of 32 rows, k-step ks): W[32 T + (lane & 31)][cols_fn(ks, lane >> 5, e)]."""
+    R, C = flat.shape[name]
+    idx = np.full((64, 8), flat.zero, dtype=np.int64)
+    lane = np.arange(64)
+    rows = 32 * T + (lane & 31)
+    for h in range(2):
+        sel = (rows < out_dim) & ((lane >> 5) == h)
+        for e in range(8):
+            c = cols_fn(ks, h, e)
+            if c >= 0:
+                idx[sel, e] = flat.base[name] + rows[sel] * C + c
+    return idx.reshape(-1)
+
+
+def _layer_chunks_w32(flat, name, out_dim, cols_fn, nks):
+    """k-step-major chunks of W32_CHUNK_KS k-steps; inside a chunk item = k-step-in-chunk * 8 + output tile."""
+    chunks = []
+    for c0 in range(0, nks, W32_CHUNK_KS):
+        chunks.append(np.concatenate([_item_index_w32(flat, name, out_dim, T, ks, cols_fn)
+                                      for ks in range(c0, min(c0 + W32_CHUNK_KS, nks)) for T in range(8)]))
+    return chunks
+
+
 D_UNORM = 65535.0         # softplus'(z) in [0, 1] is handed from the forward to the backward sweep as unorm16
 GRAD_ENC_ROW0 = 217       # rows 217..255 of the backward outputs of layers 4 and 0 carry d sdf / d enc[0..38]
 
@@ -475,8 +525,31 @@ def surface_plan_bf16(W: int = 256, D: int = 8, skips=(4,), multires: int = 6, W
         mul.append(None)
         scl.append(1.0 / D_UNORM)
     table2 = list(range(nc_grad, nc_grad + 4)) + list(range(nc_fwd + 4, nc_fwd + 4 + 24))      # B7', then B6..B1
+    # ---- fourth program: the forward layers again in the 32x32x16 fragment layout of the one-wave-per-SIMD K2 (mlp_k2_w32.hip)
+    w32_first = len(chunks)
+    for l in range(D):
+        out_dim, in_dim = dims[l]
+        if l == 0:
+            w32 = _layer_chunks_w32(flat, f"w{l}", out_dim, w32_feature_enc, 3)
+        elif l in skips:
+            def fn(ks, h, e, hw=hw):
+                if ks < 14:
+                    f = w32_feature_hidden(ks, h, e)
+                    return f if f < hw else -1
+                f = w32_feature_enc(ks - 14, h, e)
+                return hw + f if f >= 0 else -1
+            w32 = _layer_chunks_w32(flat, f"w{l}", out_dim, fn, 17)
+        else:
+            def fn(ks, h, e, in_dim=in_dim):
+                f = w32_feature_hidden(ks, h, e)
+                return f if f < in_dim else -1
+            w32 = _layer_chunks_w32(flat, f"w{l}", out_dim, fn, 16)
+        chunks += w32
+        mul += [None] * len(w32)
+        scl += [1.0] * len(w32)
     plan = PackPlanBF16(PROG_SURFACE_BF16, flat, chunks, aux, chunk_mul=mul, chunk_scale=scl, nc_main=nc_fwd, nc_cycle=nc_grad,
                         table2=table2)
+    plan.header[8], plan.header[9] = len(chunks) - w32_first, w32_first      # the w32 program: chunk count, first chunk
     # cat[h, enc] / sqrt(2) (base.py:250) is applied to the skip layer's weights instead of its inputs
     plan.scale = {f"w{l}": 1.0 / float(np.sqrt(2.0)) for l in skips}
     return plan

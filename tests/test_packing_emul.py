@@ -89,7 +89,7 @@ def _blobs_bf16(fw):
 
 def test_bf16_blob_header():
     _, surf, rad, _ = _blobs_bf16("VolSDF")
-    for blob, nc, nc_all, n_chunks in ((surf, 30, 59, 63), (rad, 21, 42, 42)):
+    for blob, nc, nc_all, n_chunks in ((surf, 30, 59, 93), (rad, 21, 42, 42)):          # surface: 63 chunks + the 30 of the w32 program
         hdr = blob[:512].view(np.int32)
         assert hdr[0] == packing.MAGIC and hdr[2] == nc and hdr[6] == nc_all and hdr[3] == blob.size
         offs = hdr[16:16 + n_chunks + 1]
@@ -189,3 +189,100 @@ def test_emulated_bf16_radiance_backward_matches_autograd(fw):
     sc = float(h7g.grad.abs().max())
     np.testing.assert_allclose(g_h7, h7g.grad.numpy(), atol=2e-4 * sc, rtol=2e-3)
     np.testing.assert_allclose(g_n, nabg.grad.numpy(), atol=2e-4 * float(nabg.grad.abs().max()), rtol=2e-3)
+
+
+# ---- the one-wave-per-SIMD K2 program (csrc/mlp_k2_w32.hip): v_mfma_f32_32x32x16_bf16 register path -------------------------
+def _w32_frag_to_A(frag):
+    """fragment [lane 64][e 8] -> A [32 rows][16 k]: lane l holds row l & 31, k = 8 (l >> 5) + e."""
+    A = np.zeros((32, 16))
+    for l in range(64):
+        A[l & 31, 8 * (l >> 5): 8 * (l >> 5) + 8] = frag[l]
+    return A
+
+
+def _w32_unit_to_B(unit):
+    """unit [lane 64][e 8] -> B [16 k][32 cols]: lane l holds column l & 31, k = 8 (l >> 5) + e."""
+    B = np.zeros((16, 32))
+    for l in range(64):
+        B[8 * (l >> 5): 8 * (l >> 5) + 8, l & 31] = unit[l]
+    return B
+
+
+def _w32_C_to_regs(C):
+    """C [32 rows][32 cols] -> [lane 64][reg 16]: lane (col = l & 31, h = l >> 5), reg r <-> row (r & 3) + 8 (r >> 2) + 4 h."""
+    out = np.zeros((64, 16))
+    for l in range(64):
+        for r in range(16):
+            out[l, r] = C[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5), l & 31]
+    return out
+
+
+def test_w32_program_register_path_matches_oracle():
+    """Walks the fourth program of the split-bf16 surface blob exactly as mlp_k2_w32.hip does - fragments -> 32x32x16 MFMAs ->
+    C registers -> (softplus) -> the next layer's B units straight from the registers - for one wave (32 columns)."""
+    sd, _ = scene_state("VolSDF", 0.01)
+    plan = packing.surface_plan_bf16()
+    blob = plan.pack(packing.surface_tensors(sd))
+    hdr = blob[:512].view(torch.int32).numpy()
+    nc, first = int(hdr[8]), int(hdr[9])
+    assert nc == 30 and first == 63
+    offs = hdr[16 + first: 16 + first + nc + 1]
+    aux = blob[hdr[4]: hdr[4] + hdr[5]].double().numpy()
+    chunks = []
+    for c in range(nc):
+        body = blob[offs[c]: offs[c + 1]].view(torch.bfloat16).double().reshape(-1, 2, 64, 8)      # [item][term][lane][e]
+        chunks.append((body[:, 0] + body[:, 1]).numpy())
+    g = torch.Generator().manual_seed(9)
+    pts = torch.rand(32, 3, generator=g) * 4 - 2
+    pts[:6] *= 0.3
+    x = pts.double().numpy()
+    # encoding units as the kernel builds them: lane (col, h), slot (q, e) -> feature w32_feature_enc(q, h, e)
+    e39 = nets.embed(pts, 6).double().numpy()
+    enc = np.zeros((3, 64, 8))
+    for q in range(3):
+        for l in range(64):
+            for e in range(8):
+                f = packing.w32_feature_enc(q, l >> 5, e)
+                enc[q, l, e] = e39[l & 31, f] if f >= 0 else 0.0
+    softplus = lambda z: np.maximum(z, 0) + np.log1p(np.exp(-np.abs(100 * z))) / 100
+
+    def bias_regs(l):
+        b = aux[256 * l: 256 * l + 256]
+        out = np.zeros((8, 64, 16))
+        for T in range(8):
+            for ln in range(64):
+                for r in range(16):
+                    out[T, ln, r] = b[32 * T + 8 * (r >> 2) + 4 * (ln >> 5) + (r & 3)]
+        return out
+    layer_ks = [3, 16, 16, 16, 17, 16, 16, 16]
+    ci, P = 0, None
+    for l in range(8):
+        nks = layer_ks[l]
+        nh = 0 if l == 0 else (14 if l == 4 else 16)
+        Q = bias_regs(l)
+        items = np.concatenate([chunks[ci + c] for c in range((nks + 3) // 4)])
+        ci += (nks + 3) // 4
+        assert items.shape[0] == nks * 8
+        for ks in range(nks):
+            if ks < nh:                                  # unit ks = softplus of regs 8 (ks & 1) .. of tile ks >> 1 of the previous layer
+                unit = softplus(P[ks >> 1][:, 8 * (ks & 1): 8 * (ks & 1) + 8])
+            else:
+                unit = enc[ks - nh]
+            B = _w32_unit_to_B(unit)
+            for T in range(8):
+                it = (ks % 4) * 8 + T + (ks // 4) * 32
+                Q[T] += _w32_C_to_regs(_w32_frag_to_A(items[it]) @ B)
+        P = Q
+    row = aux[packing.SURF_AUX_ROW: packing.SURF_AUX_ROW + 256]
+    sdf = np.zeros(32)
+    for T in range(8):
+        for ln in range(64):
+            for r in range(16):
+                sdf[ln & 31] += softplus(P[T][ln, r]) * row[32 * T + 8 * (r >> 2) + 4 * (ln >> 5) + (r & 3)]
+    sdf += aux[packing.SURF_AUX_B8]
+    ref = nets.surface_forward(sd, pts)[0].double().numpy()
+    np.testing.assert_allclose(sdf, ref, atol=3e-5, rtol=1e-4)
+    # the slot maps are bijections onto the features
+    feats = sorted(packing.w32_feature_enc(q, h, e) for q in range(3) for h in range(2) for e in range(8))
+    assert [f for f in feats if f >= 0] == list(range(39))
+    assert sorted(packing.w32_feature_hidden(ks, h, e) for ks in range(16) for h in range(2) for e in range(8)) == list(range(256))
