@@ -9,7 +9,8 @@
 //                           Backward scatters the cotangent with fp32 atomics.
 //   k_clip_style_heads      directional CLIP loss (clip_loss.py:244-254), global contrastive loss (contrastive_loss.py:146-153)
 //                           and the PatchNCE terms (patchnce_loss.py:153-173) from the 4 + P image features and the cached
-//                           text features, value AND gradient w.r.t. the image features in one launch (fp32).
+//                           text features, value AND gradient w.r.t. the image features in one launch (fp32), one workgroup
+//                           per head / per crop.
 #include "nerfart_common.h"
 #include <cmath>
 
@@ -143,37 +144,46 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return s;
 }
 
-// n values per thread summed over the workgroup at once (one barrier pair for all of them); v[k] <- total
-__device__ __forceinline__ void block_sum_vec(float* v, int n, float* redv) {
-    for (int k = 0; k < n; ++k) {
+// n <= NMAX values per thread summed over the workgroup at once (one barrier pair for all of them); v[k] <- total.  The loops run
+// to the compile-time NMAX with a predicate so that v[] stays in registers.
+template <int NMAX>
+__device__ __forceinline__ void block_sum_vec(float (&v)[NMAX], int n, float* redv) {
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
         float x = v[k];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
         v[k] = x;
     }
     __syncthreads();
-    if ((threadIdx.x & 63) == 0)
-        for (int k = 0; k < n; ++k) redv[k * (HT / 64) + (threadIdx.x >> 6)] = v[k];
-    __syncthreads();
-    for (int k = 0; k < n; ++k) {
-        float s = 0.f;
+    if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int i = 0; i < HT / 64; ++i) s += redv[k * (HT / 64) + i];
-        v[k] = s;
+        for (int k = 0; k < NMAX; ++k) if (k < n) redv[k * (HT / 64) + (threadIdx.x >> 6)] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+        float sum = 0.f;
+        if (k < n) {
+#pragma unroll
+            for (int i = 0; i < HT / 64; ++i) sum += redv[k * (HT / 64) + i];
+        }
+        v[k] = sum;
     }
 }
 
 // feats [4 + P, 512]: 0 directional prediction, 1 directional source (no gradient), 2 contrastive prediction, 3 contrastive
 // source (no gradient), 4.. the P PatchNCE crops.  text_dir [512] (unit), t_tgt / t_con [T, 512] (unit rows: templates of the
 // target prompt / of the contrastive head's negative prompt), t_neg [S, T, 512] (the PatchNCE negative prompts).
-// out[0..3] = total, directional, contrastive, patchnce (unweighted parts); g_feats [4 + P, 512] = d total / d feats.
+// out[0..3] += total, directional, contrastive, patchnce (unweighted parts; zeroed by the caller); g_feats [4 + P, 512] =
+// d total / d feats.  One workgroup per head / per PatchNCE crop: block 0 directional, 1 contrastive, 2 + p crop p.
 __global__ __launch_bounds__(HT) void k_clip_style_heads(const float* __restrict__ feats, int P, const float* __restrict__ text_dir,
                                                         const float* __restrict__ t_tgt, const float* __restrict__ t_con,
                                                         const float* __restrict__ t_neg, int S, int T, float w_dir, float w_con,
                                                         float w_nce, float margin, float tau, float* __restrict__ out,
                                                         float* __restrict__ g_feats) {
     __shared__ float red[HT / 64];
-    __shared__ float redv[(1 + MAXS) * (HT / 64)];
+    __shared__ float redv[2 * (1 + MAXS) * (HT / 64)];
     const int j = threadIdx.x;
     const float eps_cos = 1e-8f, eps_pd = 1e-6f;
     auto unit = [&](int row, float& fh, float& nrm) {          // f / |f| (criteria: f / f.norm(dim=-1, keepdim=True))
@@ -184,32 +194,31 @@ __global__ __launch_bounds__(HT) void k_clip_style_heads(const float* __restrict
     // d L / d f from d L / d fhat:  (g - fhat (fhat . g)) / |f|
     auto unit_bwd = [&](float g, float fh, float nrm) { return (g - fh * block_sum(g * fh, red)) / nrm; };
 
-    // ---- directional: 1 - cos(normalize(fhat0 - fhat1), dir)
-    float f0, n0, f1, n1;
-    unit(0, f0, n0);
-    unit(1, f1, n1);
-    const float e = f0 - f1;
-    const float en = sqrtf(block_sum(e * e, red));
-    const float eh = e / en;
-    const float d = text_dir[j];
-    const float dn = sqrtf(block_sum(d * d, red));
-    const float ehn = sqrtf(block_sum(eh * eh, red));
-    const float dot = block_sum(eh * d, red);
-    const float den = fmaxf(ehn, eps_cos) * fmaxf(dn, eps_cos);
-    const float L_dir = 1.f - dot / den;
-    // d cos / d eh = d / den - cos * eh / ehn^2 (ehn > eps)
-    const float cosv = dot / den;
-    float g_eh = -(d / den - cosv * eh / fmaxf(ehn * ehn, eps_cos * eps_cos));
-    const float g_e = (g_eh - eh * block_sum(g_eh * eh, red)) / en;
-    g_feats[0 * FD + j] = w_dir * unit_bwd(g_e, f0, n0);
-    g_feats[1 * FD + j] = 0.f;
-
-    // ---- global contrastive: mean_t(near_t^2 + relu(m - far_text_t)^2 + relu(m - far_img)^2), pairwise_distance(x, y) = |x - y + 1e-6|
-    float f2, n2, f3, n3;
-    unit(2, f2, n2);
-    unit(3, f3, n3);
-    float L_con = 0.f, g2 = 0.f;
-    {
+    if (blockIdx.x == 0) {
+        // ---- directional: 1 - cos(normalize(fhat0 - fhat1), dir)
+        float f0, n0, f1, n1;
+        unit(0, f0, n0);
+        unit(1, f1, n1);
+        const float e = f0 - f1;
+        const float en = sqrtf(block_sum(e * e, red));
+        const float eh = e / en;
+        const float d = text_dir[j];
+        const float dn = sqrtf(block_sum(d * d, red));
+        const float ehn = sqrtf(block_sum(eh * eh, red));
+        const float dot = block_sum(eh * d, red);
+        const float den = fmaxf(ehn, eps_cos) * fmaxf(dn, eps_cos);
+        const float cosv = dot / den;
+        const float g_eh = -(d / den - cosv * eh / fmaxf(ehn * ehn, eps_cos * eps_cos));      // d (1 - cos) / d eh
+        const float g_e = (g_eh - eh * block_sum(g_eh * eh, red)) / en;
+        g_feats[0 * FD + j] = w_dir * unit_bwd(g_e, f0, n0);
+        g_feats[1 * FD + j] = 0.f;
+        if (j == 0) { atomicAdd(&out[0], w_dir * (1.f - cosv)); atomicAdd(&out[1], 1.f - cosv); }
+    } else if (blockIdx.x == 1) {
+        // ---- global contrastive: mean_t(near_t^2 + relu(m - far_text_t)^2 + relu(m - far_img)^2), pairwise_distance(x, y) = |x - y + 1e-6|
+        float f2, n2, f3, n3;
+        unit(2, f2, n2);
+        unit(3, f3, n3);
+        float L_con = 0.f, g2 = 0.f;
         const float di = f2 - f3 + eps_pd;
         const float far_img = sqrtf(block_sum(di * di, red));
         const float hi = fmaxf(margin - far_img, 0.f);
@@ -217,58 +226,56 @@ __global__ __launch_bounds__(HT) void k_clip_style_heads(const float* __restrict
         if (hi > 0.f) g2 += -2.f * hi * di / far_img;
         float acc_l = 0.f;
         for (int t = 0; t < T; ++t) {
-            const float a = f2 - t_tgt[(size_t)t * FD + j] + eps_pd;
-            const float near2 = block_sum(a * a, red);
-            const float b = f2 - t_con[(size_t)t * FD + j] + eps_pd;
-            const float far_t = sqrtf(block_sum(b * b, red));
+            float v[2];
+            const float a = f2 - t_tgt[(size_t)t * FD + j] + eps_pd, b = f2 - t_con[(size_t)t * FD + j] + eps_pd;
+            v[0] = a * a; v[1] = b * b;
+            block_sum_vec(v, 2, redv);
+            const float far_t = sqrtf(v[1]);
             const float ht = fmaxf(margin - far_t, 0.f);
-            acc_l += near2 + ht * ht;
+            acc_l += v[0] + ht * ht;
             g2 += (2.f * a + (ht > 0.f ? -2.f * ht * b / far_t : 0.f)) / (float)T;
         }
         L_con += acc_l / (float)T;
-    }
-    g_feats[2 * FD + j] = w_con * unit_bwd(g2, f2, n2);
-    g_feats[3 * FD + j] = 0.f;
-
-    // ---- PatchNCE: sum_p mean_t( -log( pos / (pos + sum_s neg_s) ) ), pos = exp(cos(f, T_tgt[t]) / tau); templates outermost so that
-    // the text rows and their norms are read once per template
-    float L_nce = 0.f;
-    float fp[MAXP], npn[MAXP], fn[MAXP], gp[MAXP];
-    for (int p = 0; p < P; ++p) {
-        unit(4 + p, fp[p], npn[p]);
-        fn[p] = fmaxf(sqrtf(block_sum(fp[p] * fp[p], red)), eps_cos);      // |fhat| (= 1 up to rounding), as cosine_similarity divides
-        gp[p] = 0.f;
-    }
-    for (int t = 0; t < T; ++t) {
-        float tv[1 + MAXS], tn[1 + MAXS], v[1 + MAXS];
-        tv[0] = t_tgt[(size_t)t * FD + j];
-        for (int s = 0; s < S; ++s) tv[1 + s] = t_neg[((size_t)s * T + t) * FD + j];
-        for (int k = 0; k <= S; ++k) v[k] = tv[k] * tv[k];
-        block_sum_vec(v, 1 + S, redv);
-        for (int k = 0; k <= S; ++k) tn[k] = fmaxf(sqrtf(v[k]), eps_cos);
-        for (int p = 0; p < P; ++p) {
-            for (int k = 0; k <= S; ++k) v[k] = fp[p] * tv[k];
-            block_sum_vec(v, 1 + S, redv);
-            float c[1 + MAXS];
+        g_feats[2 * FD + j] = w_con * unit_bwd(g2, f2, n2);
+        g_feats[3 * FD + j] = 0.f;
+        if (j == 0) { atomicAdd(&out[0], w_con * L_con); atomicAdd(&out[2], L_con); }
+    } else {
+        // ---- PatchNCE crop p: mean_t( -log( pos / (pos + sum_s neg_s) ) ), pos = exp(cos(f, T_tgt[t]) / tau)
+        const int p = blockIdx.x - 2;
+        float fp, npn;
+        unit(4 + p, fp, npn);
+        const float fn = fmaxf(sqrtf(block_sum(fp * fp, red)), eps_cos);       // |fhat| (= 1 up to rounding), as cosine_similarity divides
+        float gp = 0.f, L = 0.f;
+        for (int t = 0; t < T; ++t) {
+            float tv[1 + MAXS], v[2 * (1 + MAXS)];
+            tv[0] = t_tgt[(size_t)t * FD + j];
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s) tv[1 + s] = (s < S) ? t_neg[((size_t)s * T + t) * FD + j] : 0.f;
+#pragma unroll
+            for (int k = 0; k <= MAXS; ++k) { v[2 * k] = tv[k] * tv[k]; v[2 * k + 1] = fp * tv[k]; }
+            block_sum_vec(v, 2 * (1 + S), redv);                                  // norms and dot products of the 1 + S text rows at once
+            float c[1 + MAXS], tn[1 + MAXS];
             float mx = -INFINITY;
-            for (int k = 0; k <= S; ++k) { c[k] = v[k] / (fn[p] * tn[k]); mx = fmaxf(mx, c[k] / tau); }
+#pragma unroll
+            for (int k = 0; k <= MAXS; ++k)
+                if (k <= S) { tn[k] = fmaxf(sqrtf(v[2 * k]), eps_cos); c[k] = v[2 * k + 1] / (fn * tn[k]); mx = fmaxf(mx, c[k] / tau); }
             float z = 0.f;
-            for (int k = 0; k <= S; ++k) z += __expf(c[k] / tau - mx);
+#pragma unroll
+            for (int k = 0; k <= MAXS; ++k) if (k <= S) z += __expf(c[k] / tau - mx);
             const float lse = mx + __logf(z);
-            L_nce += (lse - c[0] / tau) / (float)T;
+            L += (lse - c[0] / tau) / (float)T;
             // d/d fhat of (lse - cos_0 / tau) = sum_k (softmax_k - [k == 0]) dcos_k / tau;  dcos_k = t_k / (fn tn_k) - cos_k fhat / fn^2
             float gt = 0.f;
-            for (int k = 0; k <= S; ++k) {
-                const float sk = __expf(c[k] / tau - lse) - (k == 0 ? 1.f : 0.f);
-                gt += sk * (tv[k] / (fn[p] * tn[k]) - c[k] * fp[p] / (fn[p] * fn[p]));
-            }
-            gp[p] += gt / (tau * (float)T);
+#pragma unroll
+            for (int k = 0; k <= MAXS; ++k)
+                if (k <= S) {
+                    const float sk = __expf(c[k] / tau - lse) - (k == 0 ? 1.f : 0.f);
+                    gt += sk * (tv[k] / (fn * tn[k]) - c[k] * fp / (fn * fn));
+                }
+            gp += gt / (tau * (float)T);
         }
-    }
-    for (int p = 0; p < P; ++p) g_feats[(size_t)(4 + p) * FD + j] = w_nce * unit_bwd(gp[p], fp[p], npn[p]);
-    if (j == 0) {
-        out[0] = w_dir * L_dir + w_con * L_con + w_nce * L_nce;
-        out[1] = L_dir; out[2] = L_con; out[3] = L_nce;
+        g_feats[(size_t)(4 + p) * FD + j] = w_nce * unit_bwd(gp, fp, npn);
+        if (j == 0) { atomicAdd(&out[0], w_nce * L); atomicAdd(&out[3], L); }
     }
 }
 
@@ -319,7 +326,8 @@ int nerfart_clip_style_heads(const float* feats, int n_patches, const float* tex
         set_last_error("clip_style_heads: need n_patches <= 16, n_neg <= 16, n_templates >= 1");
         return 1;
     }
-    hipLaunchKernelGGL(k_clip_style_heads, dim3(1), dim3(HT), 0, (hipStream_t)stream, feats, n_patches, text_dir, t_tgt, t_con, t_neg, n_neg,
+    NERFART_HIP(hipMemsetAsync(out4, 0, 4 * sizeof(float), (hipStream_t)stream));
+    hipLaunchKernelGGL(k_clip_style_heads, dim3(2 + n_patches), dim3(HT), 0, (hipStream_t)stream, feats, n_patches, text_dir, t_tgt, t_con, t_neg, n_neg,
                        n_templates, w_dir, w_con, w_nce, margin, tau, out4, g_feats);
     NERFART_HIP(hipGetLastError());
     return 0;
