@@ -1,6 +1,11 @@
 // ray_common.h - wave-per-ray building blocks shared by the VolSDF / NeuS sampler and compositor
 // kernels.  One 64-lane wave owns one ray; the ray's samples live in LDS; prefix sums are
 // "sequential inside a lane's contiguous segment + shuffle scan across the 64 lanes".
+// (Round 2 experiment, reverted: odd segment lengths - seg = ceil(n / 64) | 1 - make lane l's addresses l * seg + i hit 32
+// different banks: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE fell from 86 / 73 / 52 % to 8 / 0 / 2 % in k_merge_check / k_first_check /
+// k_upsample (profiles/r02n_pmc_lds.txt) but the kernels' times did not move (1.27 -> 1.22 ms, 0.55 -> 0.54 ms: they wait on
+// dependent expf chains and binary searches, not on LDS bandwidth), and the regrouped prefix sums flipped a bisection branch of one
+// golden ray past the 1e-3 pixel bound in the split-bf16 mode.  A conflict-free layout has to keep the partition and pad addresses.)
 #pragma once
 #include "nerfart_common.h"
 #include <math.h>
