@@ -225,7 +225,6 @@ def main():
             cores = psutil.cpu_count(logical=False) or os.cpu_count()
         except Exception:
             cores = os.cpu_count()
-        torch.set_num_threads(int(cores))             # one thread per PHYSICAL core (SMT siblings only oversubscribe the GEMMs)
         cpu_model = next((ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")), "unknown")
         sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
         o, d = rays[args.warmup]
@@ -238,12 +237,23 @@ def main():
                 orender.volsdf_render(sd, oc, dc, near=0.0, far=6.0, obj_bounding_radius=3.0, N_samples=N_SAMPLES,
                                       N_importance=N_IMPORTANCE, max_upsample_steps=kw["max_upsample_steps"], chunk=max(n, 2048))
                 return time.perf_counter() - t1
-        t_cal = cpu_run(256)                          # calibration (also warms the allocator / thread pool)
+        # calibration: the port's many small tensor ops do not scale to every core of a 2-socket host - pick the thread count
+        # (never more than one per PHYSICAL core) that is fastest on 256 rays, then size the sample to about 20 s of CPU work
+        cands = sorted({int(cores), min(int(cores), 32), min(int(cores), 8)}, reverse=True)
+        t_cal, threads = None, int(cores)
+        for th in cands:
+            torch.set_num_threads(th)
+            cpu_run(64)                               # warm the thread pool / allocator at this size
+            t = cpu_run(256)
+            if t_cal is None or t < t_cal:
+                t_cal, threads = t, th
+        torch.set_num_threads(threads)
+        cores = threads
         n_cpu = int(min(max(20.0 * 256 / t_cal, 512), args.cpu_rays * 2) // 256 * 256)      # about 20 s of CPU work
         tc = cpu_run(n_cpu)
         cpu = {"value": round(n_cpu / tc, 1), "unit": "rays/s", "cores": int(cores), "kind": "port", "cpu_model": cpu_model,
                "sample": f"{n_cpu} rays strided over the same 480x270 frame in one chunk, {N_SAMPLES}+{N_IMPORTANCE} spp, "
-                         f"oracle/render.py volsdf_render on torch-CPU fp32, {int(cores)} threads, {tc:.1f} s",
+                         f"oracle/render.py volsdf_render on torch-CPU fp32, {int(cores)} threads (fastest of {cands} on a 256-ray calibration), {tc:.1f} s",
                "reference_in_survey_container": {"value": 93.0, "unit": "rays/s", "cores": 8, "cpu_model": "Intel Xeon @ 2.10GHz",
                                                  "what": "the reference's own render_fn at 128 spp, timed once in the survey "
                                                          "container (BASELINE.md section 2: 86-107 rays/s); cannot be re-run on the GPU box"}}
