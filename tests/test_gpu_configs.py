@@ -200,3 +200,34 @@ def test_cfg5_render_sharded_two_ranks_equals_single_process(tmp_path):
     errs = [open(tmp_path / f).read() for f in os.listdir(tmp_path) if f.startswith("err")]
     assert not errs, errs[0]
     assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
+
+
+def test_cfg4_neus_full_frame_properties_and_oracle_subset():
+    """BASELINE configs[3]: neus_fangzhou_vangogh.yaml dims (view embedding 4: radiance input 289), 64 + 64 samples per ray, one
+    480 x 270 frame at the benchmarked precision: finite, chunk invariant, a ray renders identically alone and inside the frame,
+    sorted depths, weights sum to the opacity, and a 64-ray strided subset within the north-star 1e-3 of the oracle."""
+    from nerfart_amd import scene, rend_util
+    from oracle import render
+    model, rk, render_fn = scene.build_model("NeuS", seed=0, beta=None, device=DEV, precision="bf16x3")
+    H, W = 480, 270
+    c2w, K = scene.camera(H, W, cam_dist=2.5)
+    o, d, _ = rend_util.get_rays(c2w[None].to(DEV), K[None].to(DEV), H, W)
+    kw = {k: v for k, v in rk.items() if k != "rayschunk"}
+    rgb, depth, ex = render_fn(o, d, calc_normal=True, detailed_output=False, **kw)
+    assert rgb.shape == (1, H * W, 3) and torch.isfinite(rgb).all() and rgb.min() >= 0 and rgb.max() <= 1 + 1e-5
+    rgb2, depth2, _ = render_fn(o, d, calc_normal=True, detailed_output=False, rayschunk=50021, **kw)
+    assert torch.equal(rgb, rgb2) and torch.equal(depth, depth2), "results must not depend on ray chunking"
+    sel = torch.arange(0, H * W, (H * W) // 64)[:64]
+    rgb_s, depth_s, ex_s = render_fn(o[:, sel], d[:, sel], calc_normal=True, detailed_output=True, **kw)
+    assert torch.equal(rgb_s, rgb[:, sel])
+    dv = ex_s["d_all"][0]
+    assert (dv[:, 1:] >= dv[:, :-1]).all()
+    assert (ex_s["visibility_weights"][0].sum(-1) - ex_s["mask_volume"][0]).abs().max() < 1e-5
+    sd, _ = scene_state("NeuS", None)
+    with torch.no_grad():
+        ref = render.neus_render(sd, o[0, sel].cpu(), d[0, sel].cpu(), obj_bounding_radius=1.0)
+    err = (rgb_s[0].cpu() - ref["rgb"]).abs().max().item()
+    derr = (depth_s[0].cpu() - ref["depth_volume"]).abs().max().item()
+    hit = float((ex["mask_volume"] > 0.5).float().mean())
+    print(f"  NeuS 480x270: {hit:.2f} of rays hit the object; subset max |rgb - oracle| {err:.2e}, depth {derr:.2e}")
+    assert err < 1e-3 and derr < 1e-2 and hit > 0.05
