@@ -156,6 +156,20 @@ def main():
             "scaling": "weak" if primary_tiles else "strong",
             "what": ("one view per rank per step" if primary_tiles else
                      "ONE 480x270 frame per step, 2,048-ray tiles round-robin over the ranks (dist.render_sharded) + one all_gather")}
+        # cfg 5's frame size: ONE 960 x 540 frame (518,400 rays) sharded the same way, one warm-up and one timed frame
+        H5, W5 = 960, 540
+        c2w5, K5 = scene.camera(H5, W5, angle=angles[0])
+        o5, d5, _ = rend_util.get_rays(c2w5[None].to(dev), K5[None].to(dev), H5, W5)
+        big = lambda: nd.render_sharded(render_fn, o5, d5, tile=2048, require_nablas=True, calc_normal=True, detailed_output=False, **kw)
+        big()
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t5 = time.perf_counter()
+        big()
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t5 = torch.tensor([time.perf_counter() - t5], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t5, op=dist.ReduceOp.MAX)
+        secondary["strong_tiles_960x540"] = {"value": round(H5 * W5 / float(t5), 1), "unit": "rays/s", "ms_per_step": round(float(t5) * 1e3, 2), "steps": 1,
+                                             "scaling": "strong", "what": "ONE 960x540 frame (cfg 5), 2,048-ray tiles round-robin over the ranks + one all_gather"}
     if world == 1 and not args.no_secondary and args.precision == "bf16x3":
         m32, _, f32 = scene.build_model("VolSDF", seed=0, beta=args.beta, device=dev, precision="fp32")
         m32.packed()

@@ -325,12 +325,18 @@ __device__ __forceinline__ size_t uoff(const GradCtx& gc, int idx) {
 }
 // (l, unit) of the second-order kernels: softplus' at slot 8 + l, tangent / activation hi parts at slot l
 __device__ __forceinline__ void d_load2(GradCtx& gc, int idx, int buf) {
+#ifdef NERFART_ABLATE_SCRATCH      // timing experiments only (tools/ablate_grad.py): no scratch / dump traffic, results wrong
+    return;
+#endif
     gc.dbuf[buf] = *reinterpret_cast<const u32x4*>(gc.ws + uoff(gc, 64 + idx) + gc.voff);
     gc.abuf[buf] = *reinterpret_cast<const u32x4*>(gc.ws + uoff(gc, idx) + gc.voff);
 }
 // Plain (compiler-visible) loads: hipcc then keeps its own vmcnt bookkeeping for them - with the LDS-DMA pieces it
 // cannot see this can only make its wait stricter.  (Hand-counted asm loads gave wrong gradients on random waves.)
 __device__ __forceinline__ void d_load(GradCtx& gc, int idx, int buf) {
+#ifdef NERFART_ABLATE_SCRATCH
+    return;
+#endif
     gc.dbuf[buf] = *reinterpret_cast<const u32x4*>(gc.ws + uoff(gc, idx) + gc.voff);
 }
 
@@ -438,7 +444,11 @@ struct Items {
                 // reverse-mode kernel, forward sweep: store the softplus' unit finished in the previous k-step
                 constexpr int HUP = (ks == 0) ? (L::PEND_IN ? 100 : -1) : L::hosted(ks - 1);
                 constexpr bool STORE = (ks == 0) ? L::PEND_IN : (HUP >= 0 && L::stores(L::mode_of(HUP)));
+#ifdef NERFART_ABLATE_SCRATCH
+                if constexpr (false) {
+#else
                 if constexpr (STORE) {
+#endif
                     *reinterpret_cast<u32x4*>(gc.pend_ptr + gc.voff_out) = gc.dpend;
                     constexpr int PM = (ks == 0) ? L::MODE : L::mode_of(HUP);        // (mode 10 layers use 10 for both kinds)
                     if constexpr (PM == 10) *reinterpret_cast<u32x4*>(gc.pend_ptr + 8 * gc.slot_stride + gc.voff_out) = gc.dpend2;

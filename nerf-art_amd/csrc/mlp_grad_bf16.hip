@@ -118,7 +118,12 @@ k_sdf_grad_bf16(const float* __restrict__ blob, PointSrc src, float R_bg, float*
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const char* ptr = gc.ws + uoff(gc, u);
+#ifdef NERFART_ABLATE_SCRATCH
+                d0[u] = u32x4{1u, 1u, 1u, 1u};
+                (void)ptr;
+#else
                 d0[u] = *reinterpret_cast<const u32x4*>(ptr + gc.voff);
+#endif
             }
             Unit X[8];
 #pragma unroll
