@@ -55,3 +55,28 @@ def test_errors_are_reported_not_swallowed():
     import pytest
     with pytest.raises(hip.NerfartHipError):
         hip.sdf_fwd(torch.zeros(8), torch.zeros(4, 3), 3.0)      # CPU tensors are refused: no CPU path
+
+
+def test_new_entry_points_validate_their_arguments_without_a_gpu():
+    """Argument checks of the round-2 entry points run before any launch: bad shapes / null buffers are errors with a message."""
+    import ctypes as C
+    from nerfart_amd import hip
+    lib = hip.lib
+    null = C.c_void_p(0)
+
+    def err():
+        return lib.nerfart_last_error().decode()
+    assert lib.nerfart_gemm_f16_nt(null, null, 65, 64, 64, null, null) != 0 and "multiples of 64" in err()
+    assert lib.nerfart_vgg16_l1_fwd(null, null, 100, 100, null, 0, null, 0, null) != 0 and "H and W" in err()
+    assert lib.nerfart_vgg16_l1_fwd(null, null, 224, 224, null, 0, null, 0, null) != 0 and "workspace" in err()
+    assert lib.nerfart_clip_vitb32_image_fwd(null, null, 4, null, 1, null, 0, null) != 0 and "null" in err()
+    assert lib.nerfart_clip_vitb32_workspace_bytes(0, 1) == 0
+    assert lib.nerfart_clip_vitb32_workspace_bytes(16, 1) > 12 * 16 * 50 * 768 * 4
+    assert lib.nerfart_resample_fwd(null, 2, 3, 8, 8, 0, 0, 8, 8, 4, 4, 1, null, null, null, null, 3, 4, 4, null) != 0 and "n_src" in err()
+    assert lib.nerfart_resample_fwd(null, 1, 3, 8, 8, 0, 0, 8, 8, 4, 4, 7, null, null, null, null, 1, 4, 4, null) != 0 and "mode" in err()
+    assert lib.nerfart_clip_style_heads(null, 17, null, null, null, null, 8, 79, 1.0, 0.2, 0.1, 2.0, 0.07, null, null, null) != 0 and "n_patches" in err()
+    assert lib.nerfart_first_crossing(null, null, 5, 1, 0.0, null, null, null, null, null, null) != 0 and "n_steps" in err()
+    assert lib.nerfart_first_crossing(null, null, 0, 256, 0.0, null, null, null, null, null, null) == 0          # no rays: nothing to do
+    offs = (C.c_longlong * 22)()
+    total = lib.nerfart_vgg16_blob_layout(C.cast(offs, C.c_void_p))
+    assert offs[21] == total and total > 2 * 2 * (64 * 64 + 9 * (64 * 64 + 64 * 128 + 128 * 128 + 128 * 256 + 2 * 256 * 256))
