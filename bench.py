@@ -210,6 +210,9 @@ def main():
         if args.precision == "bf16x3":
             # what the matrix pipe executes: MFMA_MAC_SDF multiply-adds per point, each as `mfma_per_product` bf16 MFMAs
             # (hi.hi + hi.lo + lo.hi), as a fraction of the dense bf16 peak
+            roofline["note"] = ("measured limiter (DESIGN.md 4.1b, profiles/r02k_ablate_w32.log): weight bytes moved per column - 1.9 MB of split-bf16 "
+                                "fragments per 128-point tile through L2 -> LDS-DMA -> ds_read_b128, ~78 / ~16 issue-blocking cycles per KiB - "
+                                "not matrix-pipe time (5.7 of 9.2 ms per 4 M points)")
             roofline["mfma_per_product"] = 3
             roofline["mfma_executed_frac"] = round(3 * 2.0 * MFMA_MAC_SDF * (points / launches) / avg_s / 1e12 / peak, 4)
         # HBM traffic per launch is a PROFILED figure, not measured in this run (bench.py cannot read hardware counters): it
