@@ -183,6 +183,24 @@ def main():
         secondary["fp32_exact"] = {"value": round(H * W / t32, 1), "unit": "rays/s", "ms_per_step": round(t32 * 1e3, 2), "steps": 1,
                                    "what": "same frame with --precision fp32 (v_mfma_f32_16x16x4_f32, exact fp32 products)"}
         del m32, f32
+        # the other single-GPU configurations of BASELINE.json, one warm-up + one timed frame each (bench lines of their own: tools/)
+        def one_frame(fn, Hh, Ww, **extra):
+            c2w_, K_ = scene.camera(Hh, Ww, angle=angles[1])
+            oo, dd, _ = rend_util.get_rays(c2w_[None].to(dev), K_[None].to(dev), Hh, Ww)
+            fn(oo, dd, calc_normal=True, detailed_output=False, **extra)
+            torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            fn(oo, dd, calc_normal=True, detailed_output=False, **extra)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t_
+        t5 = one_frame(render_fn, 960, 540, require_nablas=True, **kw)
+        secondary["cfg5_frame_960x540"] = {"value": round(960 * 540 / t5, 1), "unit": "rays/s", "ms_per_step": round(t5 * 1e3, 2), "steps": 1,
+                                           "what": "configs[4] frame size (518,400 rays, VolSDF 128 + 64 spp) on ONE GPU"}
+        mn, rkn, fn_n = scene.build_model("NeuS", seed=0, beta=None, device=dev, precision=args.precision)
+        t4 = one_frame(fn_n, H, W, **{k: v for k, v in rkn.items() if k != "rayschunk"})
+        secondary["cfg4_neus_480x270"] = {"value": round(H * W / t4, 1), "unit": "rays/s", "ms_per_step": round(t4 * 1e3, 2), "steps": 1,
+                                          "what": "configs[3]: neus_fangzhou_vangogh.yaml dims, 64 + 64 spp, 704.8 MFLOP/ray algorithmic"}
+        del mn, fn_n
 
     # algorithmic work of one of this rank's frames (uses the iter_usage the renderer reports)
     _, ex = step(args.warmup, detailed=True)
