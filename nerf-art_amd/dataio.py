@@ -12,7 +12,8 @@ three things; none of them is in this image, so they are restated on numpy / sci
 * `imageio.imread` -> PIL; `skimage.img_as_float32` -> / 255.
 * `skimage.transform.rescale(img, 1 / downscale, anti_aliasing=False)` (order 1, half-pixel centres) ->
   `F.interpolate(mode="bilinear", align_corners=False, antialias=False)`, the same sampling rule (for an integer
-  downscale every output pixel is the mean of a 2 x 2 neighbourhood of input pixels in both).  UNPINNED as well.
+  downscale every output pixel is the mean of a 2 x 2 neighbourhood of input pixels in both).  Pinned against the scipy call
+  skimage 0.19.3 makes for it (`ndimage.zoom(order=1, mode="mirror", grid_mode=True)`, tests/test_dataio.py); skimage itself is absent.
 """
 import glob
 import os

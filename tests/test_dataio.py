@@ -128,3 +128,21 @@ def test_camera_paths_match_reference(cg):
     # the poses are usable by get_rays: orthonormal, looking at the focus point
     for m in cp.spiral_path(c2ws, 5):
         np.testing.assert_allclose(m[:3, :3].T @ m[:3, :3], np.eye(3), atol=1e-6)
+
+
+def test_rescale_equals_the_scipy_call_skimage_makes():
+    """skimage 0.19.3 (the reference's pin, requirements.txt:43) implements `rescale(img, 1 / downscale, anti_aliasing=False)` for
+    order 1 as `scipy.ndimage.zoom(img, out / in, order=1, mode='mirror', grid_mode=True)` (skimage/transform/_warps.py resize:
+    default mode 'reflect' -> ndimage 'mirror'); scipy is present here, skimage is not - `_rescale` is held to that call."""
+    import scipy.ndimage as ndi
+    from nerfart_amd.dataio import _rescale
+    rng = np.random.default_rng(0)
+    for shape in ((12, 8, 3), (540, 960, 3), (37, 53)):
+        img = rng.random(shape).astype(np.float32)
+        for ds in (2, 4, 8, 1.5):
+            mine = _rescale(img, ds)
+            out = (int(round(shape[0] / ds)), int(round(shape[1] / ds)))
+            zoom = [out[0] / shape[0], out[1] / shape[1]] + ([1] if len(shape) == 3 else [])
+            ref = ndi.zoom(img, zoom, order=1, mode="mirror", grid_mode=True, prefilter=False)
+            assert mine.shape == ref.shape
+            np.testing.assert_allclose(mine, ref, atol=5e-7, rtol=0)
