@@ -15,7 +15,10 @@ file:line it follows.  It exists to *check* the HIP path, never to be it:
 
 Parity status: renderer path PINNED by
 the golden vectors G1-G12; its differentiable variant (row a19, the
-fine-tune step's pass 2) PINNED by G11 (the reference's own autograd).  CLIP ViT-B/32 (a23): "parity unpinned" - the
+fine-tune step's pass 2) PINNED by G11 (the reference's own autograd); the surface
+renderer (``raycast.py``: row N4, models/ray_casting.py) PINNED by
+``tests/golden/raycast_golden.npz`` (``make_golden_raycast.py``, checked by
+``tests/test_oracle_raycast.py``).  CLIP ViT-B/32 (a23): "parity unpinned" - the
 reference takes it from the un-vendored third-party ``clip`` package and
 holds no test vectors for it; the oracle there is a restatement of the
 published architecture cross-checked against ``transformers.CLIPVisionModel``.
