@@ -229,8 +229,13 @@ def main():
             # what the matrix pipe executes: MFMA_MAC_SDF multiply-adds per point, each as `mfma_per_product` bf16 MFMAs
             # (hi.hi + hi.lo + lo.hi), as a fraction of the dense bf16 peak
             roofline["note"] = ("measured limiter (DESIGN.md 4.1b, profiles/r02k_ablate_w32.log): weight bytes moved per column - 1.9 MB of split-bf16 "
-                                "fragments per 128-point tile through L2 -> LDS-DMA -> ds_read_b128, ~78 / ~16 issue-blocking cycles per KiB - "
-                                "not matrix-pipe time (5.7 of 9.2 ms per 4 M points)")
+                                "fragments per 128-point tile through L2 -> LDS-DMA -> ds_read_b128 - not matrix-pipe time (5.7 of 9.2 ms per "
+                                "4 M points)")
+            # ceilings for this kernel in the same algorithmic-flop units (profiles/r02s_ubench_coissue.txt, tools/ubench_coissue.hip):
+            # 3 MFMAs per product at the measured MFMA-only rate (17.7 nominal cycles per 16x16x32 = 0.91 of peak), and the SIMD's
+            # measured issue capacity for the kernel's own mix of MFMAs, fragment reads, LDS-DMA pieces and epilogue VALU (25.0 cycles)
+            roofline["ceiling_frac"] = {"matrix_pipe_only": round(0.91 / 3, 4), "issue_capacity_for_this_mix": round(0.91 / 3 * 17.7 / 25.0, 4),
+                                        "source": "profiles/r02s_ubench_coissue.txt"}
             roofline["mfma_per_product"] = 3
             roofline["mfma_executed_frac"] = round(3 * 2.0 * MFMA_MAC_SDF * (points / launches) / avg_s / 1e12 / peak, 4)
         # HBM traffic per launch is a PROFILED figure, not measured in this run (bench.py cannot read hardware counters): it
