@@ -211,29 +211,45 @@ struct Items32 {
             if constexpr (ks < L::NH) { bh = xb[ks & 1].h; bl = xb[ks & 1].l; }
             else { bh = xs[ks - L::NH].h; bl = xs[ks - L::NH].l; }
             constexpr int HU = L::hosted(ks);
+#ifndef W32_DMA_AT          // where the double item's LDS-DMA pieces go: gap * 2 + (0: right behind the gap's MFMA / read, 1: behind its stages).
+#define W32_DMA_AT 0        // Swept on MI355X (tools/sweep_w32.py, profiles/r02s_sweep_w32.log): 9.47 ms (gap 0) .. 9.57 ms (gap 5), same bits.
+#endif
+#define W32_PIECES(G, POS) if constexpr (W32_DMA_AT == 2 * (G) + (POS)) w_pieces<(DI * 16) / ND, ((DI + 1) * 16) / ND>(s)
             mfma1(r[S][0].h, bh, Q.t[T]);
             if constexpr (NEXT) lds_read_one<(2 * DI + 2) * 2048>(r[S ^ 1][0].h, addr);
+            W32_PIECES(0, 0);
             gap_stages<HU, 6 * D + 0>(P, Q, xb, x0n, ps);
+            W32_PIECES(0, 1);
             __builtin_amdgcn_sched_barrier(0);
             mfma1(r[S][1].h, bh, Q.t[T + 1]);
             if constexpr (NEXT) lds_read_one<(2 * DI + 3) * 2048>(r[S ^ 1][1].h, addr);
+            W32_PIECES(1, 0);
             gap_stages<HU, 6 * D + 1>(P, Q, xb, x0n, ps);
+            W32_PIECES(1, 1);
             __builtin_amdgcn_sched_barrier(0);
             mfma1(r[S][0].h, bl, Q.t[T]);
             if constexpr (NEXT) lds_read_one<(2 * DI + 2) * 2048 + 1024>(r[S ^ 1][0].l, addr);
+            W32_PIECES(2, 0);
             gap_stages<HU, 6 * D + 2>(P, Q, xb, x0n, ps);
+            W32_PIECES(2, 1);
             __builtin_amdgcn_sched_barrier(0);
             mfma1(r[S][1].h, bl, Q.t[T + 1]);
             if constexpr (NEXT) lds_read_one<(2 * DI + 3) * 2048 + 1024>(r[S ^ 1][1].l, addr);
+            W32_PIECES(3, 0);
             gap_stages<HU, 6 * D + 3>(P, Q, xb, x0n, ps);
+            W32_PIECES(3, 1);
             __builtin_amdgcn_sched_barrier(0);
             mfma1(r[S][0].l, bh, Q.t[T]);
-            w_pieces<(DI * 16) / ND, ((DI + 1) * 16) / ND>(s);
+            W32_PIECES(4, 0);
             gap_stages<HU, 6 * D + 4>(P, Q, xb, x0n, ps);
+            W32_PIECES(4, 1);
             __builtin_amdgcn_sched_barrier(0);
             mfma1(r[S][1].l, bh, Q.t[T + 1]);
+            W32_PIECES(5, 0);
             gap_stages<HU, 6 * D + 5>(P, Q, xb, x0n, ps);
+            W32_PIECES(5, 1);
             __builtin_amdgcn_sched_barrier(0);
+#undef W32_PIECES
             Items32<L, C, NKC, DI + 1>::run(P, Q, xb, xs, x0n, ps, r, addr, s);
         }
     }

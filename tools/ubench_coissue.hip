@@ -25,6 +25,7 @@ struct Fill {
     f32x2 p[8];
     u32x4 d[4];
     unsigned lds_addr;
+    u32x4 g[4];            // staging registers of the "global load + ds_write" form of the weight stream
     const char* gsrc;      // this iteration's window of the 2 MiB weight-like buffer (wave-uniform)
     unsigned voff;         // lane * 16
 };
@@ -258,11 +259,19 @@ template <int I0, int N>
 __device__ __forceinline__ void ds_ops(Fill& s) {
     if constexpr (N > 0) { asm volatile("ds_read_b128 %0, %1" : "=v"(s.d[I0 & 3]) : "v"(s.lds_addr)); ds_ops<I0 + 1, N - 1>(s); }
 }
-template <int I0, int N>
+// GM 0: LDS-DMA.  GM 1: the same KiB through registers (ds_write_b128 of the piece loaded a round earlier, then the load; the
+// write does not wait for the load here - timing only).  GM 2: LDS-DMA behind an s_waitcnt lgkmcnt(0) (no LDS read in flight).
+template <int I0, int N, int GM = 0>
 __device__ __forceinline__ void dma_ops(Fill& s) {
     if constexpr (N > 0) {
-        asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(s.voff), "s"(s.gsrc + (I0 & ~3) * 1024), "i"((I0 & 3) * 1024) : "memory");
-        dma_ops<I0 + 1, N - 1>(s);
+        if constexpr (GM == 1) {
+            asm volatile("ds_write_b128 %0, %1 offset:8192" ::"v"(s.lds_addr), "v"(s.g[I0 & 3]) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(s.g[I0 & 3]) : "v"(s.voff), "s"(s.gsrc + (I0 & ~3) * 1024), "i"((I0 & 3) * 1024) : "memory");
+        } else {
+            if constexpr (GM == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(s.voff), "s"(s.gsrc + (I0 & ~3) * 1024), "i"((I0 & 3) * 1024) : "memory");
+        }
+        dma_ops<I0 + 1, N - 1, GM>(s);
     }
 }
 constexpr int upto(int m, int total) { return (m * total) / 12; }     // how many of `total` have been issued before MFMA m of 12
@@ -274,9 +283,17 @@ struct ComboBody {
         if constexpr (M < 12) {
             if constexpr (SHAPE == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[M]) : "v"(a), "v"(b));
             else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[M & 7]) : "v"(a), "v"(b));
+            constexpr int NG = upto(M + 1, G12) - upto(M, G12), NVV = upto(M + 1, V12) - upto(M, V12);
+            if constexpr ((PAT & 32) != 0 && NG > 0) asm volatile("s_nop 7");                                 // pat & 32: 8 idle cycles, then the piece
+            if constexpr ((PAT & (8 | 32)) != 0) dma_ops<upto(M, G12), NG, 0>(s);                             // pat & 8: the piece first
             ds_ops<upto(M, D12), upto(M + 1, D12) - upto(M, D12)>(s);
-            mix_ops<PAT, upto(M, V12), upto(M + 1, V12) - upto(M, V12)>(s);
-            dma_ops<upto(M, G12), upto(M + 1, G12) - upto(M, G12)>(s);
+            if constexpr ((PAT & 16) != 0) dma_ops<upto(M, G12), NG, 0>(s);                                   // pat & 16: between reads and VALU
+            if constexpr ((PAT & 64) != 0) {                                                                 // pat & 64: one VALU, the piece, the rest
+                mix_ops<(PAT & 1), upto(M, V12), (NVV > 0 ? 1 : 0)>(s);
+                dma_ops<upto(M, G12), NG, 0>(s);
+                mix_ops<(PAT & 1), upto(M, V12) + (NVV > 0 ? 1 : 0), NVV - (NVV > 0 ? 1 : 0)>(s);
+            } else mix_ops<(PAT & 1), upto(M, V12), NVV>(s);
+            if constexpr ((PAT & (8 | 16 | 32 | 64)) == 0) dma_ops<upto(M, G12), NG, ((PAT >> 1) & 3)>(s);
             ComboBody<SHAPE, PAT, V12, D12, G12, M + 1>::run(acc, a, b, s);
         }
     }
@@ -295,6 +312,8 @@ __global__ void __launch_bounds__(64 * WAVES, 1) k_combo(float* out, int iters, 
     s.lds_addr = (unsigned)(size_t)lds + (threadIdx.x & 63) * 16;
     s.voff = (threadIdx.x & 63) * 16;
     s.gsrc = gbuf;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s.g[i] = u32x4{0, 0, 0, 0};
     const unsigned wave_skew = (threadIdx.x >> 6) * 4096;
     asm volatile("s_mov_b32 m0, %0" ::"s"((unsigned)(size_t)lds + 8192) : "memory");
     u32x4 a = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}, b = a;
@@ -333,7 +352,7 @@ __global__ void __launch_bounds__(64 * WAVES, 1) k_combo(float* out, int iters, 
 #pragma unroll
     for (int i = 0; i < 16; ++i) r += s.f[i];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r += __uint_as_float(s.d[i][0]);
+    for (int i = 0; i < 4; ++i) r += __uint_as_float(s.d[i][0]) + __uint_as_float(s.g[i][1]);
     if (r == 123.456f) out[0] = r;
 }
 
@@ -522,7 +541,16 @@ int main() {
     crun<1, 0, 44, 0, 0, 4>();  crun<1, 0, 0, 8, 0, 4>();   crun<1, 0, 0, 0, 2, 4>();
     crun<1, 0, 44, 8, 0, 4>();  crun<1, 0, 44, 8, 2, 4>();  crun<1, 0, 60, 8, 2, 4>();
     crun<1, 1, 28, 8, 2, 4>();  crun<1, 1, 44, 8, 2, 4>();
-    printf("\n# combinations, per 12 MFMAs: V12 epilogue-mix VALU (pattern 0 = today's 22 per value pair, 1 = leaner 14), D12 ds_read_b128, G12 LDS-DMA pieces\n");
+    // the weight stream in other forms (pat 2: through registers + ds_write_b128; pat 4: LDS-DMA with no LDS read in flight)
+    crun<1, 2, 44, 8, 2, 4>();  crun<1, 2, 0, 8, 2, 4>();   crun<1, 2, 0, 0, 2, 4>();
+    crun<1, 4, 44, 8, 2, 4>();  crun<1, 4, 0, 8, 2, 4>();
+    crun<1, 0, 0, 8, 2, 4>();   crun<1, 0, 44, 0, 2, 4>();
+    crun<0, 2, 22, 8, 1, 8>();  crun<0, 4, 22, 8, 1, 8>();
+    // placement of the LDS-DMA piece inside its gap (pat 8: right behind the MFMA; pat 16: between the reads and the VALU)
+    crun<1, 8, 44, 8, 2, 4>();  crun<1, 16, 44, 8, 2, 4>(); crun<1, 8, 44, 0, 2, 4>();
+    crun<0, 8, 22, 8, 1, 8>();
+    crun<1, 32, 44, 8, 2, 4>(); crun<1, 64, 44, 8, 2, 4>(); crun<1, 16, 44, 12, 2, 4>(); crun<1, 16, 60, 8, 2, 4>(); crun<1, 16, 36, 8, 2, 4>();
+    printf("\n# combinations, per 12 MFMAs: V12 epilogue-mix VALU (pat & 1: 0 = today's 22 per value pair, 1 = leaner 14), D12 ds_read_b128, G12 weight pieces (pat >> 1: 0 LDS-DMA, 1 global load + ds_write_b128, 2 LDS-DMA behind lgkmcnt(0))\n");
     printf("%-6s %-6s %-4s %4s %4s %4s %12s %10s\n", "shape", "w/simd", "pat", "V12", "D12", "G12", "ns/mfma", "cyc/mfma");
     for (const CRow& r : crows)
         printf("%-6d %-6d %-4d %4d %4d %4d %12.3f %10.2f\n", r.shape, r.waves, r.pat, r.v12, r.d12, r.g12, r.ns, r.ns * ghz);
