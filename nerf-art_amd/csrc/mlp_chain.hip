@@ -30,6 +30,10 @@ constexpr int KT_FLOATS = 16 * 256;                 // one k tile of a chunk: 16
 constexpr int CHUNK_FLOATS_MAX = 2 * KT_FLOATS;     // a chunk holds 1 or 2 k tiles (32 KiB)
 constexpr int AUX_FLOATS_MAX = 2560;
 constexpr int LDS_FLOATS = 2 * CHUNK_FLOATS_MAX + AUX_FLOATS_MAX + TAB_INTS;   // 76,288 B
+// reverse-mode grad(SDF) scratch: softplus'(z_l) as fp32, [layer 8][tile 16][wave 8][lane 64] x 16 B per workgroup
+constexpr int D_TILE_STRIDE = WAVES * 1024;
+constexpr int D_LAYER_STRIDE = 16 * D_TILE_STRIDE;
+constexpr size_t GRADF_WS_PER_WG = 8 * (size_t)D_LAYER_STRIDE;                 // 1 MiB
 
 using Pipe = PipeT<WAVES, CHUNK_FLOATS_MAX>;
 
@@ -72,8 +76,9 @@ __device__ __forceinline__ void mma_ktile(f32x4 (&acc)[16], const f32x4 xt, cons
     }
 }
 
-template <int NT_BASE, int NT_EXTRA_MAX, bool SOFTPLUS, bool TANGENT>
-__device__ __forceinline__ void run_layer(f32x4 (&X)[XT_MAX], Pipe& p, const float* bias_lds, bool full16, int nextra, bool relu) {
+template <int NT_BASE, int NT_EXTRA_MAX, bool SOFTPLUS, bool TANGENT, bool DSTORE = false>
+__device__ __forceinline__ void run_layer(f32x4 (&X)[XT_MAX], Pipe& p, const float* bias_lds, bool full16, int nextra, bool relu,
+                                          char* dws = nullptr) {
     const int lane = lane_id();
     const int g = lane >> 4;
     const bool is_val = !TANGENT || ((lane & 3) == 0);
@@ -101,7 +106,7 @@ __device__ __forceinline__ void run_layer(f32x4 (&X)[XT_MAX], Pipe& p, const flo
     for (int T = 0; T < 16; ++T) {
         if (T < 14 || full16) {
             const f32x4 b = *reinterpret_cast<const f32x4*>(bias_lds + T * 16 + g * 4);
-            f32x4 y;
+            f32x4 y, dd = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float z = acc[T][r] + (is_val ? b[r] : 0.f);
@@ -111,6 +116,10 @@ __device__ __forceinline__ void run_layer(f32x4 (&X)[XT_MAX], Pipe& p, const flo
                         softplus100_vd(z, v, d);
                         d = quad_bcast0(d);
                         y[r] = is_val ? v : d * acc[T][r];
+                    } else if (DSTORE) {
+                        float v, d;
+                        softplus100_vd(z, v, d);
+                        y[r] = v; dd[r] = d;
                     } else {
                         y[r] = softplus100(z);
                     }
@@ -119,6 +128,8 @@ __device__ __forceinline__ void run_layer(f32x4 (&X)[XT_MAX], Pipe& p, const flo
                 }
             }
             X[T] = y;
+            // reverse-mode kernel, forward sweep: softplus'(z) of this tile to the wave's scratch slot (D_TILE_STRIDE apart)
+            if (DSTORE) *reinterpret_cast<f32x4*>(dws + T * D_TILE_STRIDE + lane * 16) = dd;
         }
     }
 }
@@ -212,16 +223,16 @@ __device__ __forceinline__ void load_aux(float* aux_lds, const float* blob, cons
 
 // The 8 hidden layers of the SDF net, in place on X (out: layer-7 output in X[0..15]).
 // Layer 0 (3 input tiles) has its own body; layers 1..7 share one body in a run-time loop.
-template <bool TANGENT>
+template <bool TANGENT, bool DSTORE = false>
 __device__ __forceinline__ void surface_hidden(f32x4 (&X)[XT_MAX], float px, float py, float pz, int g, int q,
-                                               Pipe& p, const float* aux) {
+                                               Pipe& p, const float* aux, char* dws = nullptr) {
     {
         f32x4 E[3];
         encode_slots(px, py, pz, g, q, E);
 #pragma unroll
         for (int t = 0; t < 3; ++t) X[t] = E[t];
     }
-    run_layer<3, 0, true, TANGENT>(X, p, aux, true, 0, false);
+    run_layer<3, 0, true, TANGENT, DSTORE>(X, p, aux, true, 0, false, dws);
 #pragma nounroll
     for (int L = 1; L < 8; ++L) {
         if (L == 4) {
@@ -240,7 +251,7 @@ __device__ __forceinline__ void surface_hidden(f32x4 (&X)[XT_MAX], float px, flo
                 for (int r = 0; r < 4; ++r) X[14 + t][r] = E[t][r] / rs2;
         }
         // layer 3 has 217 outputs -> 14 tiles (7 zero rows); layer 4 has 17 input tiles
-        run_layer<16, 1, true, TANGENT>(X, p, aux + L * 256, L != 3, (L == 4) ? 1 : 0, false);
+        run_layer<16, 1, true, TANGENT, DSTORE>(X, p, aux + L * 256, L != 3, (L == 4) ? 1 : 0, false, DSTORE ? dws + L * D_LAYER_STRIDE : nullptr);
     }
 }
 
@@ -321,6 +332,137 @@ k_sdf_nabla(const float* __restrict__ blob, PointSrc src, float R_bg, float* __r
                 }
             } else if (g == 0) {
                 nabla_out[(size_t)m * 3 + (cq - 1)] = v;
+            }
+        }
+    }
+}
+
+// =======================================================================================
+// K3a, reverse mode (what nerfart_sdf_nabla_fwd runs at precision 0): sdf + nabla + h7 with ONE column per point, 128 points
+// per workgroup tile.  Forward sweep = K2 with softplus'(z_l) of every layer parked in the wave's scratch slot (fp32: this is the
+// exact-product mode); then d sdf / d a_{l-1} = W_l^T (d sdf / d a_l . softplus'(z_l)), l = 7 .. 0, through the transposed
+// chunks that follow the forward program in the blob (packing.surface_plan: header word 6): 2 chain sweeps per point instead of
+// the 4 columns (value + 3 tangents) of k_sdf_nabla.  The 48 encoding slots of layer 4's input (skip connection) and of layer 0
+// come out of 3-tile "tails" and meet the encoding's Jacobian in registers.  (reference: autograd.grad of sdf w.r.t. x,
+// models/base.py:252-263)
+// =======================================================================================
+// g <- (W^T g) . softplus'(z of the layer below) * scale:  NT_K k tiles (the layer's outputs), 16 or 14 output tiles
+template <int NT_K>
+__device__ __forceinline__ void run_layer_T(f32x4 (&X)[XT_MAX], Pipe& p, bool full16, const char* dws_below, float scale) {
+    const int lane = lane_id();
+    f32x4 acc[16];
+#pragma unroll
+    for (int T = 0; T < 16; ++T) acc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NT_K / 2; ++c) {
+        const float* w = pipe_acquire(p) + lane * 4;
+        mma_ktile(acc, X[2 * c], w, full16);
+        mma_ktile(acc, X[2 * c + 1], w + KT_FLOATS, full16);
+    }
+    // X is dead from here: its registers take the softplus' tiles (all loads in flight together), then the products
+#pragma unroll
+    for (int T = 0; T < 16; ++T)
+        if (T < 14 || full16) X[T] = *reinterpret_cast<const f32x4*>(dws_below + T * D_TILE_STRIDE + lane * 16);
+#pragma unroll
+    for (int T = 0; T < 16; ++T)
+        if (T < 14 || full16) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) X[T][r] = acc[T][r] * scale * X[T][r];
+        }
+}
+// E += (W_enc^T g) * scale: the 48 encoding slots (3 output tiles), 16 k tiles in 2 chunks of 8
+__device__ __forceinline__ void run_tail_T(const f32x4 (&X)[XT_MAX], Pipe& p, f32x4 (&E)[3], float scale) {
+    const int lane = lane_id();
+    f32x4 acc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const float* w = pipe_acquire(p) + lane * 4;
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) {
+            f32x4 a[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) a[i] = *reinterpret_cast<const f32x4*>(w + kt * 768 + i * 256);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][r], X[8 * c + kt][r], acc[i], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) E[i][r] += acc[i][r] * scale;
+}
+
+__global__ void __launch_bounds__(WG_THREADS, 2)
+k_sdf_grad(const float* __restrict__ blob, PointSrc src, float R_bg, float* __restrict__ sdf_out,
+           float* __restrict__ nabla_out, float* __restrict__ h7_out, char* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int* hdr = reinterpret_cast<const int*>(blob);
+    float* aux = smem + 2 * CHUNK_FLOATS_MAX;
+    const int lane = lane_id(), g = lane >> 4, j = lane & 15, wv = wave_id();
+    load_aux(aux, blob, hdr, SURF_AUX_FLOATS);
+
+    const unsigned ntiles = (src.M + 127u) / 128u;
+    if (blockIdx.x >= ntiles) return;
+    Pipe p{blob, reinterpret_cast<const int*>(aux + AUX_FLOATS_MAX), smem, hdr[6], 0, 0, 0, 0, false};     // forward + reverse chunks
+    p.wrap = (blockIdx.x + gridDim.x) < ntiles;
+    pipe_start(p);
+    char* dws = ws + (size_t)blockIdx.x * GRADF_WS_PER_WG + wv * 1024;
+    const float rs2 = 0.70710678118654752440f;
+
+    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        p.wrap = (tile + gridDim.x) < ntiles;
+        const unsigned m = tile * 128u + wv * 16 + j;
+        const Pt pt = fetch_point(src, m, false);
+        f32x4 X[XT_MAX];
+        surface_hidden<false, true>(X, pt.x, pt.y, pt.z, g, -1, p, aux, dws);
+        float sdf = dot_row16(X, aux + SURF_AUX_ROW, g) + aux[SURF_AUX_B8];
+        if (m < src.M) {
+            if (R_bg > 0.f) {                           // sdf[d_bg < sdf] = d_bg, nabla untouched (volsdf.py:351-356)
+                const float d_bg = R_bg - sqrtf(pt.x * pt.x + pt.y * pt.y + pt.z * pt.z);
+                sdf = (d_bg < sdf) ? d_bg : sdf;
+            }
+            if (g == 0) sdf_out[m] = sdf;
+            if (h7_out) {
+                float* dst = h7_out + (size_t)m * 256 + g * 4;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) *reinterpret_cast<f32x4*>(dst + t * 16) = X[t];
+            }
+        }
+        // d sdf / d z_7 = row . softplus'(z_7)
+#pragma unroll
+        for (int T = 0; T < 16; ++T) {
+            const f32x4 d = *reinterpret_cast<const f32x4*>(dws + 7 * D_LAYER_STRIDE + T * D_TILE_STRIDE + lane * 16);
+            const f32x4 row = *reinterpret_cast<const f32x4*>(aux + SURF_AUX_ROW + T * 16 + g * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) X[T][r] = row[r] * d[r];
+        }
+        f32x4 E[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) E[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma nounroll
+        for (int L = 7; L >= 5; --L) run_layer_T<16>(X, p, true, dws + (L - 1) * D_LAYER_STRIDE, 1.0f);
+        run_tail_T(X, p, E, rs2);                                                           // layer 4, encoding columns
+        run_layer_T<16>(X, p, false, dws + 3 * D_LAYER_STRIDE, rs2);                        // layer 4, the 217 hidden columns
+        run_layer_T<14>(X, p, true, dws + 2 * D_LAYER_STRIDE, 1.0f);                        // layer 3 (217 outputs = 14 k tiles)
+#pragma nounroll
+        for (int L = 2; L >= 1; --L) run_layer_T<16>(X, p, true, dws + (L - 1) * D_LAYER_STRIDE, 1.0f);
+        run_tail_T(X, p, E, 1.0f);                                                          // layer 0
+        if (nabla_out) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                f32x4 J[3];
+                encode_slots(pt.x, pt.y, pt.z, g, q, J);
+                float a = 0.f;
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a = fmaf(E[t][r], J[t][r], a);
+                a = sum_over_groups(a);
+                if (g == 0 && m < src.M) nabla_out[(size_t)m * 3 + q] = a;
             }
         }
     }
@@ -447,9 +589,20 @@ int radiance_bwd_bf16(const float* blob, long long M, const float* rgb, const fl
 int sdf_grad_bf16(const float* blob, const PointSrc& s, float R_bg, float* sdf, float* nabla, float* h7, void* ws, hipStream_t st);
 void* grad_scratch(hipStream_t st, size_t bytes);
 static int check_precision(int precision, bool allow_fwd_tangents = false) {
-    if (precision == 0 || precision == 1 || (allow_fwd_tangents && precision == 2)) return 0;
+    if (precision == 0 || precision == 1 || (allow_fwd_tangents && (precision == 2 || precision == 3))) return 0;
     set_last_error("precision must be 0 (fp32-exact MFMA) or 1 (split-bf16 'bf16x3' MFMA)");
     return 2;
+}
+// precision 0: reverse-mode kernel; precision 3: the forward-mode tangent quads of k_sdf_nabla (kept for cross-checks - same
+// blob, 2x the matrix work)
+static int sdf_nabla_f32_dispatch(int precision, const float* blob, const PointSrc& s, float R_bg, float* sdf, float* nabla, float* h7,
+                                  hipStream_t st) {
+    const long long M = s.M;
+    if (precision == 3) return launch_chain(1, M, k_sdf_nabla, (unsigned)((M + 31) / 32), st, blob, s, R_bg, sdf, nabla, h7);
+    const unsigned ntiles = (unsigned)((M + 127) / 128);
+    void* ws = grad_scratch(st, (size_t)num_cus() * GRADF_WS_PER_WG);            // launch_chain's grid is at most one workgroup per CU
+    if (!ws) { set_last_error("sdf_nabla_fwd: could not allocate the reverse-mode scratch (256 MiB per stream)"); return 1; }
+    return launch_chain(1, M, k_sdf_grad, ntiles, st, blob, s, R_bg, sdf, nabla, h7, (char*)ws);
 }
 // precision 1: reverse-mode kernel (one column per point); precision 2: the forward-mode tangent quads (kept for
 // cross-checks - same blob, 2.1x the matrix work)
@@ -494,8 +647,8 @@ int nerfart_sdf_nabla_fwd(const float* blob, int precision, const float* pts, lo
     PointSrc s = make_src(pts, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, M);
     if (int rc = validate_src(s)) return rc;
     if (int rc = check_precision(precision, true)) return rc;
-    if (precision >= 1) return sdf_nabla_bf16_dispatch(precision, blob, s, R_bg, sdf_out, nabla_out, h7_out, (hipStream_t)stream);
-    return launch_chain(1, M, k_sdf_nabla, (unsigned)((M + 31) / 32), (hipStream_t)stream, blob, s, R_bg, sdf_out, nabla_out, h7_out);
+    if (precision == 1 || precision == 2) return sdf_nabla_bf16_dispatch(precision, blob, s, R_bg, sdf_out, nabla_out, h7_out, (hipStream_t)stream);
+    return sdf_nabla_f32_dispatch(precision, blob, s, R_bg, sdf_out, nabla_out, h7_out, (hipStream_t)stream);
 }
 
 int nerfart_sdf_nabla_fwd_rays(const float* blob, int precision, const float* rays_o, const float* rays_d, const int* ray_idx,
@@ -507,8 +660,8 @@ int nerfart_sdf_nabla_fwd_rays(const float* blob, int precision, const float* ra
     PointSrc s = make_src(nullptr, nullptr, rays_o, rays_d, ray_idx, depth, n_per_ray, depth_stride, M);
     if (int rc = validate_src(s)) return rc;
     if (int rc = check_precision(precision, true)) return rc;
-    if (precision >= 1) return sdf_nabla_bf16_dispatch(precision, blob, s, R_bg, sdf_out, nabla_out, h7_out, (hipStream_t)stream);
-    return launch_chain(1, M, k_sdf_nabla, (unsigned)((M + 31) / 32), (hipStream_t)stream, blob, s, R_bg, sdf_out, nabla_out, h7_out);
+    if (precision == 1 || precision == 2) return sdf_nabla_bf16_dispatch(precision, blob, s, R_bg, sdf_out, nabla_out, h7_out, (hipStream_t)stream);
+    return sdf_nabla_f32_dispatch(precision, blob, s, R_bg, sdf_out, nabla_out, h7_out, (hipStream_t)stream);
 }
 
 int nerfart_radiance_fwd(const float* blob, int precision, int view_tiles, const float* pts, const float* view, long long M,

@@ -106,6 +106,17 @@ def _ktile_index(midx, t):
     return out.reshape(-1)
 
 
+def _ktile_index_n(midx, t, ntiles):
+    """midx [16 ntiles out slots, K in slots] -> k tile t as [T = ntiles][lane = 64][r = 4] (the reverse sweep's 3-tile tails)."""
+    out = np.empty((ntiles, 64, 4), dtype=np.int64)
+    lane = np.arange(64)
+    g, i = lane // 16, lane % 16
+    for T in range(ntiles):
+        for r in range(4):
+            out[T, :, r] = midx[16 * T + i, 16 * t + 4 * g + r]
+    return out.reshape(-1)
+
+
 def _layer_chunks(midx, nt_base, nt_extra):
     """Chunk sequence of one layer: ceil(nt_base/2) chunks of base k tiles, then ceil(nt_extra/2)
     chunks of extra k tiles (must match run_layer in mlp_chain.hip)."""
@@ -126,22 +137,27 @@ def _pad(a, n, fill=-1):
 
 
 class PackPlan:
-    """Gather plan for one program: ``index`` into the flat source vector, header words."""
+    """Gather plan for one program: ``index`` into the flat source vector, header words.  ``chunks_rev`` (fp32 surface program):
+    the transposed-weight chunks of the reverse sweep, consumed right after the forward ones by k_sdf_grad (header word 6 = the
+    number of chunks of both sweeps; word 2 stays the forward count that k_sdf_only / k_sdf_nabla run)."""
 
-    def __init__(self, prog, flat, chunks, aux):
+    def __init__(self, prog, flat, chunks, aux, chunks_rev=()):
         self.prog = prog
         self.flat = flat
+        chunks = list(chunks) + list(chunks_rev)
         offs = [HDR_INTS]
         for c in chunks:
             offs.append(offs[-1] + len(c))
-        self.nc = len(chunks)
-        assert self.nc + 1 <= 128, "chunk table is 128 entries in the kernel"
+        self.nc = len(chunks) - len(chunks_rev)
+        self.nc_all = len(chunks)
+        assert self.nc_all + 1 <= 128, "chunk table is 128 entries in the kernel"
         self.aux_off = offs[-1]
         self.index = np.concatenate(chunks + [aux])
         self.total = HDR_INTS + len(self.index)
         hdr = np.zeros(HDR_INTS, dtype=np.int32)
         hdr[0], hdr[1], hdr[2], hdr[3], hdr[4], hdr[5] = MAGIC, prog, self.nc, self.total, self.aux_off, len(aux)
-        hdr[HDR_OFFS: HDR_OFFS + self.nc + 1] = offs
+        hdr[6] = self.nc_all
+        hdr[HDR_OFFS: HDR_OFFS + self.nc_all + 1] = offs
         self.header = hdr
         self._index_t = {}
 
@@ -199,7 +215,30 @@ def surface_plan(W: int = 256, D: int = 8, skips=(4,), multires: int = 6, W_geo_
     aux.append(flat.vec_index(f"b{D}", _pad(np.array([0]), 4)))
     aux = np.concatenate(aux)
     assert len(aux) == SURF_AUX_FLOATS
-    return PackPlan(PROG_SURFACE, flat, chunks, aux)
+    # ---- reverse sweep (k_sdf_grad: d sdf / d a_{l-1} = W_l^T (d sdf / d a_l * softplus'(z_l)), l = 7 .. 0) -----------------------
+    # k slots = layer l's OUTPUT features, output slots = its INPUT slots.  Layers whose inputs include the encoding (4: the skip
+    # connection, 0) send those 48 slots through a 3-output-tile "tail" ([T = 3][lane][r] k tiles, 8 per chunk) - in the kernel's
+    # order: 7, 6, 5, tail of 4, 4, 3, 2, 1, tail of 0.
+    def transposed(l, kfeat, ofeat):
+        return flat.mat_index(f"w{l}", kfeat, ofeat).T                         # [out slot, k slot]
+
+    def tail_chunks(midx):                                                      # midx [48, 256]
+        kts = [_ktile_index_n(midx, t, 3) for t in range(midx.shape[1] // 16)]
+        return [np.concatenate(kts[c: c + 8]) for c in range(0, len(kts), 8)]
+
+    rev = []
+    hw = W - enc
+    for l in range(D - 1, 0, -1):
+        out_dim, in_dim = dims[l]
+        kfeat = _pad(ar(out_dim), (out_dim + 15) // 16 * 16)
+        if l in skips:
+            rev += tail_chunks(transposed(l, kfeat, np.where(ENC_SLOTS >= 0, hw + ENC_SLOTS, -1)))
+            ofeat = _pad(ar(hw), 256)
+        else:
+            ofeat = _pad(ar(in_dim), 256)
+        rev += _layer_chunks(transposed(l, kfeat, ofeat), len(kfeat) // 16, 0)
+    rev += tail_chunks(transposed(0, ar(W), ENC_SLOTS))
+    return PackPlan(PROG_SURFACE, flat, chunks, aux, chunks_rev=rev)
 
 
 def radiance_plan(view_tiles: int, W: int = 256, D: int = 4, W_geo_feat: int = 256) -> PackPlan:

@@ -178,6 +178,100 @@ def emul_sdf_nabla(blob_np, pts4, R_bg):
     return sdf, nab, h7
 
 
+# ---- reverse-mode kernel (k_sdf_grad): forward sweep with softplus' kept per layer, then the transposed chunks ----------------
+def run_layer_fwd_d(X, blob, bias, nt_base, nextra, full16):
+    """run_layer(softplus) that also returns softplus'(z) per output tile (what the kernel parks in its scratch)."""
+    acc = [np.zeros((64, 4), np.float32) for _ in range(16)]
+    for c in range((nt_base + 1) // 2):
+        w = blob.acquire()
+        mma_ktile(acc, X[2 * c], w, full16)
+        if 2 * c + 1 < nt_base:
+            mma_ktile(acc, X[2 * c + 1], w[KT:], full16)
+    for c in range((nextra + 1) // 2):
+        w = blob.acquire()
+        mma_ktile(acc, X[nt_base + 2 * c], w, full16)
+    D = [None] * 16
+    for T in range(16 if full16 else 14):
+        z = acc[T] + bias[T * 16 + G[:, None] * 4 + np.arange(4)[None, :]]
+        X[T] = softplus100(z)
+        D[T] = softplus100_grad(z)
+    return D
+
+
+def run_layer_T(X, blob, nt_k, full16, d_below, scale):
+    acc = [np.zeros((64, 4), np.float32) for _ in range(16)]
+    for c in range(nt_k // 2):
+        w = blob.acquire()
+        mma_ktile(acc, X[2 * c], w, full16)
+        mma_ktile(acc, X[2 * c + 1], w[KT:], full16)
+    for T in range(16 if full16 else 14):
+        X[T] = (acc[T] * np.float32(scale) * d_below[T]).astype(np.float32)
+
+
+def run_tail_T(X, blob, E, scale):
+    acc = [np.zeros((64, 4), np.float32) for _ in range(3)]
+    for c in range(2):
+        w = blob.acquire()
+        assert len(w) == 8 * 768
+        for kt in range(8):
+            for i in range(3):
+                a = w[kt * 768 + i * 256: kt * 768 + (i + 1) * 256].reshape(64, 4)
+                for r in range(4):
+                    acc[i] = mfma_16x16x4(a[:, r], X[8 * c + kt][:, r], acc[i])
+    for i in range(3):
+        E[i] = (E[i] + acc[i] * np.float32(scale)).astype(np.float32)
+
+
+def emul_sdf_grad(blob_np, pts16, R_bg):
+    """pts16 [16,3] -> sdf[16], nabla[16,3], h7[16,256] the way k_sdf_grad computes them."""
+    blob = Blob(blob_np)
+    blob.nc = int(blob.hdr[6])                                   # forward + reverse chunks
+    blob.offs = blob.hdr[HDR_OFFS: HDR_OFFS + blob.nc + 1]
+    p = pts16[J].astype(np.float32)
+    q = np.full(64, -1)
+    X = [None] * 19
+    X[0:3] = encode_slots(p, q)
+    D = [None] * 8
+    D[0] = run_layer_fwd_d(X, blob, blob.aux[0:256], 3, 0, True)
+    rs2 = np.float32(1.41421356237309504880)
+    for L in range(1, 8):
+        if L == 4:
+            E = encode_slots(p, q)
+            for t in range(14):
+                X[t] = (X[t] / rs2).astype(np.float32)
+            for t in range(3):
+                X[14 + t] = (E[t] / rs2).astype(np.float32)
+        D[L] = run_layer_fwd_d(X, blob, blob.aux[L * 256:(L + 1) * 256], 16, 1 if L == 4 else 0, L != 3)
+    sdf = dot_row16(X, blob.aux[2048:2304]) + blob.aux[2304]
+    if R_bg > 0:
+        d_bg = R_bg - np.sqrt((p ** 2).sum(1))
+        sdf = np.where(d_bg < sdf, d_bg, sdf)
+    h7 = np.zeros((16, 256), np.float32)
+    for lane in range(64):
+        for t in range(16):
+            h7[J[lane], t * 16 + G[lane] * 4: t * 16 + G[lane] * 4 + 4] = X[t][lane]
+    row = blob.aux[2048:2304]
+    for T in range(16):
+        X[T] = (row[T * 16 + G[:, None] * 4 + np.arange(4)[None, :]] * D[7][T]).astype(np.float32)
+    E = [np.zeros((64, 4), np.float32) for _ in range(3)]
+    inv = np.float32(0.70710678118654752440)
+    for L in (7, 6, 5):
+        run_layer_T(X, blob, 16, True, D[L - 1], 1.0)
+    run_tail_T(X, blob, E, inv)
+    run_layer_T(X, blob, 16, False, D[3], inv)
+    run_layer_T(X, blob, 14, True, D[2], 1.0)
+    for L in (2, 1):
+        run_layer_T(X, blob, 16, True, D[L - 1], 1.0)
+    run_tail_T(X, blob, E, 1.0)
+    assert blob.c == 0, "the reverse sweep must end exactly at the end of the chunk table"
+    nab = np.zeros((16, 3), np.float32)
+    for qq in range(3):
+        Jc = encode_slots(p, np.full(64, qq))
+        a = sum((E[t] * Jc[t]).sum(1) for t in range(3))
+        nab[:, qq] = a.reshape(4, 16).sum(0)
+    return sdf[:16], nab, h7
+
+
 def emul_radiance(blob_np, view_tiles, pts16, view16, nabla16, h7_16):
     """[16,3] x3, h7 [16,256] -> rgb[16,3]"""
     blob = Blob(blob_np)

@@ -120,6 +120,36 @@ def test_sdf_nabla_and_radiance_match_oracle(pts):
     close("feat from h7", feat, nets.surface_forward(sd, p)[1], 1e-4, 1e-4)
 
 
+@pytest.mark.parametrize("M", [1, 100, 128, 1000])
+def test_fp32_reverse_mode_nabla_matches_the_forward_mode_kernel_and_the_oracle(pts, M):
+    """precision 0 = k_sdf_grad (reverse mode, one column per point, transposed chunks of the same blob); precision 3 = the
+    forward-mode tangent quads of k_sdf_nabla.  Both multiply exact fp32 products: they agree to summation order."""
+    nets, _, _ = _oracle()
+    from nerfart_amd import hip
+    model, _, _ = _model()
+    sd, _ = scene_state("VolSDF", 0.01)
+    surf, _ = model.packed()
+    p = pts[0][:M].contiguous()
+    s_ref, n_ref, _ = nets.surface_forward_with_nablas(sd, p)
+    d_bg = 3.0 - p.norm(dim=-1)
+    s_ref = torch.where(d_bg < s_ref, d_bg, s_ref)
+    for rep in range(2):                               # the second call reuses the library's scratch
+        sdf, nab, h7 = hip.sdf_nabla_fwd(surf, p.to(DEV), 3.0, precision=0)
+        close(f"reverse sdf M={M}", sdf, s_ref, 2e-5)
+        close(f"reverse nabla M={M}", nab, n_ref, 2e-4, 2e-4)
+    sdf3, nab3, h73 = hip.sdf_nabla_fwd(surf, p.to(DEV), 3.0, precision=3)
+    close("reverse vs forward-mode sdf", sdf, sdf3.cpu(), 1e-6, 1e-6)
+    close("reverse vs forward-mode nabla", nab, nab3.cpu(), 2e-5, 2e-5)
+    close("reverse vs forward-mode h7", h7, h73.cpu(), 1e-6, 1e-6)
+    if M == 1000:                                      # more tiles than workgroups: every workgroup loops, the chunk stream wraps
+        g = torch.Generator().manual_seed(5)
+        big = (torch.rand(100003, 3, generator=g) * 5 - 2.5).to(DEV)
+        a = hip.sdf_nabla_fwd(surf, big, 3.0, precision=0)
+        b = hip.sdf_nabla_fwd(surf, big, 3.0, precision=3)
+        for name, x, y, tol in (("sdf", a[0], b[0], 1e-6), ("nabla", a[1], b[1], 2e-5), ("h7", a[2], b[2], 1e-6)):
+            close(f"100,003 points: reverse vs forward-mode {name}", x, y.cpu(), tol, tol)
+
+
 def test_neus_point_queries_match_oracle(pts):
     nets, _, _ = _oracle()
     model, _, _ = _model("NeuS", None)

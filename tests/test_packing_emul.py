@@ -30,9 +30,12 @@ def test_blob_header_and_chunk_table():
     for blob, nc in ((surf, 59), (rad, 41)):
         hdr = blob[:512].view(np.int32)
         assert hdr[0] == packing.MAGIC and hdr[2] == nc and hdr[3] == blob.size
-        offs = hdr[16:16 + nc + 1]
+        nall = max(int(hdr[6]), nc)                        # the surface program carries its reverse-sweep chunks behind the forward ones
+        assert (nall == 118) if blob is surf else (nall == nc)
+        offs = hdr[16:16 + nall + 1]
         sizes = np.diff(offs)
-        assert set(sizes.tolist()) <= {4096, 8192} and offs[0] == 512 and offs[-1] == hdr[4]
+        assert set(sizes[:nc].tolist()) <= {4096, 8192} and offs[0] == 512 and offs[-1] == hdr[4]
+        assert set(sizes[nc:].tolist()) <= {8192, 6144}     # 6144: eight 3-tile k tiles of an encoding "tail"
     assert _blobs("NeuS")[2][:512].view(np.int32)[2] == 42
 
 
@@ -59,6 +62,24 @@ def test_emulated_sdf_nabla_matches_oracle():
     np.testing.assert_allclose(sdf, s_ref.numpy(), atol=3e-6, rtol=1e-5)
     np.testing.assert_allclose(nab, n_ref.numpy(), atol=2e-5, rtol=1e-4)
     # h7 -> feature via the last layer's rows 1..256 must give the oracle's geometry feature
+    w8 = nets.folded_weight(sd, "implicit_surface.surface_fc_layers.8").numpy()
+    b8 = sd["implicit_surface.surface_fc_layers.8.bias"].numpy()
+    np.testing.assert_allclose(h7 @ w8[1:].T + b8[1:], feat_ref.numpy(), atol=1e-5, rtol=1e-4)
+
+
+def test_emulated_reverse_mode_sdf_grad_matches_oracle():
+    """k_sdf_grad's data flow (forward sweep keeping softplus', transposed chunks, 3-tile encoding tails, Jacobian of the encoding)
+    on the packed blob, against autograd on the oracle's SDF net."""
+    sd, surf, _, _ = _blobs("VolSDF")
+    g = torch.Generator().manual_seed(12)
+    pts = (torch.rand(16, 3, generator=g) * 4 - 2)
+    pts[:3] *= 0.2
+    sdf, nab, h7 = em.emul_sdf_grad(surf, pts.numpy(), 3.0)
+    s_ref, n_ref, feat_ref = nets.surface_forward_with_nablas(sd, pts)
+    d_bg = 3.0 - pts.norm(dim=-1)
+    s_ref = torch.where(d_bg < s_ref, d_bg, s_ref)
+    np.testing.assert_allclose(sdf, s_ref.numpy(), atol=3e-6, rtol=1e-5)
+    np.testing.assert_allclose(nab, n_ref.numpy(), atol=2e-5, rtol=1e-4)
     w8 = nets.folded_weight(sd, "implicit_surface.surface_fc_layers.8").numpy()
     b8 = sd["implicit_surface.surface_fc_layers.8.bias"].numpy()
     np.testing.assert_allclose(h7 @ w8[1:].T + b8[1:], feat_ref.numpy(), atol=1e-5, rtol=1e-4)
