@@ -181,7 +181,8 @@ def main():
         torch.cuda.synchronize()
         t32 = time.perf_counter() - t1
         secondary["fp32_exact"] = {"value": round(H * W / t32, 1), "unit": "rays/s", "ms_per_step": round(t32 * 1e3, 2), "steps": 1,
-                                   "what": "same frame with --precision fp32 (v_mfma_f32_16x16x4_f32, exact fp32 products)"}
+                                   "what": "same frame with --precision fp32 (v_mfma_f32_16x16x4_f32, exact fp32 products; reverse-mode grad(SDF) kernel)",
+                                   "vs_ref_3090": round(H * W / t32 / 6480.0, 2)}
         del m32, f32
         # the other single-GPU configurations of BASELINE.json, one warm-up + one timed frame each (bench lines of their own: tools/)
         def one_frame(fn, Hh, Ww, **extra):

@@ -14,7 +14,10 @@
  *   - `blob` arguments are weight blobs produced by nerf-art_amd/packing.py (layout documented
  *     there and in DESIGN.md): `surf_blob` = SDF net, `rad_blob` = geometry-feature rows + radiance net.
  *   - `precision` selects the matrix-core path AND the blob format it expects:
- *       0 = fp32-exact (v_mfma_f32_16x16x4_f32; blobs from surface_plan()/radiance_plan()),
+ *       0 = fp32-exact (v_mfma_f32_16x16x4_f32; blobs from surface_plan()/radiance_plan()).  nerfart_sdf_nabla_fwd* runs
+ *           REVERSE mode here too (k_sdf_grad: forward sweep + transposed chunks of the same blob, softplus' parked as fp32 in a
+ *           256 MiB library scratch per (device, stream)); precision 3 (these two entry points only) selects the forward-mode
+ *           tangent quads of k_sdf_nabla on the same blob (cross-checks),
  *       1 = split bf16 "bf16x3" (3 x v_mfma_f32_16x16x32_bf16 per k-step on hi/lo operand splits, ~2^-16
  *           relative per product; blobs from surface_plan_bf16()/radiance_plan_bf16()).  nerfart_sdf_nabla_fwd*
  *           then runs REVERSE mode (forward sweep + transposed-weight sweep in one kernel) and keeps one 117 MiB
