@@ -283,6 +283,12 @@ def test_edge_cases():
     model, rk, render_fn = _model()
     blob, _ = model.packed()
     assert hip.sdf_fwd(blob, torch.zeros(0, 3, device=DEV), 3.0).shape == (0,)
+    s0, n0, h0 = hip.sdf_nabla_fwd(blob, torch.zeros(0, 3, device=DEV), 3.0)
+    assert s0.shape == (0,) and n0.shape == (0, 3) and h0.shape == (0, 256)
+    with pytest.raises(RuntimeError, match="precision"):
+        hip.sdf_nabla_fwd(blob, torch.zeros(4, 3, device=DEV), 3.0, precision=7)
+    with pytest.raises(RuntimeError, match="precision"):
+        hip.sdf_fwd(blob, torch.zeros(4, 3, device=DEV), 3.0, precision=3)      # the forward-mode cross-check exists for nabla only
     o = torch.tensor([[[0.0, 0.0, -2.5]]], device=DEV)
     d = torch.tensor([[[0.0, 0.0, 1.0]]], device=DEV)
     rgb, depth, ex = render_fn(o, d, require_nablas=True, detailed_output=False, **rk)
