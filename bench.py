@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" renders one 480 x 270 frame (129,600 rays, 128 coarse + 64 fine samples per ray, up to 6
-error-bounded up-sampling rounds) of the synthetic VolSDF scene (nerf-art_amd/scene.py: dims of
+error-bounded up-sampling rounds) of the synthetic VolSDF scene (nerfart_amd/scene.py: dims of
 configs/volsdf_fangzhou_nature.yaml, seed 0, geometric init + 2% SDF perturbation, beta = 0.01, radiance
 gain 4) with rays, weights and workspaces already resident in HBM.  With N ranks every rank renders its
 own view per step (views of a camera orbit round-robin over ranks - how the reference's 90-view render

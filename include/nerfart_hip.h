@@ -11,7 +11,7 @@
  *   - `stream` is a hipStream_t (0 = default stream); all work is enqueued on it.  Entry points
  *     with a data-dependent loop (fine_sample, render) synchronise that stream internally.
  *   - return value 0 = success; non-zero = failure, message via nerfart_last_error() (thread local).
- *   - `blob` arguments are weight blobs produced by nerf-art_amd/packing.py (layout documented
+ *   - `blob` arguments are weight blobs produced by nerfart_amd/packing.py (layout documented
  *     there and in DESIGN.md): `surf_blob` = SDF net, `rad_blob` = geometry-feature rows + radiance net.
  *   - `precision` selects the matrix-core path AND the blob format it expects:
  *       0 = fp32-exact (v_mfma_f32_16x16x4_f32; blobs from surface_plan()/radiance_plan()).  nerfart_sdf_nabla_fwd* runs
@@ -75,11 +75,11 @@ int nerfart_radiance_fwd_rays(const float* rad_blob, int precision, int view_til
 /* ---- B2 "bwd", radiance half (row a19; split-bf16 blobs only).  nerfart_radiance_fwd_dump = nerfart_radiance_fwd
  * that also writes the activations of the five layers (geometry feature f, four ReLU outputs r0..r3) into `dump`
  * (nerfart_radiance_dump_bytes(M) bytes): a bf16 matrix [5][Mp][256], Mp = M rounded up to 128, rows = points, the 256
- * features in the kernels' unit order (nerf-art_amd/packing.py: unit_feature_hidden) - GEMM operands, read in place.
+ * features in the kernels' unit order (nerfart_amd/packing.py: unit_feature_hidden) - GEMM operands, read in place.
  * nerfart_radiance_bwd: d loss / d rgb[M,3] -> g_h7[M,256] (cotangent of the SDF net's layer-7 activation through the
  * geometry-feature rows), g_n[M,3] (cotangent of the normal input), and bwd_dump (same layout: the deltas of
  * R0, R1, R2, R3 - each in the slot of the activation it multiplies - and the geometry-feature cotangent): the operands
- * of the weight-gradient GEMMs (dW_l = delta_l^T act_{l-1}, plain library GEMMs; nerf-art_amd/autodiff.py).
+ * of the weight-gradient GEMMs (dW_l = delta_l^T act_{l-1}, plain library GEMMs; nerfart_amd/autodiff.py).
  * At most 2^21 points per call. */
 long long nerfart_radiance_dump_bytes(long long M);
 int nerfart_radiance_fwd_dump(const float* rad_blob, int view_tiles, const float* pts, const float* view, long long M,
@@ -97,7 +97,7 @@ int nerfart_radiance_bwd(const float* rad_blob, long long M, const float* rgb, c
  * Both dumps are matrices [slot][2 Mp][256], Mp = M rounded up to 64: rows 0..Mp-1 of a slot hold the first, rows Mp..
  * the second quantity of the pair, per point; features in unit order; so dW_l is ONE GEMM over the stacked rows, read in
  * place.  At most 2^21 points per call.
- * The GEMMs and the weight_norm chain rule are host side (nerf-art_amd/autodiff.py: surface_weight_grads_raw / _finish). */
+ * The GEMMs and the weight_norm chain rule are host side (nerfart_amd/autodiff.py: surface_weight_grads_raw / _finish). */
 long long nerfart_sdf_fwd2_dump_bytes(long long M);
 long long nerfart_sdf_bwd2_dump_bytes(long long M);
 int nerfart_sdf_fwd2(const float* surf_blob, const float* pts, const float* dir, long long M, void* f2_dump, void* stream);
@@ -207,7 +207,7 @@ int nerfart_neus_render_fwd(const float* surf_blob, const float* rad_blob, int p
  * backward w.r.t. the image (what autograd does there when the style loss is back-propagated, volsdf.py:912-915; the CLIP
  * weights are frozen).  csrc/clip_vit.hip: fp16 weights / GEMM operands on v_mfma_f32_32x32x16_f16, fp32 accumulation,
  * LayerNorm / softmax / residual stream in fp32.
- *   blob      : the `visual.*` parameters packed by nerf-art_amd/clip_native.py in the section order
+ *   blob      : the `visual.*` parameters packed by nerfart_amd/clip_native.py in the section order
  *               nerfart_clip_vitb32_blob_layout() reports (offsets[203] in bytes, last = total size; returns the total):
  *               fp16 matrices and their transposes (0 conv1, 2 + 8 l + j the four linear maps of block l, 98 proj), then
  *               fp32 vectors (100 class / positional embeddings, LayerNorm parameters, biases) - list in csrc/clip_vit.hip.
@@ -265,7 +265,7 @@ int nerfart_sphere_trace_step(const float* sdf, int n_rays, const float* far, fl
 
 /* ---- VGG16 perceptual term (criteria/perp_loss.py:9-57): torchvision vgg16.features[:16] (through relu3_3) as
  * implicit-GEMM 3 x 3 convolutions on v_mfma_f32_32x32x16_f16 (csrc/vgg_conv.hip), L1 between prediction and target features.
- *   blob : nerfart_vgg16_blob_layout() sections (offsets[22] bytes; packed by nerf-art_amd/vgg.py): per conv l = 0..6 forward
+ *   blob : nerfart_vgg16_blob_layout() sections (offsets[22] bytes; packed by nerfart_amd/vgg.py): per conv l = 0..6 forward
  *          weights, backward (tap-flipped, channel-transposed) weights, bias.
  *   img2 : [2, 3, H, W] fp32 = the ImageNet-normalised, resized prediction then target (perp_loss.py:41-45); H, W multiples of 4,
  *          H W / 16 a multiple of 64 (224 x 224 in the reference).

@@ -1,13 +1,13 @@
-"""Import shim: ``import nerfart_amd`` resolves to the sources in ``nerf-art_amd/``.
+"""nerfart_amd: MI355X-native hot path of cassiePython/NeRF-Art.
 
-The product directory carries the reference's name (``nerf-art_amd``), which is not a
-valid Python identifier; this package simply points its ``__path__`` there.
+Scope: the VolSDF / NeuS volumetric renderer - ray generation,
+error-bounded hierarchical sampling, positional encoding, the SDF and radiance MLPs with
+SDF normals, sigma/alpha compositing - as hand-written HIP kernels for gfx950 behind a
+C-ABI shared library (include/nerfart_hip.h), with a PyTorch-ROCm host that mirrors the
+reference's call shapes (render_fn / model.forward / model.forward_surface), YAML configs
+and checkpoint key layout.
+
+The compute path is the HIP library only: there is no CPU or eager-PyTorch fallback, and
+nothing in this package imports ``oracle/``.
 """
-import os as _os
-
-_here = _os.path.dirname(_os.path.abspath(__file__))
-_src = _os.path.join(_os.path.dirname(_here), "nerf-art_amd")
-__path__ = [_src]
-with open(_os.path.join(_src, "__init__.py")) as _f:
-    exec(compile(_f.read(), _os.path.join(_src, "__init__.py"), "exec"))
-del _f
+__version__ = "0.1.0"

@@ -2,7 +2,7 @@
 
     python -m nerfart_amd.build          # or: from nerfart_amd.build import build; build()
 
-Sources live in nerf-art_amd/csrc; objects go to csrc/_build, the library to
+Sources live in nerfart_amd/csrc; objects go to csrc/_build, the library to
 csrc/libnerfart_hip.so (git-ignored, travels to the GPU box with the snapshot).
 hipcc cross-compiles for gfx950 without a GPU present.
 """

@@ -149,6 +149,6 @@ def load_config(args, unknown, base_config_path=None) -> ConfigDict:
     other.pop("resume_dir", None)
     config.update(other)
     # device_ids: the reference spreads one process over GPUs with nn.DataParallel; here every process
-    # owns exactly one GPU (LOCAL_RANK) and rays are sharded across processes (nerf-art_amd/dist.py).
+    # owns exactly one GPU (LOCAL_RANK) and rays are sharded across processes (nerfart_amd/dist.py).
     config.device_ids = [int(os.environ.get("LOCAL_RANK", 0))]
     return config

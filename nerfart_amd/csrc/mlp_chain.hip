@@ -10,7 +10,7 @@
 //     B = activation (a REGISTER of the previous layer's output).  The C layout of the 16x16x4
 //     MFMA (lane (g,j), reg r  <->  feature 16t+4g+r of column j) is, up to a fixed permutation of
 //     k, the B layout of the next layer, so activations never leave registers between layers; the
-//     permutation is folded into the weight packing (nerf-art_amd/packing.py).
+//     permutation is folded into the weight packing (nerfart_amd/packing.py).
 //   * a workgroup is 8 waves x 16 columns = 128 columns per tile; weights stream L2 -> LDS in
 //     "chunks" (two 16-wide k tiles x all 16 output tiles = 32 KiB) with LDS-DMA, double buffered,
 //     one barrier per chunk; the weight blob (2.4 MB fp32) stays L2 resident on every XCD.

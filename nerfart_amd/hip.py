@@ -18,7 +18,7 @@ if not os.path.exists(LIB_PATH):
     raise ImportError(
         f"{LIB_PATH} not found: build the gfx950 kernels first "
         f"(python -c 'import __graft_entry__ as g; g.build()'  or  python -m nerfart_amd.build). "
-        f"nerf-art_amd has no CPU / eager-PyTorch fallback.")
+        f"nerfart_amd has no CPU / eager-PyTorch fallback.")
 
 lib = C.CDLL(LIB_PATH)
 
@@ -117,7 +117,7 @@ def _dev(t: torch.Tensor, dtype=torch.float32, name="tensor") -> int:
     if t is None:
         return None
     if not t.is_cuda:
-        raise NerfartHipError(f"{name} must live on the GPU (got {t.device}); nerf-art_amd has no CPU path")
+        raise NerfartHipError(f"{name} must live on the GPU (got {t.device}); nerfart_amd has no CPU path")
     if t.dtype != dtype:
         raise NerfartHipError(f"{name} must be {dtype} (got {t.dtype})")
     if not t.is_contiguous():

@@ -85,7 +85,7 @@ class SingleRenderer(nn.Module):
 
 
 def get_model(args, render_target=None):
-    """(volsdf.py:943-994) args: the YAML config as an attribute dict (nerf-art_amd/config.py).
+    """(volsdf.py:943-994) args: the YAML config as an attribute dict (nerfart_amd/config.py).
     Returns (model, trainer, render_kwargs_train, render_kwargs_test, render_fn).  trainer = trainer.Trainer with
     `render_fn` set; its `style_loss` (criteria.StyleLoss: needs the CLIP / VGG checkpoints and tokenizer) is the caller's to
     set before fine-tuning - the reference loads them inside Trainer.__init__ (volsdf.py:638-645)."""

@@ -7,7 +7,7 @@ file:line it follows.  It exists to *check* the HIP path, never to be it:
 
   * only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
     leg of ``bench.py`` may import it;
-  * nothing under ``nerf-art_amd/`` imports it (tests/test_boundary.py
+  * nothing under ``nerfart_amd/`` imports it (tests/test_boundary.py
     greps for that);
   * it is pinned against golden vectors captured from the real reference
     running in the build container (``tests/golden/make_golden.py`` ->

@@ -8,7 +8,7 @@ non-arithmetic dependencies of the reference (cv2, addict, imageio, skimage, ply
 clip, tensorboard) are stubbed - none of them carries renderer arithmetic.
 
 Full-width network weights are not stored: they are regenerated from seeds by the package's own
-initialiser (nerf-art_amd/nets.py + scene.py), which this script first proves identical to the
+initialiser (nerfart_amd/nets.py + scene.py), which this script first proves identical to the
 reference's initialiser (same RNG calls -> bit-identical state dict); a checksum of every state is
 stored so a drifting RNG would be detected rather than silently compared.
 """

@@ -16,7 +16,7 @@ def _py_files(root):
 
 def test_package_does_not_import_oracle_or_reference():
     pat = re.compile(r"^\s*(from|import)\s+oracle\b|/root/reference", re.M)
-    for root in (os.path.join(REPO, "nerf-art_amd"), os.path.join(REPO, "nerfart_amd")):
+    for root in (os.path.join(REPO, "nerfart_amd"),):
         for p in _py_files(root):
             assert not pat.search(open(p).read()), f"{p} references the oracle / the reference tree"
 
@@ -29,7 +29,7 @@ def test_runtime_files_do_not_read_reference_tree():
 
 
 def test_hip_module_has_no_fallback_branch():
-    src = open(os.path.join(REPO, "nerf-art_amd", "hip.py")).read()
+    src = open(os.path.join(REPO, "nerfart_amd", "hip.py")).read()
     assert "raise ImportError" in src and "fallback" in src
-    nets = open(os.path.join(REPO, "nerf-art_amd", "nets.py")).read()
+    nets = open(os.path.join(REPO, "nerfart_amd", "nets.py")).read()
     assert "F.linear" not in nets and "softplus" not in nets, "nets.py must not carry an eager compute path"

@@ -4,7 +4,7 @@
 construction - this only attributes time.   build:  python tools/ablate_bf16.py build ;  run (GPU): ... run"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CSRC = os.path.join(ROOT, "nerf-art_amd", "csrc")
+CSRC = os.path.join(ROOT, "nerfart_amd", "csrc")
 VARIANTS = {"full": [], "nodma": ["-DNERFART_ABLATE_DMA"], "noepi": ["-DNERFART_ABLATE_EPI"], "nomfma": ["-DNERFART_ABLATE_MFMA"],
             "nodma_noepi": ["-DNERFART_ABLATE_DMA", "-DNERFART_ABLATE_EPI"], "noldsread": ["-DNERFART_ABLATE_LDSREAD"],
             "mfma_only": ["-DNERFART_ABLATE_DMA", "-DNERFART_ABLATE_EPI", "-DNERFART_ABLATE_LDSREAD"],

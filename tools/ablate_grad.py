@@ -4,7 +4,7 @@ the scratch loads / stores (results WRONG by construction - timing only) against
     python tools/ablate_grad.py build   (here)   /   run   (on the GPU box)"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CSRC = os.path.join(ROOT, "nerf-art_amd", "csrc")
+CSRC = os.path.join(ROOT, "nerfart_amd", "csrc")
 OUT = os.path.join(ROOT, "gpurun_ablate")
 
 

@@ -3,7 +3,7 @@
 construction - this only attributes time).   python tools/ablate_w32.py build   (here)  /  run   (on the GPU box)"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CSRC = os.path.join(ROOT, "nerf-art_amd", "csrc")
+CSRC = os.path.join(ROOT, "nerfart_amd", "csrc")
 OUT = os.path.join(ROOT, "gpurun_ablate")
 VARIANTS = {"full": [], "nodma": ["-DW32_NO_DMA"], "nomfma": ["-DW32_NO_MFMA"], "noepi": ["-DW32_NO_EPI"], "nolds": ["-DW32_NO_LDS"],
             "mfma_only": ["-DW32_NO_DMA", "-DW32_NO_EPI", "-DW32_NO_LDS"], "nomfma_nodma": ["-DW32_NO_MFMA", "-DW32_NO_DMA"],

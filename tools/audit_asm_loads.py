@@ -8,7 +8,7 @@ Straight-line only: a branch or label between a read and its first use is report
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CSRC = os.path.join(ROOT, "nerf-art_amd", "csrc")
+CSRC = os.path.join(ROOT, "nerfart_amd", "csrc")
 REG = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")
 
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Writes nerf-art_amd/data/prompt_templates.txt: the 79 prompt templates the reference's style losses average text
+"""Writes nerfart_amd/data/prompt_templates.txt: the 79 prompt templates the reference's style losses average text
 features over (the list `imagenet_templates` in criteria/clip_loss.py:6-87, contrastive_loss.py, patchnce_loss.py -
 OpenAI CLIP's published ImageNet prompt-engineering list).  DATA, one template per line; read where the reference
 lies, build container only:    python tools/make_prompt_templates.py
@@ -8,7 +8,7 @@ import ast
 import os
 
 SRC = "/root/reference/criteria/clip_loss.py"
-DST = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nerf-art_amd", "data", "prompt_templates.txt")
+DST = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nerfart_amd", "data", "prompt_templates.txt")
 
 tree = ast.parse(open(SRC).read())
 templates = next(ast.literal_eval(n.value) for n in tree.body

@@ -4,7 +4,7 @@ inside a double item, ...), each timed on 4 M points and checked against the def
    python tools/sweep_w32.py build   (here)   /   python tools/sweep_w32.py run   (on the GPU box)"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CSRC = os.path.join(ROOT, "nerf-art_amd", "csrc")
+CSRC = os.path.join(ROOT, "nerfart_amd", "csrc")
 OUT = os.path.join(ROOT, "gpurun_ablate")
 VARIANTS = {f"dma_at_{k}": [f"-DW32_DMA_AT={k}"] for k in range(12)}
 VARIANTS.update(json.loads(os.environ.get("W32_EXTRA", "{}")))
