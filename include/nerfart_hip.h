@@ -264,9 +264,10 @@ int nerfart_root_finish(const float* rays_o, const float* rays_dn, int n_rays, c
 int nerfart_sphere_trace_step(const float* sdf, int n_rays, const float* far, float far_s, float* d, unsigned char* mask, void* stream);
 
 /* ---- VGG16 perceptual term (criteria/perp_loss.py:9-57): torchvision vgg16.features[:16] (through relu3_3) as
- * implicit-GEMM 3 x 3 convolutions on v_mfma_f32_32x32x16_f16 (csrc/vgg_conv.hip), L1 between prediction and target features.
+ * implicit-GEMM 3 x 3 convolutions on v_mfma_f32_32x32x2_f32 (fp32 operands as the reference's net; csrc/vgg_conv.hip), L1
+ * between prediction and target features.
  *   blob : nerfart_vgg16_blob_layout() sections (offsets[22] bytes; packed by nerfart_amd/vgg.py): per conv l = 0..6 forward
- *          weights, backward (tap-flipped, channel-transposed) weights, bias.
+ *          weights, backward (tap-flipped, channel-transposed) weights, bias - all fp32.
  *   img2 : [2, 3, H, W] fp32 = the ImageNet-normalised, resized prediction then target (perp_loss.py:41-45); H, W multiples of 4,
  *          H W / 16 a multiple of 64 (224 x 224 in the reference).
  * nerfart_vgg16_l1_fwd writes loss_out[0] (device) = mean |relu3_3(pred) - relu3_3(target)|; with keep_for_bwd the workspace

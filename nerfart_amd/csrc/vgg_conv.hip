@@ -2,20 +2,20 @@
 // conv stack through relu3_3 on the matrix cores, L1 between the prediction's and the target's features, and the backward pass
 // to the prediction's pixels (the VGG weights are frozen).
 //
-//   conv1_1 (3 -> 64): explicit im2col of the 3-channel input (27 -> 64 columns) + GEMM
-//   the other six 3 x 3 convolutions: IMPLICIT GEMM (gemm_f16.h, A_CONV3) on NHWC fp16 activations, bias + ReLU fused;
+//   conv1_1 (3 -> 64): explicit im2col of the 3-channel input (27 -> 32 columns) + GEMM
+//   the other six 3 x 3 convolutions: IMPLICIT GEMM (gemm_f32.h, A_CONV3) on NHWC fp32 activations, bias + ReLU fused;
 //   2 x 2 max-pools in between; backward = the same kernel on tap-flipped, channel-transposed weights with the ReLU mask of the
 //   layer below fused into the epilogue, un-pooling fused with the mask, col2im gather for conv1_1.
-// fp16 operands / fp32 accumulation (the reference runs torchvision's fp32 VGG: ~1e-3 relative on the features).  The backward
-// chain starts from sign(f_pred - f_target) in {-1, 0, 1} (exact in fp16); the 1 / N of the mean and the upstream cotangent are
-// applied to the pixel gradient in fp32.
-#include "gemm_f16.h"
+// fp32 operands on v_mfma_f32_32x32x2_f32 (round 3; fp16 operands before): the reference runs torchvision's fp32 VGG, and the
+// pixel gradient of this term is piecewise constant in the ReLU / max-pool / sign decisions - half-precision activations flipped
+// ~1e-3 of them (gradient 6e-2 off the reference's; now at the level the reference itself moves between thread counts).
+#include "gemm_f32.h"
 #include <cmath>
 
 namespace nerfart {
 namespace vgg {
 
-using namespace nerfart::gemm16;
+using namespace nerfart::gemm32;
 
 constexpr int NCONV = 7;
 static const int CIN[NCONV] = {3, 64, 64, 128, 128, 256, 256};
@@ -23,15 +23,15 @@ static const int COUT[NCONV] = {64, 64, 128, 128, 256, 256, 256};
 // resolution level of each conv's input / output: 0 = H x W, 1 = / 2, 2 = / 4 (a 2 x 2 max-pool precedes convs 2 and 4)
 static const int LEVEL[NCONV] = {0, 0, 1, 1, 2, 2, 2};
 
-// blob sections (256-byte aligned): 3 l + 0: forward weights fp16 [Cout, Kf] (l = 0: Kf = 64, column c 9 + ky 3 + kx < 27;
-// l > 0: Kf = 9 Cin, column (ky 3 + kx) Cin + c);  3 l + 1: backward weights fp16 (l = 0: [64, 64], row k < 27 = W[:, k]^T;
-// l > 0: [Cin, 9 Cout], column (ky' 3 + kx') Cout + o = W[o, c, 2 - ky', 2 - kx']);  3 l + 2: bias fp32 [Cout].
+// blob sections (256-byte aligned), all fp32: 3 l + 0: forward weights [Cout, Kf] (l = 0: Kf = 32, column c 9 + ky 3 + kx < 27;
+// l > 0: Kf = 9 Cin, column (ky 3 + kx) Cin + c);  3 l + 1: backward weights (l = 0: [64, 64], row k < 27 = W[:, k]^T;
+// l > 0: [Cin, 9 Cout], column (ky' 3 + kx') Cout + o = W[o, c, 2 - ky', 2 - kx']);  3 l + 2: bias [Cout].
 constexpr int N_SECTIONS = 3 * NCONV;
 static long long section_bytes(int i) {
     const int l = i / 3, j = i % 3;
     if (j == 2) return 4LL * COUT[l];
-    if (l == 0) return 2LL * 64 * 64;
-    return 2LL * 9 * CIN[l] * COUT[l];
+    if (l == 0) return 4LL * 64 * (j == 0 ? 32 : 64);
+    return 4LL * 9 * CIN[l] * COUT[l];
 }
 static long long blob_layout(long long* offs) {
     long long o = 0;
@@ -43,12 +43,12 @@ static long long blob_layout(long long* offs) {
     return o;
 }
 
-// img [B, 3, H, W] fp32 -> cols fp16 [B H W, 64]
-__global__ __launch_bounds__(256) void k_im2col_c3(const float* __restrict__ img, half_t* __restrict__ cols, int B, int H, int W) {
-    const long long total = (long long)B * H * W * 64;
+// img [B, 3, H, W] fp32 -> cols fp32 [B H W, 32]
+__global__ __launch_bounds__(256) void k_im2col_c3(const float* __restrict__ img, float* __restrict__ cols, int B, int H, int W) {
+    const long long total = (long long)B * H * W * 32;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int k = (int)(i & 63);
-        const long long m = i >> 6;
+        const int k = (int)(i & 31);
+        const long long m = i >> 5;
         float v = 0.f;
         if (k < 27) {
             const int c = k / 9, ky = (k % 9) / 3, kx = k % 3;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_im2col_c3(const float* __restrict__ img
             const int yy = y + ky - 1, xx = x + kx - 1;
             if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = img[(((size_t)b * 3 + c) * H + yy) * W + xx];
         }
-        cols[i] = (half_t)v;
+        cols[i] = v;
     }
 }
 // dcols fp32 [H W, 64] -> g_img [3, H, W] = scale * sum over the 9 windows that contain the pixel
@@ -76,58 +76,55 @@ __global__ __launch_bounds__(256) void k_col2im_c3(const float* __restrict__ dco
         g_img[i] = v * s;
     }
 }
-// NHWC fp16 [B, H, W, C] -> [B, H/2, W/2, C]; 8 channels per thread
-__global__ __launch_bounds__(256) void k_maxpool2(const half_t* __restrict__ x, half_t* __restrict__ y, int B, int H, int W, int C) {
-    const int Ho = H / 2, Wo = W / 2, C8 = C / 8;
-    const long long total = (long long)B * Ho * Wo * C8;
+// NHWC fp32 [B, H, W, C] -> [B, H/2, W/2, C]; 4 channels per thread
+__global__ __launch_bounds__(256) void k_maxpool2(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
+    const long long total = (long long)B * Ho * Wo * C4;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int c8 = (int)(i % C8), ox = (int)((i / C8) % Wo), oy = (int)((i / ((long long)C8 * Wo)) % Ho), b = (int)(i / ((long long)C8 * Wo * Ho));
-        const half_t* p = x + (((size_t)b * H + 2 * oy) * W + 2 * ox) * C + c8 * 8;
-        const half8 a = *reinterpret_cast<const half8*>(p), bb = *reinterpret_cast<const half8*>(p + C);
-        const half8 c = *reinterpret_cast<const half8*>(p + (size_t)W * C), d = *reinterpret_cast<const half8*>(p + (size_t)W * C + C);
-        half8 o;
+        const int c4 = (int)(i % C4), ox = (int)((i / C4) % Wo), oy = (int)((i / ((long long)C4 * Wo)) % Ho), b = (int)(i / ((long long)C4 * Wo * Ho));
+        const float* p = x + (((size_t)b * H + 2 * oy) * W + 2 * ox) * C + c4 * 4;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p), bb = *reinterpret_cast<const f32x4*>(p + C);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(p + (size_t)W * C), d = *reinterpret_cast<const f32x4*>(p + (size_t)W * C + C);
+        f32x4 o;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float m = fmaxf(fmaxf((float)a[k], (float)bb[k]), fmaxf((float)c[k], (float)d[k]));
-            o[k] = (half_t)m;
-        }
-        *reinterpret_cast<half8*>(y + i * 8) = o;
+        for (int k = 0; k < 4; ++k) o[k] = fmaxf(fmaxf(a[k], bb[k]), fmaxf(c[k], d[k]));
+        *reinterpret_cast<f32x4*>(y + i * 4) = o;
     }
 }
 // g [B, H/2, W/2, C] -> dz [B, H, W, C]: to the window's first maximum (row-major scan, as torch), times [y > 0] (the ReLU below)
-__global__ __launch_bounds__(256) void k_unpool2_relu(const half_t* __restrict__ g, const half_t* __restrict__ yact, half_t* __restrict__ dz,
+__global__ __launch_bounds__(256) void k_unpool2_relu(const float* __restrict__ g, const float* __restrict__ yact, float* __restrict__ dz,
                                                      int B, int H, int W, int C) {
-    const int Ho = H / 2, Wo = W / 2, C8 = C / 8;
-    const long long total = (long long)B * Ho * Wo * C8;
+    const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
+    const long long total = (long long)B * Ho * Wo * C4;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int c8 = (int)(i % C8), ox = (int)((i / C8) % Wo), oy = (int)((i / ((long long)C8 * Wo)) % Ho), b = (int)(i / ((long long)C8 * Wo * Ho));
-        const size_t p0 = (((size_t)b * H + 2 * oy) * W + 2 * ox) * C + c8 * 8;
+        const int c4 = (int)(i % C4), ox = (int)((i / C4) % Wo), oy = (int)((i / ((long long)C4 * Wo)) % Ho), b = (int)(i / ((long long)C4 * Wo * Ho));
+        const size_t p0 = (((size_t)b * H + 2 * oy) * W + 2 * ox) * C + c4 * 4;
         const size_t offs[4] = {p0, p0 + C, p0 + (size_t)W * C, p0 + (size_t)W * C + C};
-        half8 v[4], o[4];
+        f32x4 v[4], o[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const half8*>(yact + offs[q]);
-        const half8 gg = *reinterpret_cast<const half8*>(g + i * 8);
+        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4*>(yact + offs[q]);
+        const f32x4 gg = *reinterpret_cast<const f32x4*>(g + i * 4);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 4; ++k) {
             int best = 0;
-            float m = (float)v[0][k];
+            float m = v[0][k];
 #pragma unroll
-            for (int q = 1; q < 4; ++q) if ((float)v[q][k] > m) { m = (float)v[q][k]; best = q; }
+            for (int q = 1; q < 4; ++q) if (v[q][k] > m) { m = v[q][k]; best = q; }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o[q][k] = (q == best && m > 0.f) ? gg[k] : (half_t)0.f;
+            for (int q = 0; q < 4; ++q) o[q][k] = (q == best && m > 0.f) ? gg[k] : 0.f;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<half8*>(dz + offs[q]) = o[q];
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(dz + offs[q]) = o[q];
     }
 }
-// f [2 n] fp16 (prediction's features, then the target's): loss[0] += sum |fp - ft| / n;  g [n] = sign(fp - ft) [fp > 0]
-__global__ __launch_bounds__(256) void k_l1_sign(const half_t* __restrict__ f, long long n, float* __restrict__ loss, half_t* __restrict__ g) {
+// f [2 n] (prediction's features, then the target's): loss[0] += sum |fp - ft| / n;  g [n] = sign(fp - ft) [fp > 0]
+__global__ __launch_bounds__(256) void k_l1_sign(const float* __restrict__ f, long long n, float* __restrict__ loss, float* __restrict__ g) {
     __shared__ float red[4];
     float acc = 0.f;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const float a = (float)f[i], b = (float)f[n + i], d = a - b;
+        const float a = f[i], b = f[n + i], d = a - b;
         acc += fabsf(d);
-        if (g) g[i] = (half_t)((a > 0.f) ? ((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f)) : 0.f);
+        if (g) g[i] = (a > 0.f) ? ((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f)) : 0.f;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
@@ -150,13 +147,13 @@ static Work work_layout(int H, int W, int keep) {
     long long o = 0;
     auto take = [&](long long b) { const long long at = o; o += up(b, 256); return at; };
     w.o_loss = take(256);
-    w.o_cols = take(2 * w.M[0] * 64);
-    for (int l = 0; l < NCONV; ++l) w.o_y[l] = take(2 * w.M[LEVEL[l]] * COUT[l]);
-    w.o_p[0] = take(2 * w.M[1] * 64);
-    w.o_p[1] = take(2 * w.M[2] * 128);
-    // backward ping-pong buffers (prediction only: half the rows), sized for the largest cotangent (H W x 64 halfs)
-    w.o_ga = take(keep ? 2 * (w.M[0] / 2) * 64 : 0);
-    w.o_gb = take(keep ? 2 * (w.M[0] / 2) * 64 : 0);
+    w.o_cols = take(4 * w.M[0] * 32);
+    for (int l = 0; l < NCONV; ++l) w.o_y[l] = take(4 * w.M[LEVEL[l]] * COUT[l]);
+    w.o_p[0] = take(4 * w.M[1] * 64);
+    w.o_p[1] = take(4 * w.M[2] * 128);
+    // backward ping-pong buffers (prediction only: half the rows), sized for the largest cotangent (H W x 64 floats)
+    w.o_ga = take(keep ? 4 * (w.M[0] / 2) * 64 : 0);
+    w.o_gb = take(keep ? 4 * (w.M[0] / 2) * 64 : 0);
     w.o_dcols = take(keep ? 4 * (w.M[0] / 2) * 64 : 0);
     w.total = o;
     return w;
@@ -194,28 +191,28 @@ int nerfart_vgg16_l1_fwd(const void* blob, const float* img2, int H, int W, floa
     char* ws = (char*)workspace;
     float* loss = (float*)(ws + w.o_loss);
     NERFART_HIP(hipMemsetAsync(loss, 0, 256, st));
-    half_t* cols = (half_t*)(ws + w.o_cols);
-    hipLaunchKernelGGL(k_im2col_c3, dim3(grid_for(w.M[0] * 64)), dim3(256), 0, st, img2, cols, 2, H, W);
-    const half_t* x = cols;
+    float* cols = (float*)(ws + w.o_cols);
+    hipLaunchKernelGGL(k_im2col_c3, dim3(grid_for(w.M[0] * 32)), dim3(256), 0, st, img2, cols, 2, H, W);
+    const float* x = cols;
     int h = H, wd = W;
     for (int l = 0; l < NCONV; ++l) {
-        half_t* y = (half_t*)(ws + w.o_y[l]);
+        float* y = (float*)(ws + w.o_y[l]);
         if (l == 2 || l == 4) {                                    // max-pool in front of conv2_1 / conv3_1
-            half_t* p = (half_t*)(ws + w.o_p[l == 2 ? 0 : 1]);
-            hipLaunchKernelGGL(k_maxpool2, dim3(grid_for(w.M[LEVEL[l]] * CIN[l] / 8)), dim3(256), 0, st, x, p, 2, h, wd, CIN[l]);
+            float* p = (float*)(ws + w.o_p[l == 2 ? 0 : 1]);
+            hipLaunchKernelGGL(k_maxpool2, dim3(grid_for(w.M[LEVEL[l]] * CIN[l] / 4)), dim3(256), 0, st, x, p, 2, h, wd, CIN[l]);
             x = p; h /= 2; wd /= 2;
         }
         Epi e{};
-        e.bias = (const float*)(bl + off[3 * l + 2]); e.out_f16 = y; e.ldo = COUT[l]; e.m_valid = (int)w.M[LEVEL[l]];
+        e.bias = (const float*)(bl + off[3 * l + 2]); e.out = y; e.ldo = COUT[l]; e.m_valid = (int)w.M[LEVEL[l]];
         e.cH = h; e.cW = wd; e.cC = CIN[l];
-        const half_t* Wf = (const half_t*)(bl + off[3 * l]);
-        const int rc = (l == 0) ? gemm<EPI_BIAS_RELU_F16, A_F16>(st, x, 64, Wf, (int)w.M[0], 64, 64, e)
-                                : gemm<EPI_BIAS_RELU_F16, A_CONV3>(st, x, 0, Wf, (int)w.M[LEVEL[l]], COUT[l], 9 * CIN[l], e);
+        const float* Wf = (const float*)(bl + off[3 * l]);
+        const int rc = (l == 0) ? gemm<EPI_BIAS_RELU, A_MAT>(st, x, 32, Wf, (int)w.M[0], 64, 32, e)
+                                : gemm<EPI_BIAS_RELU, A_CONV3>(st, x, 0, Wf, (int)w.M[LEVEL[l]], COUT[l], 9 * CIN[l], e);
         if (rc) return 1;
         x = y;
     }
     const long long n = (w.M[2] / 2) * 256;
-    hipLaunchKernelGGL(k_l1_sign, dim3(grid_for(n)), dim3(256), 0, st, x, n, loss, keep_for_bwd ? (half_t*)(ws + w.o_ga) : (half_t*)nullptr);
+    hipLaunchKernelGGL(k_l1_sign, dim3(grid_for(n)), dim3(256), 0, st, x, n, loss, keep_for_bwd ? (float*)(ws + w.o_ga) : (float*)nullptr);
     NERFART_HIP(hipMemcpyAsync(loss_out, loss, sizeof(float), hipMemcpyDeviceToDevice, st));
     NERFART_HIP(hipGetLastError());
     return 0;
@@ -233,35 +230,35 @@ int nerfart_vgg16_l1_bwd(const void* blob, int H, int W, const float* upstream, 
     char* ws = (char*)workspace;
     float* scale = (float*)(ws + w.o_loss) + 8;
     hipLaunchKernelGGL(k_set_scale, dim3(1), dim3(1), 0, st, scale, upstream, 1.0f / (float)((w.M[2] / 2) * 256));
-    half_t* ga = (half_t*)(ws + w.o_ga);                           // holds sign * mask of relu3_3 (written by the forward)
-    half_t* gb = (half_t*)(ws + w.o_gb);
+    float* ga = (float*)(ws + w.o_ga);                             // holds sign * mask of relu3_3 (written by the forward)
+    float* gb = (float*)(ws + w.o_gb);
     int h = H / 4, wd = W / 4;
     for (int l = NCONV - 1; l >= 1; --l) {
         // cotangent of conv l's output (already masked by its ReLU) -> cotangent of its input
         const long long Mi = w.M[LEVEL[l]] / 2;
         Epi e{};
-        e.out_f16 = gb; e.ldo = CIN[l]; e.m_valid = (int)Mi; e.cH = h; e.cW = wd; e.cC = COUT[l];
-        const half_t* Wb = (const half_t*)(bl + off[3 * l + 1]);
+        e.out = gb; e.ldo = CIN[l]; e.m_valid = (int)Mi; e.cH = h; e.cW = wd; e.cC = COUT[l];
+        const float* Wb = (const float*)(bl + off[3 * l + 1]);
         const bool pooled_input = (l == 2 || l == 4);
         int rc;
         if (pooled_input) {
-            rc = gemm<EPI_F16, A_CONV3>(st, ga, 0, Wb, (int)Mi, CIN[l], 9 * COUT[l], e);
+            rc = gemm<EPI_PLAIN, A_CONV3>(st, ga, 0, Wb, (int)Mi, CIN[l], 9 * COUT[l], e);
         } else {
-            e.aux_f16 = (const half_t*)(ws + w.o_y[l - 1]);        // prediction rows come first in every activation buffer
-            rc = gemm<EPI_RELUMASK_F16, A_CONV3>(st, ga, 0, Wb, (int)Mi, CIN[l], 9 * COUT[l], e);
+            e.aux = (const float*)(ws + w.o_y[l - 1]);             // prediction rows come first in every activation buffer
+            rc = gemm<EPI_RELUMASK, A_CONV3>(st, ga, 0, Wb, (int)Mi, CIN[l], 9 * COUT[l], e);
         }
         if (rc) return 1;
         if (pooled_input) {                                        // un-pool into the activation below and apply its ReLU mask
             h *= 2; wd *= 2;
-            hipLaunchKernelGGL(k_unpool2_relu, dim3(grid_for(Mi * CIN[l] / 8)), dim3(256), 0, st, gb, (const half_t*)(ws + w.o_y[l - 1]), ga, 1, h, wd, CIN[l]);
+            hipLaunchKernelGGL(k_unpool2_relu, dim3(grid_for(Mi * CIN[l] / 4)), dim3(256), 0, st, gb, (const float*)(ws + w.o_y[l - 1]), ga, 1, h, wd, CIN[l]);
         } else {
-            half_t* t = ga; ga = gb; gb = t;
+            float* t = ga; ga = gb; gb = t;
         }
     }
     // conv1_1: d cols = g1 W0 (27 real columns), then the col2im gather
     float* dcols = (float*)(ws + w.o_dcols);
-    { Epi e{}; e.out_f32 = dcols; e.ldo = 64; e.m_valid = (int)(w.M[0] / 2);
-      if (gemm<EPI_F32, A_F16>(st, ga, 64, (const half_t*)(bl + off[1]), (int)(w.M[0] / 2), 64, 64, e)) return 1; }
+    { Epi e{}; e.out = dcols; e.ldo = 64; e.m_valid = (int)(w.M[0] / 2);
+      if (gemm<EPI_PLAIN, A_MAT>(st, ga, 64, (const float*)(bl + off[1]), (int)(w.M[0] / 2), 64, 64, e)) return 1; }
     hipLaunchKernelGGL(k_col2im_c3, dim3(grid_for(3LL * H * W)), dim3(256), 0, st, dcols, g_img, H, W, scale);
     NERFART_HIP(hipGetLastError());
     return 0;

@@ -62,10 +62,10 @@ import pytest  # noqa: E402
 @pytest.mark.gpu
 @pytest.mark.parametrize("hw", [(60, 34), (480, 270)])
 def test_vgg_loss_on_the_gpu_matches_cpu(hw):
-    """The hand-written path (resample gather -> implicit-GEMM conv stack on the fp16 matrix cores -> L1 -> backward to the
-    pixels; csrc/vgg_conv.hip) against the fp32 torch formulation on the CPU with the same weights.  fp16 operands: the loss
-    agrees to ~1e-3 relative; the L1's sign() flips where two features are equal to rounding, so the gradient is compared as
-    a whole."""
+    """The hand-written path (resample gather -> implicit-GEMM conv stack on the fp32 matrix-core instructions -> L1 -> backward
+    to the pixels; csrc/vgg_conv.hip) against the fp32 torch formulation on the CPU with the same weights.  The gradient is
+    piecewise constant in the ReLU / max-pool / sign decisions (a few sit within round-off: tests/test_style_golden.py), so it is
+    compared as a whole."""
     from nerfart_amd.vgg import VGGPerceptualLoss
     mine = VGGPerceptualLoss(seed=1)
     g = torch.Generator().manual_seed(2)
@@ -80,10 +80,9 @@ def test_vgg_loss_on_the_gpu_matches_cpu(hw):
     rel = float((p_gpu.grad.cpu() / 3.0 - p_cpu.grad).norm() / p_cpu.grad.norm())
     cos = float(torch.nn.functional.cosine_similarity(p_gpu.grad.cpu().flatten(), p_cpu.grad.flatten(), dim=0))
     print(f"  vgg {hw}: loss gpu {float(l_gpu):.6f} cpu {float(l_cpu):.6f}; pixel gradient rel err {rel:.3e}, cosine {cos:.5f}")
-    np.testing.assert_allclose(float(l_gpu), float(l_cpu), rtol=5e-3)
-    # measured on MI355X (round 2): 60 x 34: 2.0e-2 / 0.99979; 480 x 270 (down-sampled noise images: many near-equal features whose
-    # sign is decided inside the fp16 rounding of the activations): 6.3e-2 / 0.99800
-    assert rel < 0.1 and cos > 0.995, (rel, cos)
+    np.testing.assert_allclose(float(l_gpu), float(l_cpu), rtol=1e-4)
+    # round 2 (fp16 operands): 60 x 34: 2.0e-2 / 0.99979; 480 x 270: 6.3e-2 / 0.99800.  fp32 operands (round 3): see profiles/r03*
+    assert rel < 2e-2 and cos > 0.9998, (rel, cos)
     # the torch formulation on the GPU (native switched off) agrees as well
     dev.native = False
     l_t = dev(pred.cuda(), gt.cuda())
