@@ -57,12 +57,17 @@ int nerfart_sdf_fwd_rays(const float* surf_blob, int precision, const float* ray
 
 /* ---- B2 (first half): ImplicitSurface.forward_with_nablas (models/base.py:265-282) + the clamp of
  * VolSDF.forward_surface_with_nablas (volsdf.py:349-357; nabla is NOT replaced).  Outputs sdf[M],
- * nabla[M,3] and, if h7_out != NULL, the layer-7 activation h7[M,256] consumed by nerfart_radiance_fwd. */
+ * nabla[M,3] and, if h7_out != NULL, the layer-7 activation h7[M,256] consumed by nerfart_radiance_fwd.
+ * workspace: nerfart_sdf_nabla_workspace_bytes(precision) bytes of device memory owned by the CALLER (PyTorch's caching
+ * allocator in the Python host), uninitialised, private to the call until the stream has passed it: the
+ * reverse-mode kernels park softplus'(z_l) of the forward sweep there (one region per resident workgroup; precisions 2 / 3
+ * need none and accept NULL).  The library allocates no device memory. */
+long long nerfart_sdf_nabla_workspace_bytes(int precision);
 int nerfart_sdf_nabla_fwd(const float* surf_blob, int precision, const float* pts, long long M, float R_bg, float* sdf_out,
-                          float* nabla_out, float* h7_out, void* stream);
+                          float* nabla_out, float* h7_out, void* workspace, long long workspace_bytes, void* stream);
 int nerfart_sdf_nabla_fwd_rays(const float* surf_blob, int precision, const float* rays_o, const float* rays_d, const int* ray_idx,
                                const float* depth, int n_slots, int n_per_ray, int depth_stride, float R_bg,
-                               float* sdf_out, float* nabla_out, float* h7_out, void* stream);
+                               float* sdf_out, float* nabla_out, float* h7_out, void* workspace, long long workspace_bytes, void* stream);
 
 /* ---- B2 (second half): geometry feature (last SDF layer rows 1..256, base.py:253-256) + RadianceNet.forward
  * (models/base.py:372-391) on [x, view (raw: view_tiles=1 | embed 4: view_tiles=3), nabla, feat]. */
@@ -278,6 +283,16 @@ long long nerfart_vgg16_workspace_bytes(int H, int W, int keep_for_bwd);
 int nerfart_vgg16_l1_fwd(const void* blob, const float* img2, int H, int W, float* loss_out, int keep_for_bwd, void* workspace,
                          long long workspace_bytes, void* stream);
 int nerfart_vgg16_l1_bwd(const void* blob, int H, int W, const float* upstream, float* g_img, void* workspace, long long workspace_bytes, void* stream);
+
+/* ---- weight-gradient reductions of pass 2 (row a19; what autograd accumulates through volsdf.py:759-770): for n_mats matrix
+ * pairs, dW[m] [256, a_cols] fp32 = Z_m^T A_m over `rows` rows and, if cs != NULL, cs[m] [256] = column sums of the first cs_rows
+ * rows of Z_m (the bias gradients).  Z_m [rows, 256] and A_m [rows, a_cols] (a_cols = 256 or 64) are bf16 row-major matrices
+ * z_stride / a_stride BYTES apart (the point-major dumps of the backward kernels, read in place; a stride of 0 shares one
+ * operand); 16-byte aligned.  accumulate != 0 adds to dW / cs.  workspace = nerfart_wgrad_workspace_bytes(n_mats, rows, a_cols)
+ * bytes, caller owned (split-K partial results).  csrc/wgrad.hip: v_mfma_f32_32x32x16_bf16 on ds_read_b64_tr_b16 fragments. */
+long long nerfart_wgrad_workspace_bytes(int n_mats, long long rows, int a_cols);
+int nerfart_wgrad_bf16(const void* Z, long long z_stride, const void* A, long long a_stride, int n_mats, long long rows, int a_cols,
+                       long long cs_rows, float* dW, float* cs, int accumulate, void* workspace, long long workspace_bytes, void* stream);
 
 /* The GEMM kernel of the encoder on its own (tests): C[M,N] fp32 = A[M,K] fp16 . W[N,K]^T fp16; M, N, K multiples of 64. */
 int nerfart_gemm_f16_nt(const void* A, const void* W, int M, int N, int K, float* C, void* stream);

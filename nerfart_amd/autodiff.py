@@ -94,35 +94,27 @@ def _perms(device):
     return _PERMS[key]
 
 
-def _mmT(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """a^T b with bf16 operands and an fp32 result: the weight-gradient GEMMs (plain library GEMMs, hipBLASLt).
-    The reduction runs over ~10^5..10^6 rows into a <= 256 x 256 result - 16 output tiles would occupy 16 of 256 CUs - so
-    the rows are split into up to 64 batches (split-K as a batched GEMM) and the partial results summed in fp32."""
-    a = a if a.dtype == torch.bfloat16 else a.to(torch.bfloat16)
-    b = b if b.dtype == torch.bfloat16 else b.to(torch.bfloat16)
-    n = a.shape[0]
-    s = 64
-    while s > 1 and (n % s or n // s < 1024):
-        s //= 2
-    if s == 1 or not (a.is_contiguous() and b.is_contiguous()):
-        return torch.mm(a.t(), b, out_dtype=torch.float32)
-    return torch.bmm(a.view(s, n // s, a.shape[1]).transpose(1, 2), b.view(s, n // s, b.shape[1]), out_dtype=torch.float32).sum(0)
+def _narrow64(cols, rows_pad: int, split: bool = True) -> torch.Tensor:
+    """fp32 column blocks [(tensor [n_i, c_i], first_row)] -> one bf16 [rows_pad, 64] operand of nerfart_wgrad_bf16: the hi parts in
+    columns 0 .. c-1 and (split) the lo parts x - hi in columns 32 .. 32 + c-1 - the caller adds the two halves of the result."""
+    c = cols[0][0].shape[1]
+    assert c <= (32 if split else 64)
+    out = torch.zeros(rows_pad, 64, dtype=torch.bfloat16, device=cols[0][0].device)
+    for t, r0 in cols:
+        hi = t.to(torch.bfloat16)
+        out[r0:r0 + t.shape[0], :c] = hi
+        if split:
+            out[r0:r0 + t.shape[0], 32:32 + c] = (t - hi.float()).to(torch.bfloat16)
+    return out
 
 
-def _bmmT(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """[L, n, p]^T [L, n, q] -> [L, p, q] fp32 (bf16 operands), the row reduction split into up to 64 batches per matrix:
-    all same-shaped layers of a network in ONE library call (each call costs ~0.8 ms of host time in hipBLASLt)."""
-    L, n, p_ = a.shape
-    q = b.shape[2]
-    s = 64
-    while s > 1 and (n % s or n // s < 1024):
-        s //= 2
-    out = torch.bmm(a.reshape(L * s, n // s, p_).transpose(1, 2), b.reshape(L * s, n // s, q), out_dtype=torch.float32)
-    return out.view(L, s, p_, q).sum(1)
-
-
-def _colsum(a: torch.Tensor) -> torch.Tensor:
-    return a.sum(0, dtype=torch.float32)          # (a GEMM against a ones column takes the N = 1 GEMV path: 70x slower)
+def _wgrad_narrow(Z: torch.Tensor, A64: torch.Tensor, c: int, split: bool, n_mats: int = 1, z_stride: int = 0, want_cs: bool = False, cs_rows: int = 0):
+    """Z_m^T [A narrow] -> [n_mats, 256, c] (+ column sums) through the hand-written kernel, hi + lo columns of A summed."""
+    from . import hip
+    rows = A64.shape[0]
+    w, cs = hip.wgrad(Z, A64, n_mats, rows, 64, z_stride, 0, cs_rows=cs_rows, want_cs=want_cs)
+    w = w[:, :, :c] + w[:, :, 32:32 + c] if split else w[:, :, :c]
+    return w, cs
 
 
 def _inv_perm(device):
@@ -150,9 +142,17 @@ def radiance_weight_grads_raw(model, x, v, n, h7, rgb, g_rgb, dump, bdump):
     d4 = g_rgb * rgb * (1.0 - rgb)
     rad = model.radiance_net
     ex = torch.cat([embed(x, rad.embed_multires), embed(v, rad.embed_multires_view), n], dim=-1)
-    ww = _bmmT(deltas[0:4], acts[0:4])                                      # (d0, f), (d1, r0), (d2, r1), (d3, r2)
-    cs = deltas.sum(1, dtype=torch.float32)                                 # [5, 256] column sums
-    return [ww, cs, _mmT(pad(d4), acts[4]), d4.sum(0), _mmT(deltas[0], pad(ex)), _mmT(deltas[4], pad(h7))]
+    from . import hip
+    slot = Mp * 512                                                         # bytes between the dumps' slots
+    bf = torch.bfloat16
+    # (d0, f), (d1, r0), (d2, r1), (d3, r2) and the column sums of d0..d3 in one pass over the dumps (csrc/wgrad.hip)
+    ww, cs03 = hip.wgrad(deltas[0], acts[0], 4, Mp, 256, slot, slot, cs_rows=Mp, want_cs=True)
+    wh7, cs4 = hip.wgrad(deltas[4], pad(h7).to(bf), 1, Mp, 256, 0, 0, cs_rows=Mp, want_cs=True)
+    cs = torch.cat([cs03, cs4], dim=0)                                      # [5, 256]
+    w4 = _wgrad_narrow(acts[4], _narrow64([(d4, 0)], Mp), 3, True)[0][0].t()                # [3, 256] = d4^T r3
+    nex = ex.shape[1]
+    wex = _wgrad_narrow(deltas[0], _narrow64([(ex, 0)], Mp, nex <= 32), nex, nex <= 32)[0][0]  # [256, nex] = d0^T [x | v | n]
+    return [ww, cs, w4, d4.sum(0), wex, wh7[0]]
 
 
 def radiance_weight_grads_finish(model, raw):
@@ -214,15 +214,22 @@ def surface_weight_grads_raw(model, pts, sbar, hbar7, nbar):
     bf = torch.bfloat16
     Mp = (M + 63) // 64 * 64                                            # the kernels' tiles; padded rows are zero where it matters
     padr = lambda t: t if Mp == M else torch.cat([t, torch.zeros(Mp - M, *t.shape[1:], device=t.device, dtype=t.dtype)], dim=0)
-    e2 = torch.cat([padr(embed(pts, surf.embed_multires)), padr(embed_tangent(pts, nbar, surf.embed_multires))], dim=0).to(bf)    # [e; edot]
+    e2 = torch.cat([padr(embed(pts, surf.embed_multires)), padr(embed_tangent(pts, nbar, surf.embed_multires))], dim=0)           # [e; edot] fp32
     RZ = _pair_all(r2, _R2_SLOTS, 8)                                    # [8, 2 Mp, 256]: 65535 * [zbar_l; t_l d_l]
     FA = _pair_all(f2, _F2_SLOTS, 8)                                    # [8, 2 Mp, 256]: [a_l; adot_l]
     sbar = padr(sbar)
-    ww = _bmmT(RZ[1:8], FA[0:7])                                        # layers 1..7 against the previous layer's (a | adot)
-    we = _bmmT(torch.stack([RZ[0], RZ[4]]), e2[None].expand(2, -1, -1))    # layers 0 and 4 against the encoding
-    cs = RZ[:, :Mp].sum(1, dtype=torch.float32)                         # [8, 256]: sum_p zbar_l
-    a7, ad7 = FA[7][:Mp], FA[7][Mp:]
-    w8 = _mmT(a7, sbar[:, None])[:, 0] + _colsum(ad7)
+    from . import hip
+    slot = 2 * Mp * 512                                                 # bytes between the dumps' slots
+    # layers 1..7 against the previous layer's (a | adot), with the column sums of zbar_1..7 (first Mp rows) in the same pass
+    ww, cs17 = hip.wgrad(RZ[1], FA[0], 7, 2 * Mp, 256, slot, slot, cs_rows=Mp, want_cs=True)
+    # layers 0 and 4 (four slots apart) against the encoding [e; edot], one shared narrow operand; column sums of zbar_0
+    nenc = e2.shape[1]
+    we, cs04 = _wgrad_narrow(RZ[0], _narrow64([(e2, 0)], 2 * Mp, nenc <= 32), nenc, nenc <= 32, n_mats=2, z_stride=4 * slot,
+                             want_cs=True, cs_rows=Mp)
+    cs = torch.cat([cs04[0:1], cs17], dim=0)                            # [8, 256]: sum_p zbar_l
+    # w8 row: a7^T sbar + column sums of adot7 = FA[7]^T [sbar; 1]
+    ones = torch.ones(Mp, 1, dtype=torch.float32, device=pts.device)
+    w8 = _wgrad_narrow(FA[7], _narrow64([(sbar[:, None], 0), (ones, Mp)], 2 * Mp), 1, True)[0][0][:, 0]
     return [ww, we, cs, w8, sbar.sum()]
 
 

@@ -1,9 +1,6 @@
 // capi_common.cpp - error reporting shared by every entry point of libnerfart_hip.so.
 #include "nerfart_common.h"
-#include <map>
-#include <mutex>
 #include <string>
-#include <utility>
 #include <vector>
 
 namespace nerfart {
@@ -13,29 +10,6 @@ int check_hip(hipError_t e, const char* what) {
     if (e == hipSuccess) return 0;
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
     return 1;
-}
-}  // namespace nerfart
-
-// ---- library-owned scratch of the reverse-mode SDF-gradient kernel ---------------------------------
-// One allocation per (device, stream), made on first use and kept for the life of the process (the C ABI of
-// nerfart_sdf_nabla_fwd has no workspace argument; per-stream buffers keep the entry point re-entrant).
-namespace nerfart {
-void* grad_scratch(hipStream_t st, size_t bytes) {
-    static std::mutex mu;
-    static std::map<std::pair<int, void*>, std::pair<void*, size_t>> pool;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    auto& e = pool[{dev, (void*)st}];
-    if (e.second < bytes) {
-        if (e.first) (void)hipFree(e.first);
-        e = {nullptr, 0};
-        void* p = nullptr;
-        if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
-        (void)hipMemset(p, 0, bytes);
-        e = {p, bytes};
-    }
-    return e.first;
 }
 }  // namespace nerfart
 

@@ -62,6 +62,37 @@ __device__ __forceinline__ f32x4 mfma3(const u32x4 ah, const u32x4 al, const u32
     return acc;
 }
 
+// The item's wait for its A fragments and its three MFMAs as ONE statement (round 3): hipcc pads one wait state after every asm
+// statement whose VGPR outputs the next instruction touches, so `s_waitcnt` (outputs = the fragments) + `mfma3` cost an s_nop 0
+// between them plus the s_nop 1 inside mfma3 - 3 issue cycles per item that nothing needs: the A operands come from LDS (the wait
+// itself), and the B unit was written by VALU instructions at least two LDS reads + the wait earlier (its last `v_cvt_pk` sits in
+// item 15 of the previous k-step; PAD adds one state in front of item 0 anyway).  The fragments are plain inputs: named as
+// outputs, hipcc pads the next VALU that recycles their registers; that no compiler copy of them sits between the ds_read
+// statement and this one is what tools/audit_asm_loads.py (tests/test_asm_audit.py) checks in the ISA.
+template <int CNT, bool PAD>
+__device__ __forceinline__ f32x4 wait_mfma3(u32x4& ah, u32x4& al, const u32x4 bh, const u32x4 bl, f32x4 acc) {
+#if defined(NERFART_ABLATE_MFMA) || defined(NERFART_OLD_ITEM)
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(ah), "+v"(al) : "i"(CNT));
+    return mfma3(ah, al, bh, bl, acc);
+#else
+    if constexpr (PAD) {
+        asm volatile("s_waitcnt lgkmcnt(%5)\n\t"
+                     "s_nop 0\n\t"
+                     "v_mfma_f32_16x16x32_bf16 %0, %1, %3, %0\n\t"
+                     "v_mfma_f32_16x16x32_bf16 %0, %1, %4, %0\n\t"
+                     "v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0"
+                     : "+v"(acc) : "v"(ah), "v"(al), "v"(bh), "v"(bl), "i"(CNT));
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(%5)\n\t"
+                     "v_mfma_f32_16x16x32_bf16 %0, %1, %3, %0\n\t"
+                     "v_mfma_f32_16x16x32_bf16 %0, %1, %4, %0\n\t"
+                     "v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0"
+                     : "+v"(acc) : "v"(ah), "v"(al), "v"(bh), "v"(bl), "i"(CNT));
+    }
+    return acc;
+#endif
+}
+
 // Two accumulator chains interleaved: the triples of tiles T-1 and T (same B unit) issued alternately, so that no MFMA
 // depends on the one just before it.
 __device__ __forceinline__ void mfma6(const u32x4 ah0, const u32x4 al0, const u32x4 ah1, const u32x4 al1, const u32x4 bh,
@@ -120,6 +151,7 @@ struct Stream {
     int nxt, nxt_o0;           // the chunk to stream during the NEXT chunk (offset looked up one acquire ahead)
     int pb;
     bool wrap;                 // another tile follows: chunk 0 comes after chunk nc-1
+    int late_st;               // VMEM stores issued after the chunk's last LDS-DMA piece: they may stay in flight across the acquire
 };
 
 __device__ __forceinline__ void stream_lookup(Stream& s, int chunk) {
@@ -172,7 +204,12 @@ __device__ __forceinline__ void stream_start(Stream& s) {
 }
 __device__ __forceinline__ const float* stream_acquire(Stream& s) {
 #ifndef NERFART_ABLATE_VMWAIT   // timing experiments only (tools/ablate_bf16.py): results are wrong without these
-    wait_glds();          // my pieces of the current chunk have landed
+    // my pieces of the current chunk have landed.  vmcnt counts loads and stores alike and retires in issue order: a unit store
+    // issued AFTER the chunk's last piece (Items, LATE_ST) may stay in flight - its acknowledgement from a missing L2 line
+    // takes longer than the rest of the chunk
+    if (s.late_st) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else wait_glds();
+    s.late_st = 0;
 #endif
 #ifndef NERFART_ABLATE_BARRIER
     __syncthreads();      // everyone's pieces landed; everyone is done reading buffer pb^1
@@ -200,9 +237,26 @@ __device__ __forceinline__ const float* stream_acquire(Stream& s) {
 // ---------------------------------------------------------------------------------------
 // max(z, 0) in one instruction (fmaxf() first canonicalises z with a v_max_f32 z, z)
 __device__ __forceinline__ float relu1(float z) {
+#ifdef NERFART_OLD_ITEM
     float y;
     asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(z));
     return y;
+#else
+    float y;
+    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(z));
+    return y;
+#endif
+}
+// max(z, 0) + log2(1 + e) * ln 2 / 100 from the v_log_f32 result L: the v_max and the v_fmac as one statement - as two, hipcc
+// pads an s_nop between the asm v_max and the v_fmac that consumes it (round 3).  Same two instructions, same bits.
+__device__ __forceinline__ float softplus_tail(float z, float L) {
+#ifdef NERFART_OLD_ITEM
+    return relu1(z) + L * (0.69314718055994530942f / 100.0f);
+#else
+    float y;
+    asm("v_max_f32 %0, 0, %1\n\tv_fmac_f32 %0, 0x3be32166, %2" : "=&v"(y) : "v"(z), "v"(L));
+    return y;
+#endif
 }
 
 // lane 2i of every pair (2i, 2i+1) to both: one VALU op with DPP quad_perm [0,0,2,2]
@@ -260,8 +314,8 @@ __device__ __forceinline__ void epi_phase(float z0, float z1, Work& w, unsigned&
             w.y0 = fmaf(odd * t0 * w.e0, 65535.0f - w.r0, z0 * w.r0);
             w.y1 = fmaf(odd * t1 * w.e1, 65535.0f - w.r1, z1 * w.r1);
         } else if constexpr (MODE == 10) {
-            const float v0 = relu1(z0) + __builtin_amdgcn_logf(1.0f + w.e0) * (0.69314718055994530942f / 100.0f);
-            const float v1 = relu1(z1) + __builtin_amdgcn_logf(1.0f + w.e1) * (0.69314718055994530942f / 100.0f);
+            const float v0 = softplus_tail(z0, __builtin_amdgcn_logf(1.0f + w.e0));
+            const float v1 = softplus_tail(z1, __builtin_amdgcn_logf(1.0f + w.e1));
             const float d0 = pair_bcast0((z0 >= 0.f) ? w.r0 : w.e0 * w.r0);
             const float d1 = pair_bcast0((z1 >= 0.f) ? w.r1 : w.e1 * w.r1);
             w.y0 = is_val ? v0 : d0 * z0;
@@ -269,8 +323,8 @@ __device__ __forceinline__ void epi_phase(float z0, float z1, Work& w, unsigned&
             typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
             dout = __builtin_bit_cast(unsigned, (u16x2)__builtin_amdgcn_cvt_pknorm_u16(d0, d1));
         } else {
-            const float v0 = relu1(z0) + __builtin_amdgcn_logf(1.0f + w.e0) * (0.69314718055994530942f / 100.0f);
-            const float v1 = relu1(z1) + __builtin_amdgcn_logf(1.0f + w.e1) * (0.69314718055994530942f / 100.0f);
+            const float v0 = softplus_tail(z0, __builtin_amdgcn_logf(1.0f + w.e0));
+            const float v1 = softplus_tail(z1, __builtin_amdgcn_logf(1.0f + w.e1));
             if constexpr (MODE == 1) {
                 // value lanes carry z (bias included); tangent lanes carry dz and take softplus'(z) from their quad's lane 0
                 const float d0 = quad_bcast0((z0 >= 0.f) ? w.r0 : w.e0 * w.r0);
@@ -334,10 +388,14 @@ __device__ __forceinline__ void d_load2(GradCtx& gc, int idx, int buf) {
 // Plain (compiler-visible) loads: hipcc then keeps its own vmcnt bookkeeping for them - with the LDS-DMA pieces it
 // cannot see this can only make its wait stricter.  (Hand-counted asm loads gave wrong gradients on random waves.)
 __device__ __forceinline__ void d_load(GradCtx& gc, int idx, int buf) {
-#ifdef NERFART_ABLATE_SCRATCH
+#if defined(NERFART_ABLATE_SCRATCH) || defined(NERFART_ABLATE_SCRATCH_LD)
     return;
 #endif
+#if defined(NERFART_EXP_SCRATCH_NT) && (NERFART_EXP_SCRATCH_NT & 2)
+    gc.dbuf[buf] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(gc.ws + uoff(gc, idx) + gc.voff));
+#else
     gc.dbuf[buf] = *reinterpret_cast<const u32x4*>(gc.ws + uoff(gc, idx) + gc.voff);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -435,24 +493,38 @@ struct Items {
                 mfma6(r.h[SP], r.l[SP], r.h[S], r.l[S], bh, bl, Q.t[T - 1], Q.t[T]);
             }
 #else
-            lds_wait_pair<PENDING>(r.h[S], r.l[S]);
-            Q.t[T] = mfma3(r.h[S], r.l[S], bh, bl, Q.t[T]);
+            Q.t[T] = wait_mfma3<PENDING, T == 0>(r.h[S], r.l[S], bh, bl, Q.t[T]);
 #endif
             constexpr int HU = L::hosted(ks);
             constexpr int HM = L::mode_of(HU);
-            if constexpr (T == 0) {
+#ifdef NERFART_EXP_ST_LATE        // experiment: the unit store behind the k-step's LDS-DMA pieces (item 9), left in flight across the acquire
+            constexpr int ST_ITEM = 9;
+#else
+            constexpr int ST_ITEM = 0;
+#endif
+            if constexpr (T == ST_ITEM) {
                 // reverse-mode kernel, forward sweep: store the softplus' unit finished in the previous k-step
                 constexpr int HUP = (ks == 0) ? (L::PEND_IN ? 100 : -1) : L::hosted(ks - 1);
                 constexpr bool STORE = (ks == 0) ? L::PEND_IN : (HUP >= 0 && L::stores(L::mode_of(HUP)));
-#ifdef NERFART_ABLATE_SCRATCH
+#if defined(NERFART_ABLATE_SCRATCH) || defined(NERFART_ABLATE_SCRATCH_ST)
                 if constexpr (false) {
 #else
                 if constexpr (STORE) {
 #endif
+#ifdef NERFART_EXP_ST_LATE
+                    constexpr int PM0 = (ks == 0) ? L::MODE : L::mode_of(HUP);
+                    if constexpr (PM0 != 10 && kk == NKC - 1) const_cast<Stream&>(s).late_st = 1;
+#endif
+#if defined(NERFART_EXP_SCRATCH_NT) && (NERFART_EXP_SCRATCH_NT & 1)
+                    __builtin_nontemporal_store(gc.dpend, reinterpret_cast<u32x4*>(gc.pend_ptr + gc.voff_out));
+#else
                     *reinterpret_cast<u32x4*>(gc.pend_ptr + gc.voff_out) = gc.dpend;
+#endif
                     constexpr int PM = (ks == 0) ? L::MODE : L::mode_of(HUP);        // (mode 10 layers use 10 for both kinds)
                     if constexpr (PM == 10) *reinterpret_cast<u32x4*>(gc.pend_ptr + 8 * gc.slot_stride + gc.voff_out) = gc.dpend2;
                 }
+            }
+            if constexpr (T == 0) {
                 // backward sweep: load the softplus' unit needed by the slices of the NEXT k-step
                 if constexpr (ks + 1 < L::NKS) {
                     constexpr int HN = L::hosted(ks + 1);
@@ -636,7 +708,11 @@ __device__ __forceinline__ void last_epilogue(const Acc& Q, const float* rows, f
             for (int r = 0; r < 4; ++r) dot[n] = fmaf(y[r], w[r], dot[n]);
         }
         if constexpr (MODE != 2) {
+#ifdef NERFART_EXP_H7_NT
+            if (h7 != nullptr && ec.is_val) __builtin_nontemporal_store(y, reinterpret_cast<f32x4*>(h7 + 16 * T + 4 * g));
+#else
             if (h7 != nullptr && ec.is_val) *reinterpret_cast<f32x4*>(h7 + 16 * T + 4 * g) = y;
+#endif
         } else {
             if (dump != nullptr) {          // unit T/2 = (tile T regs 0..3 | tile T+1 regs 0..3), bf16 hi parts
                 du[2 * (T & 1)] = pack_bf16(y[0], y[1]);
@@ -748,7 +824,7 @@ __device__ __forceinline__ float surface_chain(float px, float py, float pz, int
 __device__ __forceinline__ Stream make_stream(const float* blob, const float* aux, float* smem, int nc) {
     Stream s;
     s.blob = blob; s.tab = reinterpret_cast<const int*>(aux + AUX_FLOATS_MAX); s.lds = smem; s.nc = nc;
-    s.iss_src = blob; s.iss_dst = 0; s.voff_a = 0; s.voff_b = 0; s.nxt = -1; s.nxt_o0 = 0; s.pb = 0; s.wrap = false;
+    s.iss_src = blob; s.iss_dst = 0; s.voff_a = 0; s.voff_b = 0; s.nxt = -1; s.nxt_o0 = 0; s.pb = 0; s.wrap = false; s.late_st = 0;
     return s;
 }
 

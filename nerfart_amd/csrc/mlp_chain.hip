@@ -587,7 +587,12 @@ int radiance_fwd_dump_bf16(const float* blob, int view_tiles, const PointSrc& s,
 int radiance_bwd_bf16(const float* blob, long long M, const float* rgb, const float* g_rgb, void* fwd_dump, void* bwd_dump, float* g_h7,
                       float* g_n, hipStream_t st);
 int sdf_grad_bf16(const float* blob, const PointSrc& s, float R_bg, float* sdf, float* nabla, float* h7, void* ws, hipStream_t st);
-void* grad_scratch(hipStream_t st, size_t bytes);
+// bytes of the reverse-mode kernels' softplus' scratch (one private region per resident workgroup): caller owned
+static size_t nabla_ws_bytes(int precision) {
+    if (precision == 0) return (size_t)num_cus() * GRADF_WS_PER_WG;
+    if (precision == 1) return sdf_grad_ws_bytes();
+    return 0;                                         // forward-mode tangent kernels (2, 3): none
+}
 static int check_precision(int precision, bool allow_fwd_tangents = false) {
     if (precision == 0 || precision == 1 || (allow_fwd_tangents && (precision == 2 || precision == 3))) return 0;
     set_last_error("precision must be 0 (fp32-exact MFMA) or 1 (split-bf16 'bf16x3' MFMA)");
@@ -596,22 +601,26 @@ static int check_precision(int precision, bool allow_fwd_tangents = false) {
 // precision 0: reverse-mode kernel; precision 3: the forward-mode tangent quads of k_sdf_nabla (kept for cross-checks - same
 // blob, 2x the matrix work)
 static int sdf_nabla_f32_dispatch(int precision, const float* blob, const PointSrc& s, float R_bg, float* sdf, float* nabla, float* h7,
-                                  hipStream_t st) {
+                                  void* ws, hipStream_t st) {
     const long long M = s.M;
     if (precision == 3) return launch_chain(1, M, k_sdf_nabla, (unsigned)((M + 31) / 32), st, blob, s, R_bg, sdf, nabla, h7);
     const unsigned ntiles = (unsigned)((M + 127) / 128);
-    void* ws = grad_scratch(st, (size_t)num_cus() * GRADF_WS_PER_WG);            // launch_chain's grid is at most one workgroup per CU
-    if (!ws) { set_last_error("sdf_nabla_fwd: could not allocate the reverse-mode scratch (256 MiB per stream)"); return 1; }
-    return launch_chain(1, M, k_sdf_grad, ntiles, st, blob, s, R_bg, sdf, nabla, h7, (char*)ws);
+    return launch_chain(1, M, k_sdf_grad, ntiles, st, blob, s, R_bg, sdf, nabla, h7, (char*)ws);   // grid <= one workgroup per CU
 }
 // precision 1: reverse-mode kernel (one column per point); precision 2: the forward-mode tangent quads (kept for
 // cross-checks - same blob, 2.1x the matrix work)
 static int sdf_nabla_bf16_dispatch(int precision, const float* blob, const PointSrc& s, float R_bg, float* sdf, float* nabla,
-                                   float* h7, hipStream_t st) {
+                                   float* h7, void* ws, hipStream_t st) {
     if (precision == 2) return sdf_nabla_bf16(blob, s, R_bg, sdf, nabla, h7, st);
-    void* ws = grad_scratch(st, sdf_grad_ws_bytes());
-    if (!ws) { set_last_error("sdf_nabla_fwd: could not allocate the reverse-mode scratch (117 MiB per stream)"); return 1; }
     return sdf_grad_bf16(blob, s, R_bg, sdf, nabla, h7, ws, st);
+}
+static int check_nabla_ws(int precision, const void* ws, long long ws_bytes) {
+    const size_t need = nabla_ws_bytes(precision);
+    if (need && (!ws || ws_bytes < (long long)need)) {
+        set_last_error("sdf_nabla_fwd: workspace missing or smaller than nerfart_sdf_nabla_workspace_bytes(precision)");
+        return 2;
+    }
+    return 0;
 }
 }  // namespace nerfart
 
@@ -640,28 +649,32 @@ int nerfart_sdf_fwd_rays(const float* blob, int precision, const float* rays_o, 
     return launch_chain(0, M, k_sdf_only, (unsigned)((M + 127) / 128), (hipStream_t)stream, blob, s, R_bg, sdf_out, out_stride);
 }
 
+long long nerfart_sdf_nabla_workspace_bytes(int precision) { return (long long)nabla_ws_bytes(precision); }
+
 int nerfart_sdf_nabla_fwd(const float* blob, int precision, const float* pts, long long M, float R_bg, float* sdf_out,
-                          float* nabla_out, float* h7_out, void* stream) {
+                          float* nabla_out, float* h7_out, void* workspace, long long workspace_bytes, void* stream) {
     if (int rc = check_M(M)) return rc;
     if (M == 0) return 0;
     PointSrc s = make_src(pts, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, M);
     if (int rc = validate_src(s)) return rc;
     if (int rc = check_precision(precision, true)) return rc;
-    if (precision == 1 || precision == 2) return sdf_nabla_bf16_dispatch(precision, blob, s, R_bg, sdf_out, nabla_out, h7_out, (hipStream_t)stream);
-    return sdf_nabla_f32_dispatch(precision, blob, s, R_bg, sdf_out, nabla_out, h7_out, (hipStream_t)stream);
+    if (int rc = check_nabla_ws(precision, workspace, workspace_bytes)) return rc;
+    if (precision == 1 || precision == 2) return sdf_nabla_bf16_dispatch(precision, blob, s, R_bg, sdf_out, nabla_out, h7_out, workspace, (hipStream_t)stream);
+    return sdf_nabla_f32_dispatch(precision, blob, s, R_bg, sdf_out, nabla_out, h7_out, workspace, (hipStream_t)stream);
 }
 
 int nerfart_sdf_nabla_fwd_rays(const float* blob, int precision, const float* rays_o, const float* rays_d, const int* ray_idx,
                                const float* depth, int n_slots, int n_per_ray, int depth_stride, float R_bg,
-                               float* sdf_out, float* nabla_out, float* h7_out, void* stream) {
+                               float* sdf_out, float* nabla_out, float* h7_out, void* workspace, long long workspace_bytes, void* stream) {
     const long long M = (long long)n_slots * n_per_ray;
     if (int rc = check_M(M)) return rc;
     if (M == 0) return 0;
     PointSrc s = make_src(nullptr, nullptr, rays_o, rays_d, ray_idx, depth, n_per_ray, depth_stride, M);
     if (int rc = validate_src(s)) return rc;
     if (int rc = check_precision(precision, true)) return rc;
-    if (precision == 1 || precision == 2) return sdf_nabla_bf16_dispatch(precision, blob, s, R_bg, sdf_out, nabla_out, h7_out, (hipStream_t)stream);
-    return sdf_nabla_f32_dispatch(precision, blob, s, R_bg, sdf_out, nabla_out, h7_out, (hipStream_t)stream);
+    if (int rc = check_nabla_ws(precision, workspace, workspace_bytes)) return rc;
+    if (precision == 1 || precision == 2) return sdf_nabla_bf16_dispatch(precision, blob, s, R_bg, sdf_out, nabla_out, h7_out, workspace, (hipStream_t)stream);
+    return sdf_nabla_f32_dispatch(precision, blob, s, R_bg, sdf_out, nabla_out, h7_out, workspace, (hipStream_t)stream);
 }
 
 int nerfart_radiance_fwd(const float* blob, int precision, int view_tiles, const float* pts, const float* view, long long M,

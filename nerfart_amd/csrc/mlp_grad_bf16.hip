@@ -53,8 +53,13 @@ k_sdf_grad_bf16(const float* __restrict__ blob, PointSrc src, float R_bg, float*
     GradCtx gc;
     gc.ws = ws + (size_t)blockIdx.x * GRAD_WS_PER_WG + wv * 1024;
     gc.ws_out = gc.ws;
+#ifdef NERFART_EXP_SCRATCH_SMALL    // timing experiment: every unit lands on the same L2-resident KiB (results wrong)
+    gc.slot_stride = 0;
+    gc.unit_stride = 0;
+#else
     gc.slot_stride = 8 * 8192;
     gc.unit_stride = 8192;
+#endif
     gc.voff = gc.voff_out = lane * 16;
     gc.pend_ptr = gc.ws;
     const EpiCtx ec{0.f, 0.f, true};
@@ -118,9 +123,11 @@ k_sdf_grad_bf16(const float* __restrict__ blob, PointSrc src, float R_bg, float*
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const char* ptr = gc.ws + uoff(gc, u);
-#ifdef NERFART_ABLATE_SCRATCH
+#if defined(NERFART_ABLATE_SCRATCH) || defined(NERFART_ABLATE_SCRATCH_LD)
                 d0[u] = u32x4{1u, 1u, 1u, 1u};
                 (void)ptr;
+#elif defined(NERFART_EXP_SCRATCH_NT) && (NERFART_EXP_SCRATCH_NT & 2)
+                d0[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ptr + gc.voff));
 #else
                 d0[u] = *reinterpret_cast<const u32x4*>(ptr + gc.voff);
 #endif

@@ -168,7 +168,9 @@ using namespace nerfart;
 extern "C" {
 
 int nerfart_sdf_fwd_rays(const float*, int, const float*, const float*, const int*, const float*, int, int, int, float, float*, int, void*);
-int nerfart_sdf_nabla_fwd_rays(const float*, int, const float*, const float*, const int*, const float*, int, int, int, float, float*, float*, float*, void*);
+int nerfart_sdf_nabla_fwd_rays(const float*, int, const float*, const float*, const int*, const float*, int, int, int, float, float*, float*, float*, void*,
+                               long long, void*);
+long long nerfart_sdf_nabla_workspace_bytes(int precision);
 int nerfart_radiance_fwd_rays(const float*, int, int, const float*, const float*, const int*, const float*, int, int, int, const float*, const float*, float*, void*);
 int nerfart_normalize_dirs(const float*, float*, int, void*);
 int nerfart_linspace_depths(const float*, int, const float*, const float*, float, float, int, float*, int, void*);
@@ -225,6 +227,8 @@ int nerfart_neus_composite(int n_rays, int P, const float* d_all, const float* s
 
 typedef struct {
     float *rays_dn, *near, *far, *t_coarse, *u_new, *d, *s, *d_new, *s_new, *d_mid, *sdf, *nabla, *nabla_mid, *sdf_mid, *rad, *h7;
+    char* nabla_ws;           // softplus' scratch of the reverse-mode grad(SDF) kernel
+    size_t nabla_ws_bytes;
 } neus_ws_t;
 
 static size_t carve_neus(char* base, int R, int n_samples, int n_imp, int k3_rays, neus_ws_t* w) {
@@ -249,6 +253,10 @@ static size_t carve_neus(char* base, int R, int n_samples, int n_imp, int k3_ray
     p = (float*)take((size_t)rk * (P - 1) * 4); if (w) w->sdf_mid = p;
     p = (float*)take((size_t)R * (P - 1) * 12); if (w) w->rad = p;
     p = (float*)take((size_t)rk * (P - 1) * 256 * 4); if (w) w->h7 = p;
+    const long long nb0 = nerfart_sdf_nabla_workspace_bytes(0), nb1 = nerfart_sdf_nabla_workspace_bytes(1);
+    const size_t nb = (size_t)(nb0 > nb1 ? nb0 : nb1);
+    char* np = take(nb);
+    if (w) { w->nabla_ws = np; w->nabla_ws_bytes = nb; }
     return o;
 }
 
@@ -313,13 +321,13 @@ int nerfart_neus_render_fwd(const float* surf_blob, const float* rad_blob, int p
     }
     if (d_all_out) NERFART_HIP(hipMemcpyAsync(d_all_out, w.d, sizeof(float) * (size_t)n_rays * P, hipMemcpyDeviceToDevice, stream));
     // sdf + nablas at the P sample points (neus.py:320)
-    if (int rc = nerfart_sdf_nabla_fwd_rays(surf_blob, precision, rays_o, w.rays_dn, nullptr, w.d, n_rays, P, P, 0.f, sdf, nabla, nullptr, stream)) return rc;
+    if (int rc = nerfart_sdf_nabla_fwd_rays(surf_blob, precision, rays_o, w.rays_dn, nullptr, w.d, n_rays, P, P, 0.f, sdf, nabla, nullptr, w.nabla_ws, (long long)w.nabla_ws_bytes, stream)) return rc;
     // radiance at the P-1 mid-points, with their own nablas (neus.py:324 -> forward_radiance :111-114)
     for (int c0 = 0; c0 < n_rays; c0 += k3_rays_chunk) {
         const int rk = (n_rays - c0 < k3_rays_chunk) ? n_rays - c0 : k3_rays_chunk;
         const size_t po = (size_t)c0 * (P - 1);
         if (int rc = nerfart_sdf_nabla_fwd_rays(surf_blob, precision, rays_o + 3 * (size_t)c0, w.rays_dn + 3 * (size_t)c0, nullptr,
-                                                w.d_mid + po, rk, P - 1, P - 1, 0.f, w.sdf_mid, w.nabla_mid, w.h7, stream)) return rc;
+                                                w.d_mid + po, rk, P - 1, P - 1, 0.f, w.sdf_mid, w.nabla_mid, w.h7, w.nabla_ws, (long long)w.nabla_ws_bytes, stream)) return rc;
         if (int rc = nerfart_radiance_fwd_rays(rad_blob, precision, view_tiles, rays_o + 3 * (size_t)c0, w.rays_dn + 3 * (size_t)c0, nullptr,
                                                w.d_mid + po, rk, P - 1, P - 1, w.nabla_mid, w.h7, rad + 3 * po, stream)) return rc;
     }

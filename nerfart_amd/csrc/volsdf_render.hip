@@ -277,7 +277,9 @@ extern "C" {
 
 // ---- forward declarations of the MLP entry points (mlp_chain.hip) ---------------------
 int nerfart_sdf_fwd_rays(const float*, int, const float*, const float*, const int*, const float*, int, int, int, float, float*, int, void*);
-int nerfart_sdf_nabla_fwd_rays(const float*, int, const float*, const float*, const int*, const float*, int, int, int, float, float*, float*, float*, void*);
+int nerfart_sdf_nabla_fwd_rays(const float*, int, const float*, const float*, const int*, const float*, int, int, int, float, float*, float*, float*, void*,
+                               long long, void*);
+long long nerfart_sdf_nabla_workspace_bytes(int precision);
 int nerfart_radiance_fwd_rays(const float*, int, int, const float*, const float*, const int*, const float*, int, int, int, const float*, const float*, float*, void*);
 
 // torch.linspace(start, end, n) in fp32: step = (end-start)/(n-1); the first half counts up from
@@ -500,6 +502,8 @@ typedef struct {
     float *rays_dn, *d_fine, *d_coarse, *t_coarse, *d_all, *sdf, *nabla, *rad, *beta_map, *iter_usage, *h7;
     char* sampler;
     size_t sampler_bytes;
+    char* nabla_ws;           // softplus' scratch of the reverse-mode grad(SDF) kernel (nerfart_sdf_nabla_workspace_bytes)
+    size_t nabla_ws_bytes;
 } render_ws_t;
 
 static size_t carve_render(char* base, int R, int n_samples, int n_imp, int max_iter, int k3_rays, render_ws_t* w) {
@@ -523,6 +527,10 @@ static size_t carve_render(char* base, int R, int n_samples, int n_imp, int max_
     const size_t sb = carve_sampler(nullptr, R, n_init + max_iter * n_up, n_up, n_init, n_imp, nullptr);
     char* sp = take(sb);
     if (w) { w->sampler = sp; w->sampler_bytes = sb; }
+    const long long nb0 = nerfart_sdf_nabla_workspace_bytes(0), nb1 = nerfart_sdf_nabla_workspace_bytes(1);
+    const size_t nb = (size_t)(nb0 > nb1 ? nb0 : nb1);          // sized for either precision
+    char* np = take(nb);
+    if (w) { w->nabla_ws = np; w->nabla_ws_bytes = nb; }
     return o;
 }
 
@@ -578,7 +586,7 @@ int nerfart_volsdf_render_fwd(const float* surf_blob, const float* rad_blob, int
         const int rk = (n_rays - c0 < k3_rays_chunk) ? n_rays - c0 : k3_rays_chunk;
         const size_t po = (size_t)c0 * P;
         if (int rc = nerfart_sdf_nabla_fwd_rays(surf_blob, precision, rays_o + 3 * (size_t)c0, w.rays_dn + 3 * (size_t)c0, nullptr,
-                                                d_all + po, rk, P, P, R_bg, sdf + po, nabla + 3 * po, w.h7, stream)) return rc;
+                                                d_all + po, rk, P, P, R_bg, sdf + po, nabla + 3 * po, w.h7, w.nabla_ws, (long long)w.nabla_ws_bytes, stream)) return rc;
         if (int rc = nerfart_radiance_fwd_rays(rad_blob, precision, view_tiles, rays_o + 3 * (size_t)c0, w.rays_dn + 3 * (size_t)c0,
                                                nullptr, d_all + po, rk, P, P, nabla + 3 * po, w.h7, rad + 3 * po, stream)) return rc;
     }

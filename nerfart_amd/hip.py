@@ -44,8 +44,11 @@ _SIGS = {
     "nerfart_profile_end": (_i, [_p, _p, _p]),
     "nerfart_sdf_fwd": (_i, [_p, _i, _p, _ll, _f, _p, _p]),
     "nerfart_sdf_fwd_rays": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _f, _p, _i, _p]),
-    "nerfart_sdf_nabla_fwd": (_i, [_p, _i, _p, _ll, _f, _p, _p, _p, _p]),
-    "nerfart_sdf_nabla_fwd_rays": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p]),
+    "nerfart_sdf_nabla_workspace_bytes": (_ll, [_i]),
+    "nerfart_sdf_nabla_fwd": (_i, [_p, _i, _p, _ll, _f, _p, _p, _p, _p, _ll, _p]),
+    "nerfart_sdf_nabla_fwd_rays": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _ll, _p]),
+    "nerfart_wgrad_workspace_bytes": (_ll, [_i, _ll, _i]),
+    "nerfart_wgrad_bf16": (_i, [_p, _ll, _p, _ll, _i, _ll, _i, _ll, _p, _p, _i, _p, _ll, _p]),
     "nerfart_radiance_fwd": (_i, [_p, _i, _i, _p, _p, _ll, _p, _p, _p, _p]),
     "nerfart_radiance_fwd_rays": (_i, [_p, _i, _i, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "nerfart_get_rays": (_i, [_p, _p, _i, _i, _p, _i, _p, _p, _p]),
@@ -160,9 +163,32 @@ def sdf_nabla_fwd(surf_blob, pts, R_bg: float, want_h7: bool = True, precision: 
     sdf = torch.empty(M, dtype=torch.float32, device=pts.device)
     nab = torch.empty(M, 3, dtype=torch.float32, device=pts.device)
     h7 = torch.empty(M, 256, dtype=torch.float32, device=pts.device) if want_h7 else None
+    ws, nb = nabla_workspace(precision, pts.device)
     _check(lib.nerfart_sdf_nabla_fwd(_dev(surf_blob), int(precision), _dev(pts, name="pts"), M, float(R_bg), _dev(sdf), _dev(nab),
-                                     _dev(h7), _stream()), "nerfart_sdf_nabla_fwd")
+                                     _dev(h7), _dev(ws, torch.uint8), nb, _stream()), "nerfart_sdf_nabla_fwd")
     return sdf, nab, h7
+
+
+def nabla_workspace(precision: int, device):
+    """The reverse-mode grad(SDF) kernels' scratch (softplus' of the forward sweep), from PyTorch's caching allocator: visible
+    to torch.cuda.max_memory_allocated(), stream-ordered like every other tensor of the call."""
+    nb = int(lib.nerfart_sdf_nabla_workspace_bytes(int(precision)))
+    return (torch.empty(nb, dtype=torch.uint8, device=device) if nb else None), nb
+
+
+def wgrad(Z, A, n_mats: int, rows: int, a_cols: int, z_stride: int, a_stride: int, cs_rows: int = 0, want_cs: bool = False):
+    """dW [n_mats, 256, a_cols] fp32 = Z_m^T A_m (+ cs [n_mats, 256] = column sums of the first cs_rows rows of Z_m) over bf16
+    row-major operands: Z / A are tensors whose data_ptr() is matrix 0 ([rows, 256] / [rows, a_cols]); strides in BYTES between
+    matrices (0 = shared operand).  nerfart_wgrad_bf16 (csrc/wgrad.hip)."""
+    dev = Z.device
+    assert Z.dtype == torch.bfloat16 and A.dtype == torch.bfloat16 and Z.is_cuda and A.is_cuda
+    dW = torch.empty(n_mats, 256, a_cols, dtype=torch.float32, device=dev)
+    cs = torch.empty(n_mats, 256, dtype=torch.float32, device=dev) if want_cs else None
+    nb = int(lib.nerfart_wgrad_workspace_bytes(n_mats, rows, a_cols))
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    _check(lib.nerfart_wgrad_bf16(Z.data_ptr(), int(z_stride), A.data_ptr(), int(a_stride), n_mats, rows, a_cols, int(cs_rows),
+                                  _dev(dW), _dev(cs), 0, _dev(ws, torch.uint8), nb, _stream()), "nerfart_wgrad_bf16")
+    return dW, cs
 
 
 def radiance_fwd(rad_blob, view_tiles: int, pts, view, nabla, h7, precision: int = 0):

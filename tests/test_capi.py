@@ -77,6 +77,12 @@ def test_new_entry_points_validate_their_arguments_without_a_gpu():
     assert lib.nerfart_clip_style_heads(null, 17, null, null, null, null, 8, 79, 1.0, 0.2, 0.1, 2.0, 0.07, null, null, null) != 0 and "n_patches" in err()
     assert lib.nerfart_first_crossing(null, null, 5, 1, 0.0, null, null, null, null, null, null) != 0 and "n_steps" in err()
     assert lib.nerfart_first_crossing(null, null, 0, 256, 0.0, null, null, null, null, null, null) == 0          # no rays: nothing to do
+    # round 3: the reverse-mode grad(SDF) scratch is the caller's (no hipMalloc inside the library)
+    assert lib.nerfart_sdf_nabla_workspace_bytes(1) == 256 * 7 * 8 * 8 * 1024 and lib.nerfart_sdf_nabla_workspace_bytes(0) > 0
+    assert lib.nerfart_sdf_nabla_workspace_bytes(2) == 0 and lib.nerfart_sdf_nabla_workspace_bytes(3) == 0
+    one = C.c_void_p(16)                                           # a non-null, never dereferenced pointer: the checks come first
+    assert lib.nerfart_sdf_nabla_fwd(one, 1, one, 4, 3.0, one, one, null, null, 0, null) != 0 and "workspace" in err()
+    assert lib.nerfart_sdf_nabla_fwd(one, 1, one, 4, 3.0, one, one, null, one, 1024, null) != 0 and "workspace" in err()
     offs = (C.c_longlong * 22)()
     total = lib.nerfart_vgg16_blob_layout(C.cast(offs, C.c_void_p))
     assert offs[21] == total and total > 2 * 2 * (64 * 64 + 9 * (64 * 64 + 64 * 128 + 128 * 128 + 128 * 256 + 2 * 256 * 256))

@@ -287,6 +287,19 @@ def test_edge_cases():
     assert s0.shape == (0,) and n0.shape == (0, 3) and h0.shape == (0, 256)
     with pytest.raises(RuntimeError, match="precision"):
         hip.sdf_nabla_fwd(blob, torch.zeros(4, 3, device=DEV), 3.0, precision=7)
+    # the reverse-mode scratch is the caller's: it comes from PyTorch's caching allocator (visible to its statistics) and the
+    # entry point refuses a missing / short one
+    import ctypes as C
+    torch.cuda.synchronize(); torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
+    before = torch.cuda.max_memory_allocated()
+    hip.sdf_nabla_fwd(blob, torch.zeros(256, 3, device=DEV), 3.0, precision=0)
+    assert torch.cuda.max_memory_allocated() - before >= hip.lib.nerfart_sdf_nabla_workspace_bytes(0)
+    x4 = torch.zeros(4, 3, device=DEV)
+    outs = [torch.empty(4, device=DEV), torch.empty(4, 3, device=DEV)]
+    small = torch.empty(1024, dtype=torch.uint8, device=DEV)
+    rc = hip.lib.nerfart_sdf_nabla_fwd(C.c_void_p(blob.data_ptr()), 0, C.c_void_p(x4.data_ptr()), 4, 3.0, C.c_void_p(outs[0].data_ptr()),
+                                       C.c_void_p(outs[1].data_ptr()), None, C.c_void_p(small.data_ptr()), 1024, None)
+    assert rc != 0 and "workspace" in hip.lib.nerfart_last_error().decode()
     with pytest.raises(RuntimeError, match="precision"):
         hip.sdf_fwd(blob, torch.zeros(4, 3, device=DEV), 3.0, precision=3)      # the forward-mode cross-check exists for nabla only
     o = torch.tensor([[[0.0, 0.0, -2.5]]], device=DEV)

@@ -8,6 +8,9 @@ from conftest import scene_state, tt
 from test_gpu_parity import DEV
 
 pytestmark = pytest.mark.gpu
+# gradients of the native pass 2 against the reference Trainer's own autograd (goldens): relative error of every parameter's gradient
+# norm / of its leading 32 entries
+NORM_TOL, HEAD_TOL = 5e-3, 1e-2          # round 2: 2e-2 / 5e-2; measured (profiles/r03g_train_err.log): <= 4.7e-3 / 9.4e-3
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
@@ -494,6 +497,7 @@ def test_reconstruction_branch_matches_the_reference_trainer(fw):
         # the eikonal term of the VolSDF branch sits on an arg-max (the sample of largest visibility weight): one ray whose two
         # best samples are a rounding apart moves it by a fraction of a percent
         np.testing.assert_allclose(out[k], float(z[tag + k]), rtol=1e-2 if k == "loss_eikonal" else 2e-3, atol=2e-6, err_msg=k)
+    worst_n = worst_h = 0.0
     for name, p in model.named_parameters():
         key = tag + "gradnorm_" + name
         if key not in z.files:
@@ -502,9 +506,15 @@ def test_reconstruction_branch_matches_the_reference_trainer(fw):
         gold_n = float(z[key])
         head = torch.from_numpy(z[tag + "gradhead_" + name]).to(DEV)
         got = p.grad.reshape(-1)[: head.numel()]
-        assert abs(float(p.grad.norm()) - gold_n) <= 2e-2 * gold_n + 1e-7, (name, float(p.grad.norm()), gold_n)
+        worst_n = max(worst_n, abs(float(p.grad.norm()) - gold_n) / (gold_n + 1e-12))
+        assert abs(float(p.grad.norm()) - gold_n) <= NORM_TOL * gold_n + 1e-7, (name, float(p.grad.norm()), gold_n)
         rel = float((got - head).norm() / (head.norm() + 1e-12))
-        assert rel < 5e-2 or float(head.norm()) < 1e-3 * gold_n, (name, rel)
+        if float(head.norm()) >= 1e-3 * gold_n:
+            worst_h = max(worst_h, rel)
+            if rel > 3e-3:
+                print(f"    {name}: leading-entries error {rel:.2e}, norm error {abs(float(p.grad.norm()) - gold_n) / gold_n:.2e}")
+        assert rel < HEAD_TOL or float(head.norm()) < 1e-3 * gold_n, (name, rel)
+    print(f"  reconstruction branch {fw}: worst gradient-norm error {worst_n:.2e}, worst leading-entries error {worst_h:.2e} (vs the reference Trainer)")
 
 
 @pytest.mark.parametrize("fw", ["VolSDF", "NeuS"])
@@ -533,6 +543,7 @@ def test_finetune_branch_matches_the_reference_trainer(fw):
     ret = tr(args, torch.tensor([0]), model_input, ground_truth, rk, 0, optimizer=opt)
     np.testing.assert_allclose(float(ret["losses"]), float(z[tag + "loss"]), rtol=2e-3)
     n = 0
+    worst_n = worst_h = 0.0
     for name, p in model.named_parameters():
         key = tag + "gradnorm_" + name
         if key not in z.files:
@@ -542,7 +553,13 @@ def test_finetune_branch_matches_the_reference_trainer(fw):
         gold_n = float(z[key])
         head = torch.from_numpy(z[tag + "gradhead_" + name]).to(DEV)
         got = p.grad.reshape(-1)[: head.numel()]
-        assert abs(float(p.grad.norm()) - gold_n) <= 2e-2 * gold_n + 1e-8, (name, float(p.grad.norm()), gold_n)
+        worst_n = max(worst_n, abs(float(p.grad.norm()) - gold_n) / (gold_n + 1e-12))
+        assert abs(float(p.grad.norm()) - gold_n) <= NORM_TOL * gold_n + 1e-8, (name, float(p.grad.norm()), gold_n)
         rel = float((got - head).norm() / (head.norm() + 1e-12))
-        assert rel < 5e-2 or float(head.norm()) < 1e-3 * gold_n, (name, rel)
+        if float(head.norm()) >= 1e-3 * gold_n:
+            worst_h = max(worst_h, rel)
+            if rel > 3e-3:
+                print(f"    {name}: leading-entries error {rel:.2e}, norm error {abs(float(p.grad.norm()) - gold_n) / gold_n:.2e}")
+        assert rel < HEAD_TOL or float(head.norm()) < 1e-3 * gold_n, (name, rel)
+    print(f"  fine-tune branch {fw}: worst gradient-norm error {worst_n:.2e}, worst leading-entries error {worst_h:.2e} (vs the reference Trainer)")
     assert n == (43 if fw == "VolSDF" else 28)

@@ -8,15 +8,26 @@ CSRC = os.path.join(ROOT, "nerfart_amd", "csrc")
 OUT = os.path.join(ROOT, "gpurun_ablate")
 
 
+VARIANTS = {
+    "no_scratch": ["-DNERFART_ABLATE_SCRATCH"],
+    "no_scratch_stores": ["-DNERFART_ABLATE_SCRATCH_ST"],
+    "no_scratch_loads": ["-DNERFART_ABLATE_SCRATCH_LD"],
+    "small_scratch": ["-DNERFART_EXP_SCRATCH_SMALL"],
+    "late_store": ["-DNERFART_EXP_ST_LATE"],
+    "late_store_no_loads": ["-DNERFART_EXP_ST_LATE", "-DNERFART_ABLATE_SCRATCH_LD"],
+}
+
+
 def build():
     os.makedirs(OUT, exist_ok=True)
     objs = [os.path.join(CSRC, "_build", f) for f in os.listdir(os.path.join(CSRC, "_build")) if f.endswith(".o") and f != "mlp_grad_bf16.o"]
-    obj = os.path.join(OUT, "grad_noscratch.o")
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-x", "hip", "-DNERFART_ABLATE_SCRATCH",
-                           "-c", os.path.join(CSRC, "mlp_grad_bf16.hip"), "-o", obj])
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(OUT, "libgrad_noscratch.so")] + objs + [obj])
-    os.remove(obj)
-    print("built")
+    for name, defs in VARIANTS.items():
+        obj = os.path.join(OUT, f"grad_{name}.o")
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-x", "hip"] + defs +
+                              ["-c", os.path.join(CSRC, "mlp_grad_bf16.hip"), "-o", obj])
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(OUT, f"libgrad_{name}.so")] + objs + [obj])
+        os.remove(obj)
+    print("built", list(VARIANTS))
 
 
 def run():
@@ -36,7 +47,7 @@ for want in (True, False):
     print("MS", "h7" if want else "no_h7", e0.elapsed_time(e1) / 5)
 ''' % ROOT
     res = {}
-    for name, lib in (("full", None), ("no_scratch", os.path.join(OUT, "libgrad_noscratch.so"))):
+    for name, lib in [("full", None)] + [(n, os.path.join(OUT, f"libgrad_{n}.so")) for n in VARIANTS]:
         env = dict(os.environ)
         if lib:
             env["NERFART_HIP_LIB"] = lib
