@@ -111,9 +111,13 @@ def main():
         o_, d_, _ = rend_util.get_rays(c2w[None].to(dev), K[None].to(dev), H, W)
         shared.append((o_, d_))
 
+    # ... of which each rank keeps its own 2,048-ray tiles resident (the inputs of the timed step: the shard's rays, like the whole
+    # frame's rays in the other mode, are made before the clock starts - nerfart_amd.dist.shard_rays)
+    shared_mine = [nd.shard_rays(o_, d_, tile=2048) for (o_, d_) in shared] if world > 1 else shared
+
     def step_tiles(s, detailed=False):
-        o, d = shared[s]
-        return nd.render_sharded(render_fn, o, d, tile=2048, require_nablas=True, calc_normal=True, detailed_output=False, **kw)
+        o, d = shared_mine[s]
+        return nd.render_sharded(render_fn, o, d, tile=2048, n_rays=H * W, require_nablas=True, calc_normal=True, detailed_output=False, **kw)
 
     def timed(fn, profile=False):
         """W warm-up calls, then exactly K timed ones between barrier + synchronize pairs; max over ranks."""
@@ -160,7 +164,8 @@ def main():
         H5, W5 = 960, 540
         c2w5, K5 = scene.camera(H5, W5, angle=angles[0])
         o5, d5, _ = rend_util.get_rays(c2w5[None].to(dev), K5[None].to(dev), H5, W5)
-        big = lambda: nd.render_sharded(render_fn, o5, d5, tile=2048, require_nablas=True, calc_normal=True, detailed_output=False, **kw)
+        o5m, d5m = nd.shard_rays(o5, d5, tile=2048)
+        big = lambda: nd.render_sharded(render_fn, o5m, d5m, tile=2048, n_rays=H5 * W5, require_nablas=True, calc_normal=True, detailed_output=False, **kw)
         big()
         torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
         t5 = time.perf_counter()
@@ -174,15 +179,31 @@ def main():
         m32, _, f32 = scene.build_model("VolSDF", seed=0, beta=args.beta, device=dev, precision="fp32")
         m32.packed()
         o_, d_ = rays[0]
-        f32(o_, d_, require_nablas=True, calc_normal=True, detailed_output=False, **kw)
+        a32, _, _ = f32(o_, d_, require_nablas=True, calc_normal=True, detailed_output=False, **kw)
+        torch.cuda.synchronize()
+        # pixel agreement of the benchmarked precision with the exact-fp32 frame (same view): rays past the north-star 1e-3 are rays
+        # whose error-bounded sampling took another branch in the two arithmetics (tests/test_gpu_bf16x3.py bounds their share)
+        a16, _, _ = render_fn(o_, d_, require_nablas=True, calc_normal=True, detailed_output=False, **kw)
+        e16 = (a16 - a32).abs().max(dim=-1).values
+        pix = {"rays": int(e16.numel()), "rays_over_1e-3": int((e16 > 1e-3).sum()), "max_abs": round(float(e16.max()), 6),
+               "p999_abs": round(float(e16.flatten().kthvalue(int(0.999 * e16.numel())).values), 7),
+               "psnr_db": round(float(-10 * torch.log10(((a16 - a32) ** 2).mean().clamp_min(1e-20))), 1)}
+        del a32, a16, e16
+        n32 = 5                                           # five timed frames (five views of the orbit), one warm-up above
+        views32 = []
+        for s_ in range(n32):
+            c2w_, K_ = scene.camera(H, W, angle=angles[(7 * s_ + 3) % len(angles)])
+            views32.append(rend_util.get_rays(c2w_[None].to(dev), K_[None].to(dev), H, W)[:2])
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        f32(*rays[min(1, len(rays) - 1)], require_nablas=True, calc_normal=True, detailed_output=False, **kw)
+        for oo_, dd_ in views32:
+            f32(oo_, dd_, require_nablas=True, calc_normal=True, detailed_output=False, **kw)
         torch.cuda.synchronize()
-        t32 = time.perf_counter() - t1
-        secondary["fp32_exact"] = {"value": round(H * W / t32, 1), "unit": "rays/s", "ms_per_step": round(t32 * 1e3, 2), "steps": 1,
-                                   "what": "same frame with --precision fp32 (v_mfma_f32_16x16x4_f32, exact fp32 products; reverse-mode grad(SDF) kernel)",
+        t32 = (time.perf_counter() - t1) / n32
+        secondary["fp32_exact"] = {"value": round(H * W / t32, 1), "unit": "rays/s", "ms_per_step": round(t32 * 1e3, 2), "steps": n32,
+                                   "what": "same workload with --precision fp32 (v_mfma_f32_16x16x4_f32, exact fp32 products; reverse-mode grad(SDF) kernel)",
                                    "vs_ref_3090": round(H * W / t32 / 6480.0, 2)}
+        secondary["bf16x3_vs_fp32_pixels"] = pix
         del m32, f32
         # the other single-GPU configurations of BASELINE.json, one warm-up + one timed frame each (bench lines of their own: tools/)
         def one_frame(fn, Hh, Ww, **extra):
@@ -298,6 +319,28 @@ def main():
                "reference_in_survey_container": {"value": 93.0, "unit": "rays/s", "cores": 8, "cpu_model": "Intel Xeon @ 2.10GHz",
                                                  "what": "the reference's own render_fn at 128 spp, timed once in the survey "
                                                          "container (BASELINE.md section 2: 86-107 rays/s); cannot be re-run on the GPU box"}}
+
+    if cpu is not None:
+        # BASELINE configs[0] IN FULL: 64 x 64 rays, 32 coarse + 64 fine spp, the CPU plumbing case - the oracle on the
+        # host cores next to the HIP renderer on the same rays
+        H1 = W1 = 64
+        c2w1, K1 = scene.camera(H1, W1)
+        o1, d1, _ = rend_util.get_rays(c2w1[None].to(dev), K1[None].to(dev), H1, W1)
+        with torch.no_grad():
+            t1 = time.perf_counter()
+            orender.volsdf_render(sd, o1[0].cpu(), d1[0].cpu(), near=0.0, far=6.0, obj_bounding_radius=3.0, N_samples=32,
+                                  N_importance=N_IMPORTANCE, max_upsample_steps=kw["max_upsample_steps"], chunk=4096)
+            tc1 = time.perf_counter() - t1
+        kw1 = dict(kw, N_samples=32)
+        render_fn(o1, d1, require_nablas=True, calc_normal=True, detailed_output=False, **kw1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        render_fn(o1, d1, require_nablas=True, calc_normal=True, detailed_output=False, **kw1)
+        torch.cuda.synchronize()
+        tg1 = time.perf_counter() - t1
+        cpu["cfg1_64x64_32spp_in_full"] = {"value": round(H1 * W1 / tc1, 1), "unit": "rays/s", "cores": int(cores), "seconds": round(tc1, 2),
+                                           "hip_same_rays": {"value": round(H1 * W1 / tg1, 1), "unit": "rays/s", "ms": round(tg1 * 1e3, 2)},
+                                           "reference_in_survey_container": {"value": 278.0, "unit": "rays/s", "cores": 8}}
 
     if rank == 0:
         out = {

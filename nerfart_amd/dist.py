@@ -56,57 +56,105 @@ def _host_staged(t: torch.Tensor) -> bool:
     return t.is_cuda and dist.get_backend() == "gloo"
 
 
-def all_gather_tiles(t: torch.Tensor):
-    """all_gather of equally shaped [n, C] tensors -> list ordered by rank (one RCCL call)."""
-    if world_size() == 1:
-        return [t]
+def all_gather_tiles(t: torch.Tensor) -> torch.Tensor:
+    """all_gather of equally shaped [n, C] tensors -> [world, n, C] ordered by rank: one all_gather_into_tensor (RCCL)."""
+    w = world_size()
+    if w == 1:
+        return t[None]
     if _host_staged(t):
         h = t.detach().cpu().contiguous()
-        out = [torch.empty_like(h) for _ in range(world_size())]
-        dist.all_gather(out, h)
-        return [o.to(t.device) for o in out]
-    out = [torch.empty_like(t) for _ in range(world_size())]
-    dist.all_gather(out, t.contiguous())
+        out = torch.empty((w,) + tuple(h.shape), dtype=h.dtype)
+        dist.all_gather_into_tensor(out.view(w * h.shape[0], *h.shape[1:]), h)
+        return out.to(t.device)
+    out = torch.empty((w,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out.view(w * t.shape[0], *t.shape[1:]), t.contiguous())
     return out
 
 
+_KEY_WIDTHS = {"rgb": 3, "depth_volume": 1, "mask_volume": 1, "normals_volume": 3}      # columns of the [rays, C] tile (SURVEY 8e)
+_PLANS = {}
+
+
+class ShardPlan:
+    """Everything about a (n_rays, tile, world) sharding that does not depend on the frame, built ONCE and kept on the device: this
+    rank's ray indices, the size of the largest shard (the fixed all_gather size) and the permutation that turns the gathered
+    [world * n_max, C] buffer back into ray order (one index_select per frame instead of `world` masked scatters)."""
+
+    def __init__(self, n_rays: int, tile: int, rank_: int, world: int, device):
+        per = [my_ray_indices(n_rays, tile, q, world) for q in range(world)]
+        self.n_rays, self.tile, self.world, self.rank = n_rays, tile, world, rank_
+        self.n_max = max(int(t.numel()) for t in per)
+        self.idx = per[rank_].to(device)
+        src = torch.empty(n_rays, dtype=torch.long)
+        for q, t in enumerate(per):
+            src[t] = q * self.n_max + torch.arange(t.numel())
+        self.unshard = src.to(device)                      # full[i] = gathered.view(-1, C)[unshard[i]]
+
+
+def shard_plan(n_rays: int, tile: int, device) -> ShardPlan:
+    key = (n_rays, tile, rank(), world_size(), str(device))
+    if key not in _PLANS:
+        _PLANS[key] = ShardPlan(n_rays, tile, rank(), world_size(), device)
+    return _PLANS[key]
+
+
+def shard_rays(rays_o: torch.Tensor, rays_d: torch.Tensor, tile: int = 2048):
+    """This rank's rays of a frame ([1, n_mine, 3] each) - call it when the frame's rays are made, outside the render step."""
+    plan = shard_plan(rays_o.shape[-2], tile, rays_o.device)
+    return rays_o[:, plan.idx].contiguous(), rays_d[:, plan.idx].contiguous()
+
+
+def gather_frame(plan: ShardPlan, buf: torch.Tensor) -> torch.Tensor:
+    """buf [n_max, C] (this rank's tile rows, zero padded) -> [n_rays, C] in ray order on every rank: ONE all_gather_into_tensor
+    (RCCL over xGMI) + one index_select."""
+    if plan.world == 1:
+        return buf[: plan.n_rays]
+    if _host_staged(buf):
+        h = buf.detach().cpu().contiguous()
+        out = torch.empty(plan.world * plan.n_max, buf.shape[1], dtype=buf.dtype)
+        dist.all_gather_into_tensor(out, h)
+        out = out.to(buf.device)
+    else:
+        out = torch.empty(plan.world * plan.n_max, buf.shape[1], dtype=buf.dtype, device=buf.device)
+        dist.all_gather_into_tensor(out, buf.contiguous())
+    return out.index_select(0, plan.unshard)
+
+
 def render_sharded(render_fn, rays_o: torch.Tensor, rays_d: torch.Tensor, keys=("rgb", "depth_volume", "mask_volume", "normals_volume"),
-                   tile: int = 2048, **render_kwargs):
+                   tile: int = 2048, n_rays: int = None, **render_kwargs):
     """Ray-parallel render of one frame across all ranks.
 
-    rays_o / rays_d: [1, N, 3] (same on every rank).  Returns {key: [1, N, C]} assembled on every rank.
-    Ranks with fewer tiles pad to the largest shard so the all_gather is one fixed-size call."""
-    w, r = world_size(), rank()
-    N = rays_o.shape[-2]
+    rays_o / rays_d: [1, N, 3], the same on every rank - or, with `n_rays` = N given, already this rank's shard of the frame
+    (`shard_rays`: the gather then happens once where the rays are made, not inside the step).  Returns {key: [1, N, C]}
+    assembled on every rank.  Ranks with fewer tiles pad to the largest shard so the all_gather is one fixed-size call; the
+    sharding's index tensors are built once per (N, tile, world) (`shard_plan`)."""
+    sharded_in = n_rays is not None
+    N = n_rays if sharded_in else rays_o.shape[-2]
     dev = rays_o.device
-    idx = my_ray_indices(N, tile, r, w, dev)
-    _, _, ex = render_fn(rays_o[:, idx], rays_d[:, idx], **render_kwargs) if idx.numel() else (None, None, {})
-    cols, widths = [], []
+    plan = shard_plan(N, tile, dev)
+    n_mine = int(plan.idx.numel())
+    if sharded_in:
+        assert rays_o.shape[-2] == n_mine, (rays_o.shape, n_mine)
+        ro, rd = rays_o, rays_d
+    else:
+        ro, rd = rays_o[:, plan.idx], rays_d[:, plan.idx]
+    ex = render_fn(ro, rd, **render_kwargs)[2] if n_mine else {}
+    widths = []
     for k in keys:
-        if idx.numel():
+        if n_mine:
             v = ex[k][0]
-            v = v[:, None] if v.dim() == 1 else v
+            widths.append(1 if v.dim() == 1 else v.shape[1])
         else:
-            v = None
-        cols.append(v)
-        widths.append(None if v is None else v.shape[1])
-    if w == 1:
-        return {k: (c[None] if c.shape[1] > 1 else c[None, :, 0]) for k, c in zip(keys, cols)}
-    # widths must agree across ranks even if a rank had no rays: exchange them
-    wt = torch.tensor([x if x is not None else 0 for x in widths], dtype=torch.long)
-    wt = wt if dist.get_backend() == "gloo" else wt.to(dev)
-    dist.all_reduce(wt, op=dist.ReduceOp.MAX)
-    widths = wt.tolist()
-    n_max = max(len(my_ray_indices(N, tile, q, w)) for q in range(w))
+            widths.append(_KEY_WIDTHS[k])                   # a rank without rays still has to agree on the tile's columns
     C = sum(widths)
-    buf = torch.zeros(n_max, C, device=dev, dtype=torch.float32)
-    if idx.numel():
-        buf[: idx.numel()] = torch.cat(cols, dim=1)
-    gathered = all_gather_tiles(buf)
-    full = torch.empty(N, C, device=dev, dtype=torch.float32)
-    for q in range(w):
-        qi = my_ray_indices(N, tile, q, w, dev)
-        full[qi] = gathered[q][: qi.numel()]
+    buf = torch.zeros(plan.n_max, C, device=dev, dtype=torch.float32)
+    c0 = 0
+    for k, wd in zip(keys, widths):
+        if n_mine:
+            v = ex[k][0]
+            buf[:n_mine, c0:c0 + wd] = v[:, None] if v.dim() == 1 else v
+        c0 += wd
+    full = gather_frame(plan, buf)
     out, c0 = {}, 0
     for k, wd in zip(keys, widths):
         v = full[:, c0:c0 + wd]

@@ -450,7 +450,7 @@ class Trainer(nn.Module):
         if optimizer is not None:
             optimizer.zero_grad()
         if sharded:
-            idx = nd.my_ray_indices(rgb.shape[1], tile, nd.rank(), nd.world_size(), rgb.device)
+            idx = nd.shard_plan(rgb.shape[1], tile, rgb.device).idx          # cached per (frame size, tile, world)
             eik = self.backward_patches(rays_o.reshape(-1, 3)[idx], rays_d.reshape(-1, 3)[idx], gradient[0][idx], kept=self._kept,
                                         **render_kwargs)
             # ranks that own fewer parameters' gradients than others (none here: every rank touches every tensor)

@@ -112,7 +112,12 @@ def test_full_frame_bf16x3_vs_fp32():
     err = (a - b).abs()
     print(f"  fp32 vs bf16x3 full frame: identical rounds on {same:.4f} of rays; rgb max {err.max().item():.2e}, "
           f"99.9 pct {err.flatten().kthvalue(int(0.999 * err.numel())).values.item():.2e}, PSNR {psnr:.1f} dB")
-    assert same >= 0.995 and psnr >= 80.0                   # measured 0.9967 / 87.9 dB
+    over = int((err.max(dim=-1).values > 1e-3).sum())
+    print(f"  rays whose bf16x3 pixel differs from the fp32 pixel by more than 1e-3: {over} of {H * W} ({over / (H * W):.5f})")
+    # measured (profiles/r03i_parity_s.log): 0.9966 identical rounds, max 3.5e-3, 87.6 dB; the rays past 1e-3 are rays whose
+    # error-bounded sampling took a different branch in the two arithmetics (Algorithm 1 is discontinuous), not arithmetic error
+    assert same >= 0.995 and psnr >= 85.0 and err.max().item() < 8e-3
+    assert over <= 0.002 * H * W
 
 
 @pytest.mark.parametrize("M", [1, 127, 128, 1500])

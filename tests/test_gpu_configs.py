@@ -131,15 +131,16 @@ def test_cfg5_960x540_frame_properties_and_oracle_subset():
     same = ex_s["iter_usage"][0].cpu() == ref["iter_usage"]
     err = (rgb_s[0].cpu() - ref["rgb"]).abs().max(dim=-1).values
     print(f"  960x540 subset: identical rounds on {same.float().mean():.3f}; max rgb err (same rounds) {err[same].max():.2e}, (all) {err.max():.2e}")
-    assert same.float().mean() >= 0.95
-    assert err[same].max() < 1e-3 and err.max() < 2e-2
+    assert same.float().mean() >= 0.98                      # measured 1.000 (round 3), flipped rays 0
+    assert err[same].max() < 1e-3 and err.max() < 5e-3
     assert (depth_s[0].cpu() - ref["depth_volume"])[same].abs().max() < 1e-2
 
 
 def test_cfg2_bf16x3_full_frame_vs_oracle():
     """The benchmarked configuration and precision against the oracle itself (not against the HIP fp32 frame): 320 rays strided
-    over the 480 x 270 frame.  Budget: at most 2 % of rays may take a different number of up-sampling rounds than the CPU; all
-    others meet the north-star 1e-3 on every channel; the flipped rays stay within 2e-2 and the subset's PSNR >= 60 dB."""
+    over the 480 x 270 frame.  Budget: at most 1 % of rays may take a different number of up-sampling rounds than the CPU; all
+    others meet the north-star 1e-3 on every channel; the flipped rays stay within 5e-3 and the subset's PSNR >= 80 dB
+    (measured, profiles/r03i_parity_s.log: 0 of 320 flipped, max 5.5e-4, 92.4 dB; round 2: 0.31 % flipped at 4.75e-4)."""
     from nerfart_amd import scene
     from oracle import render
     model, rk, render_fn = scene.build_model("VolSDF", seed=0, beta=0.01, device=DEV, precision="bf16x3")
@@ -157,9 +158,9 @@ def test_cfg2_bf16x3_full_frame_vs_oracle():
     psnr = -10 * np.log10(max(float(((got - ref["rgb"]) ** 2).mean()), 1e-20))
     print(f"  bf16x3 vs oracle, {n} rays: identical rounds {same.float().mean():.4f}; max err same-rounds {err[same].max():.2e}, "
           f"flipped {float(err[~same].max()) if (~same).any() else 0.0:.2e}; PSNR {psnr:.1f} dB")
-    assert same.float().mean() >= 0.98
+    assert same.float().mean() >= 0.99
     assert err[same].max() < 1e-3, "north-star pixel bound on every ray that sampled the same rounds"
-    assert err.max() < 2e-2 and psnr >= 60.0
+    assert err.max() < 5e-3 and psnr >= 80.0
     assert (depth[0, sel].cpu() - ref["depth_volume"])[same].abs().max() < 1e-2
 
 

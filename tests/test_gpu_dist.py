@@ -63,3 +63,65 @@ def test_sharded_finetune_step_two_ranks_one_gpu(tmp_path):
     errs = [open(tmp_path / f).read() for f in os.listdir(tmp_path) if f.startswith("err")]
     assert not errs, errs[0]
     assert sorted(f for f in os.listdir(tmp_path)) == ["ok0", "ok1"]
+
+
+def _nccl_worker(rank, world, port, out_dir):
+    """One rank per GPU over RCCL (the production backend): the sharded frame equals the single-process frame bit for bit and the
+    sharded fine-tune step's all-reduced gradients equal the single-process step's."""
+    import numpy as np
+    import torch.distributed as dist
+    try:
+        torch.cuda.set_device(rank)
+        dev = torch.device("cuda", rank)
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, device_id=dev)
+        from nerfart_amd import scene, rend_util, dist as nd
+        from nerfart_amd.trainer import Trainer
+        model, rk, render_fn = scene.build_model("VolSDF", seed=0, beta=0.01, device=dev, precision="bf16x3")
+        H, W = 96, 54
+        c2w, K = scene.camera(H, W)
+        o, d, _ = rend_util.get_rays(c2w[None].to(dev), K[None].to(dev), H, W)
+        kw = {k: v for k, v in rk.items() if k != "rayschunk"}
+        keys = ("rgb", "depth_volume", "mask_volume", "normals_volume")
+        frame = nd.render_sharded(render_fn, o, d, keys=keys, tile=256, detailed_output=False, require_nablas=True, calc_normal=True, **kw)
+        om, dm = nd.shard_rays(o, d, tile=256)
+        frame2 = nd.render_sharded(render_fn, om, dm, keys=keys, tile=256, n_rays=H * W, detailed_output=False, require_nablas=True,
+                                   calc_normal=True, **kw)
+        with torch.no_grad():
+            _, _, ex = render_fn(o, d, detailed_output=False, require_nablas=True, calc_normal=True, **kw)
+        for k in keys:
+            np.testing.assert_array_equal(frame[k].cpu().numpy(), ex[k].cpu().numpy(), err_msg=k)
+            np.testing.assert_array_equal(frame2[k].cpu().numpy(), ex[k].cpu().numpy(), err_msg=k + " (pre-sharded rays)")
+        target = (torch.rand(1, H * W, 3, generator=torch.Generator().manual_seed(2)) * 0.2 + 0.6).to(dev)
+        loss_fn = lambda pred, gt: ((pred - gt) ** 2).mean()
+        tr = Trainer(model, pass2_rays=64, patches_per_launch=2)
+        model.zero_grad()
+        out = tr.finetune_step(render_fn, o, d, target, H, loss_fn, **kw)
+        sharded = {n: p.grad.clone() for n, p in model.named_parameters()}
+        torch.cuda.synchronize()
+        dist.barrier()
+        # the single-process step on every rank (no process group in the way: world_size() is read from torch.distributed)
+        dist.destroy_process_group()
+        model.zero_grad()
+        ref = Trainer(model, pass2_rays=64, patches_per_launch=2).finetune_step(render_fn, o, d, target, H, loss_fn, **kw)
+        assert abs(out["loss"] - ref["loss"]) < 1e-7
+        for n, p in model.named_parameters():
+            rel = float((sharded[n] - p.grad).norm() / (p.grad.norm() + 1e-12))
+            assert rel < 1e-4, (n, rel)
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    except Exception:
+        import traceback
+        open(os.path.join(out_dir, f"err{rank}"), "w").write(traceback.format_exc())
+        raise
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs: the RCCL path (one process per GPU); the 1-GPU box runs the gloo variant above")
+def test_sharded_render_and_finetune_step_over_rccl(tmp_path):
+    import torch.multiprocessing as mp
+    world = min(torch.cuda.device_count(), 8)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    mp.spawn(_nccl_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    errs = [open(tmp_path / f).read() for f in os.listdir(tmp_path) if f.startswith("err")]
+    assert not errs, errs[0]
+    assert len([f for f in os.listdir(tmp_path) if f.startswith("ok")]) == world

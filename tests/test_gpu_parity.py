@@ -250,11 +250,13 @@ def test_volsdf_render_matches_reference_golden(golden, beta, ns):
            "implicit_surface": (3e-5, 0), "implicit_nablas": (3e-4, 3e-4), "radiance": (1e-4, 0), "alpha": (2e-4, 0),
            "p_i": (2e-4, 0), "visibility_weights": (2e-4, 0), "d_vals": (3e-4, 0), "sigma": (1e-2, 2e-3),
            "beta_map": (1e-6, 0.2), "iter_usage": (0, 0)}
+    # per-sample keys: the floor is the measured fraction of each case (profiles/r03i_parity_s.log) minus a hair - 1.000 on every
+    # key at beta 0.1; >= 0.9954 at beta 0.01 n128; >= 0.9906 at beta 0.002; the beta 0.01 n32 case has ONE ray of 64 (1.6 %) whose
+    # bisection takes another branch (0.967 .. 0.985 of the entries agree).  Round 2 passed all four at 0.96.
+    floor = {(0.1, 128): 1.0, (0.01, 128): 0.995, (0.002, 128): 0.99, (0.01, 32): 0.965}[(beta, ns)]
     for k in keys:
         a, r = tol[k]
-        # measured (round 2, gpurun_out/r02a_pytest.log): 1.000 on every key at beta 0.1, >= 0.995 at beta 0.002 / 0.01 n128; the
-        # beta 0.01 n32 case has ONE ray of 64 whose bisection takes another branch (0.967 .. 0.985 of its entries differ)
-        close(k, ex[k][0].cpu()[m], tt(golden[tag + k])[m], a, r, frac=0.96)
+        close(k, ex[k][0].cpu()[m], tt(golden[tag + k])[m], a, r, frac=floor)
     # the pixel bound of north_star holds for EVERY ray
     close("rgb (all rays, 1e-3)", ex["rgb"][0].cpu()[m], tt(golden[tag + "rgb"])[m], 1e-3)
     close("mask (all rays, 1e-3)", ex["mask_volume"][0].cpu()[m], tt(golden[tag + "mask_volume"])[m], 1e-3)
@@ -348,6 +350,7 @@ def test_full_frame_properties():
         ref = render.volsdf_render(sd, ro[0].cpu(), rd[0].cpu(), near=0.0, far=6.0, obj_bounding_radius=3.0, N_samples=128, max_upsample_steps=6)
     same = (ex_s["iter_usage"][0].cpu() == ref["iter_usage"])
     print("  full-frame subset: identical iter_usage on", same.double().mean().item())
+    assert same.double().mean().item() >= 0.98, "fp32 path: measured 1.000 (64 of 64 rays take the CPU's number of rounds)"
     close("rgb vs oracle", rgb_s[0].cpu()[same], ref["rgb"][same], 1e-4, frac=0.97)
     close("rgb vs oracle (all rays, 1e-3)", rgb_s[0].cpu()[same], ref["rgb"][same], 1e-3)
     close("depth vs oracle", depth_s[0].cpu()[same], ref["depth_volume"][same], 5e-3)
