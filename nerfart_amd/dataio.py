@@ -128,9 +128,16 @@ class SceneDataset(torch.utils.data.Dataset):
         pixels = np.stack([load_rgb(f, downscale) for f in frames])           # [n, 3, H, W]
         self.H, self.W = pixels.shape[-2:]
         self.rgb_images = list(torch.from_numpy(np.ascontiguousarray(pixels.reshape(self.n_images, 3, -1).transpose(0, 2, 1))).float().unbind(0))
+        if mattes and len(mattes) != self.n_images:
+            raise ValueError(f"{len(mattes)} mattes for {self.n_images} images: the mask folder must hold one matte per image (or none)")
+        self.has_mattes = bool(mattes)
         if mattes:
             self.object_masks = list(torch.from_numpy(np.stack([load_mask(m, downscale).reshape(-1) for m in mattes])).bool().unbind(0))
-        else:                                                                   # no matte folder: everything is object
+        else:
+            # no matte folder: the reference leaves its list empty and __getitem__ fails; here every pixel counts as object, which
+            # is only right for objectives WITHOUT a mask term (VolSDF; NeuS with w_mask = 0) - `has_mattes` lets the caller refuse
+            import warnings
+            warnings.warn("SceneDataset: no mattes found - object_mask is all ones; do not train a mask loss (NeuS w_mask > 0) on this scene")
             self.object_masks = list(torch.ones(self.n_images, self.H * self.W, dtype=torch.bool).unbind(0))
 
     def __len__(self):

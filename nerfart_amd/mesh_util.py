@@ -40,14 +40,18 @@ def sdf_volume(implicit_surface, volume_size: float = 2.0, N: int = 512, chunk: 
     return out.reshape(N, N, N)
 
 
-def extract_mesh(implicit_surface, volume_size=2.0, level=0.0, N=512, filepath="./surface.ply", show_progress=True, chunk=1 << 24):
-    """mesh_util.extract_mesh: SDF volume -> marching cubes -> .ply (needs skimage and plyfile)."""
+def extract_mesh(implicit_surface, volume_size=2.0, level=0.0, N=512, filepath="./surface.ply", show_progress=True, chunk=1 << 24,
+                 reference_shear: bool = False):
+    """mesh_util.extract_mesh: SDF volume -> marching cubes -> .ply (needs skimage and plyfile).  reference_shear=True samples
+    the sheared grid the reference's true-division index arithmetic produces under Python 3 (vertex-for-vertex parity with its
+    meshes); the default is the regular grid ("deviations").  show_progress is accepted for call compatibility:
+    the sweep is a handful of kernel launches, there is nothing to show."""
     try:
         from skimage import measure
         import plyfile
     except ImportError as e:                                        # pragma: no cover - third-party, absent in this image
         raise ImportError("extract_mesh needs scikit-image (marching cubes) and plyfile; sdf_volume() returns the SDF grid without them") from e
-    vol = sdf_volume(implicit_surface, volume_size, N, chunk).cpu().numpy()
+    vol = sdf_volume(implicit_surface, volume_size, N, chunk, reference_shear=reference_shear).cpu().numpy()
     spacing = volume_size / N                                        # the reference passes volume_size / N (not / (N - 1)), mesh_util.py:112
     verts, faces, _, _ = measure.marching_cubes(vol, level=level, spacing=[spacing] * 3)
     verts = verts + np.array([-volume_size / 2.0] * 3)

@@ -100,7 +100,7 @@ def surface_render(rays_o, rays_d, model, calc_normal=True, rayschunk=8192, netc
                    show_progress=False, ray_casting_algo="", ray_casting_cfgs={}, **not_used_kwargs):
     """render.py's `--use_surface_render` path (ray_casting.py:185-263): ray cast to the surface, shade the hit points with
     model.forward.  -> (colors [(B), N, 3] (0 where nothing is hit), depths, extras{implicit_nablas, mask_surface[, normals_surface]}).
-    rays_d is NOT normalised on entry.  rayschunk / netchunk are accepted and ignored (results do not depend on chunking)."""
+    rays_d is NOT normalised on entry.  Rays are marched in slices of rayschunk (results do not depend on it); netchunk is accepted and ignored."""
     if ray_casting_algo not in ("root_finding", "sphere_tracing"):
         raise NotImplementedError(f"ray_casting_algo {ray_casting_algo!r}")
     if not use_view_dirs:
@@ -109,12 +109,22 @@ def surface_render(rays_o, rays_d, model, calc_normal=True, rayschunk=8192, netc
         shape = [rays_d.shape[0], -1, 3] if batched else [-1, 3]
         o = rays_o.reshape(shape).float()
         dn = F.normalize(rays_d.reshape(shape).float(), dim=-1)
-        if ray_casting_algo == "root_finding":
-            depths, pts, mask, _ = root_finding_surface_points(model.implicit_surface, o, dn, batched=batched, **ray_casting_cfgs)
-        else:
-            depths, pts, mask = sphere_tracing_surface_points(model.implicit_surface, o, dn, batched=batched, **ray_casting_cfgs)
-        colors, _, nablas = model.forward(pts.contiguous(), dn.contiguous())
-        colors = torch.where(mask[..., None], colors, torch.zeros_like(colors))
+        # rays are independent: march them in slices of `rayschunk` (never more than 2^31 march samples per launch), as the
+        # reference does (ray_casting.py:241-262) - the [rays, N_steps] march buffers stay bounded, the results are identical
+        n_steps = int(ray_casting_cfgs.get("N_steps", 256)) if ray_casting_algo == "root_finding" else 1
+        N = o.shape[-2]
+        step = max(1, min(int(rayschunk) if rayschunk else N, ((1 << 31) - 1) // max(n_steps, 1)))
+        parts = []
+        for s in range(0, N, step):
+            oc, dc = o[..., s:s + step, :].contiguous(), dn[..., s:s + step, :].contiguous()
+            cfg = {k: (v[..., s:s + step] if torch.is_tensor(v) and v.dim() >= 1 and v.shape[-1] == N else v) for k, v in ray_casting_cfgs.items()}
+            if ray_casting_algo == "root_finding":
+                depths, pts, mask, _ = root_finding_surface_points(model.implicit_surface, oc, dc, batched=batched, **cfg)
+            else:
+                depths, pts, mask = sphere_tracing_surface_points(model.implicit_surface, oc, dc, batched=batched, **cfg)
+            colors, _, nablas = model.forward(pts.contiguous(), dc)
+            parts.append((torch.where(mask[..., None], colors, torch.zeros_like(colors)), depths, nablas, mask))
+        colors, depths, nablas, mask = (torch.cat([p[i] for p in parts], dim=-2 if i in (0, 2) else -1) for i in range(4))
         extras = OrderedDict([("implicit_nablas", nablas), ("mask_surface", mask)])
         if calc_normal:
             normals = F.normalize(nablas, dim=-1)

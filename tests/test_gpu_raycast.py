@@ -58,6 +58,9 @@ def test_ray_casting_matches_reference_goldens(rg, fw, precision):
         col, dep, ex = rc.surface_render(o, d, model, calc_normal=True, rayschunk=37, ray_casting_algo=algo, ray_casting_cfgs=cfgs)
         k = f"{fw}_render_{algo}_"
         assert list(ex.keys()) == ["implicit_nablas", "mask_surface", "normals_surface"]
+        col1, dep1, ex1 = rc.surface_render(o, d, model, calc_normal=True, rayschunk=4096, ray_casting_algo=algo, ray_casting_cfgs=cfgs)
+        assert torch.equal(col, col1) and torch.equal(dep, dep1) and torch.equal(ex["mask_surface"], ex1["mask_surface"]), \
+            "rays are marched in slices of rayschunk: 37-ray slices == one slice"
         m = ex["mask_surface"][0].cpu()
         assert np.array_equal(m.numpy(), rg[k + "mask_surface"])
         _close(k + "rgb", col[0], rg[k + "rgb"], 1e-4 if precision == "fp32" else 1e-3)
