@@ -272,6 +272,12 @@ __device__ __forceinline__ void epi_phase(float z0, float z1, Work& w, unsigned&
     return;
 #endif
     if constexpr (PH == 0) {
+        if constexpr (MODE == 4) {
+            // first backward step of the reverse-mode kernel: softplus'(z_7) from the same z_7 the last forward epilogue just took
+            // exp2(-|100 z|) of - hipcc merged the two and carried the 64 exponentials per lane across (spill store in the forward
+            // epilogue, scratch reload + vmcnt(0) inside the backward item stream).  Opaque copies: recompute, two VALU per pair.
+            asm volatile("" : "+v"(z0), "+v"(z1));
+        }
         if constexpr (MODE == 0 || MODE == 1 || MODE == 4 || MODE == 5 || MODE == 10) {
             w.e0 = __builtin_amdgcn_exp2f(fabsf(z0) * -144.269504088896340736f);     // exp(-|100 z|)
             w.e1 = __builtin_amdgcn_exp2f(fabsf(z1) * -144.269504088896340736f);
@@ -371,7 +377,18 @@ struct GradCtx {
     u32x4 dacc;               // forward sweep: unit being packed
     u32x4 dpend;              // forward sweep: finished unit, stored at the first triple of the next k-step
     char* pend_ptr;
+    // k_sdf_grad_bf16 (round 3): its scratch is addressed as a buffer - descriptor (uniform) + ONE 32-bit voffset register (wave *
+    // 1024 + lane * 16 + the unit's byte offset) - instead of a 64-bit per-lane pointer per unit: hipcc hoisted the 56 unit
+    // addresses out of the tile loop (112 VGPRs) and spilled them, ~220 scratch reloads per lane per tile.  The
+    // unit offset goes into the vector register, not into the scalar soffset: see the note at mlp_chain.hip's Scratch.
+    bool buf = false;
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned pend_soff;
 };
+__device__ __forceinline__ u32x4 unit_load(const GradCtx& gc, int idx) {
+    if (gc.buf) return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(gc.rsrc, (int)(gc.voff + (unsigned)((idx >> 3) * gc.slot_stride + (idx & 7) * gc.unit_stride)), 0, 0));
+    return *reinterpret_cast<const u32x4*>(gc.ws + (size_t)(idx >> 3) * gc.slot_stride + (size_t)(idx & 7) * gc.unit_stride + gc.voff);
+}
 // k_radiance_bwd_bf16's sweep position `layer` (4: R3^T .. 1: R0^T, 0: W8^T) -> slot of the delta that sweep step produces
 __device__ __forceinline__ int rad_delta_slot(int layer) { return layer > 0 ? layer - 1 : 4; }
 __device__ __forceinline__ size_t uoff(const GradCtx& gc, int idx) {
@@ -394,7 +411,7 @@ __device__ __forceinline__ void d_load(GradCtx& gc, int idx, int buf) {
 #if defined(NERFART_EXP_SCRATCH_NT) && (NERFART_EXP_SCRATCH_NT & 2)
     gc.dbuf[buf] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(gc.ws + uoff(gc, idx) + gc.voff));
 #else
-    gc.dbuf[buf] = *reinterpret_cast<const u32x4*>(gc.ws + uoff(gc, idx) + gc.voff);
+    gc.dbuf[buf] = unit_load(gc, idx);
 #endif
 }
 
@@ -518,7 +535,8 @@ struct Items {
 #if defined(NERFART_EXP_SCRATCH_NT) && (NERFART_EXP_SCRATCH_NT & 1)
                     __builtin_nontemporal_store(gc.dpend, reinterpret_cast<u32x4*>(gc.pend_ptr + gc.voff_out));
 #else
-                    *reinterpret_cast<u32x4*>(gc.pend_ptr + gc.voff_out) = gc.dpend;
+                    if (gc.buf) __builtin_amdgcn_raw_buffer_store_b128(gc.dpend, gc.rsrc, (int)(gc.voff_out + gc.pend_soff), 0, 0);
+                    else *reinterpret_cast<u32x4*>(gc.pend_ptr + gc.voff_out) = gc.dpend;
 #endif
                     constexpr int PM = (ks == 0) ? L::MODE : L::mode_of(HUP);        // (mode 10 layers use 10 for both kinds)
                     if constexpr (PM == 10) *reinterpret_cast<u32x4*>(gc.pend_ptr + 8 * gc.slot_stride + gc.voff_out) = gc.dpend2;
@@ -618,7 +636,8 @@ struct Items {
                                         : (HM == 11)                     ? (HU == 100 ? (gc.layer - 1) * 8 : gc.layer * 8 + HU)
                                                                          : (HU == 100 ? rad_delta_slot(gc.layer - 1) * 8
                                                                                       : rad_delta_slot(gc.layer) * 8 + HU);
-                        gc.pend_ptr = gc.ws_out + uoff(gc, idx);
+                        if (gc.buf) gc.pend_soff = (unsigned)uoff(gc, idx);
+                        else gc.pend_ptr = gc.ws_out + uoff(gc, idx);
                     }
                 }
             }

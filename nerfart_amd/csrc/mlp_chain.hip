@@ -34,6 +34,24 @@ constexpr int LDS_FLOATS = 2 * CHUNK_FLOATS_MAX + AUX_FLOATS_MAX + TAB_INTS;   /
 constexpr int D_TILE_STRIDE = WAVES * 1024;
 constexpr int D_LAYER_STRIDE = 16 * D_TILE_STRIDE;
 constexpr size_t GRADF_WS_PER_WG = 8 * (size_t)D_LAYER_STRIDE;                 // 1 MiB
+// The reverse-mode kernel's scratch as a buffer (round 3): descriptor built from kernel arguments and blockIdx (uniform), ONE
+// 32-bit voffset register per access (wave * 1024 + lane * 16 + the layer / tile offset, one v_add) - with 64-bit lane pointers
+// hipcc hoisted the 128 (layer, tile) addresses out of the tile loop and spilled them (113 VGPR spills, now 3).
+// The layer / tile offset is NOT passed as the instruction's scalar soffset: that form (hipcc re-materialises the SGPR between
+// back-to-back accesses) returned wrong data on the MI355X for the lanes of waves 4..7 with lane % 16 >= 12, run-dependent
+// (tools/dbg_fp32_scratch.py: 12.5 % of the points of every tile, sdf and h7 exact, nabla off by up to 0.17); the same accesses with
+// the offset in the vector register, or through plain pointers, are exact.  Cause not established - avoided.
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+struct Scratch {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff;                                   // wave * 1024 + lane * 16
+};
+__device__ __forceinline__ void sc_store(const Scratch& sc, int off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, v), sc.rsrc, sc.voff + off, 0, 0);
+}
+__device__ __forceinline__ f32x4 sc_load(const Scratch& sc, int off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sc.rsrc, sc.voff + off, 0, 0));
+}
 
 using Pipe = PipeT<WAVES, CHUNK_FLOATS_MAX>;
 
@@ -78,7 +96,7 @@ __device__ __forceinline__ void mma_ktile(f32x4 (&acc)[16], const f32x4 xt, cons
 
 template <int NT_BASE, int NT_EXTRA_MAX, bool SOFTPLUS, bool TANGENT, bool DSTORE = false>
 __device__ __forceinline__ void run_layer(f32x4 (&X)[XT_MAX], Pipe& p, const float* bias_lds, bool full16, int nextra, bool relu,
-                                          char* dws = nullptr) {
+                                          const Scratch* sc = nullptr, int sc_layer = 0) {
     const int lane = lane_id();
     const int g = lane >> 4;
     const bool is_val = !TANGENT || ((lane & 3) == 0);
@@ -129,7 +147,7 @@ __device__ __forceinline__ void run_layer(f32x4 (&X)[XT_MAX], Pipe& p, const flo
             }
             X[T] = y;
             // reverse-mode kernel, forward sweep: softplus'(z) of this tile to the wave's scratch slot (D_TILE_STRIDE apart)
-            if (DSTORE) *reinterpret_cast<f32x4*>(dws + T * D_TILE_STRIDE + lane * 16) = dd;
+            if constexpr (DSTORE) sc_store(*sc, sc_layer + T * D_TILE_STRIDE, dd);
         }
     }
 }
@@ -225,14 +243,14 @@ __device__ __forceinline__ void load_aux(float* aux_lds, const float* blob, cons
 // Layer 0 (3 input tiles) has its own body; layers 1..7 share one body in a run-time loop.
 template <bool TANGENT, bool DSTORE = false>
 __device__ __forceinline__ void surface_hidden(f32x4 (&X)[XT_MAX], float px, float py, float pz, int g, int q,
-                                               Pipe& p, const float* aux, char* dws = nullptr) {
+                                               Pipe& p, const float* aux, const Scratch* sc = nullptr) {
     {
         f32x4 E[3];
         encode_slots(px, py, pz, g, q, E);
 #pragma unroll
         for (int t = 0; t < 3; ++t) X[t] = E[t];
     }
-    run_layer<3, 0, true, TANGENT, DSTORE>(X, p, aux, true, 0, false, dws);
+    run_layer<3, 0, true, TANGENT, DSTORE>(X, p, aux, true, 0, false, sc, 0);
 #pragma nounroll
     for (int L = 1; L < 8; ++L) {
         if (L == 4) {
@@ -251,7 +269,7 @@ __device__ __forceinline__ void surface_hidden(f32x4 (&X)[XT_MAX], float px, flo
                 for (int r = 0; r < 4; ++r) X[14 + t][r] = E[t][r] / rs2;
         }
         // layer 3 has 217 outputs -> 14 tiles (7 zero rows); layer 4 has 17 input tiles
-        run_layer<16, 1, true, TANGENT, DSTORE>(X, p, aux + L * 256, L != 3, (L == 4) ? 1 : 0, false, DSTORE ? dws + L * D_LAYER_STRIDE : nullptr);
+        run_layer<16, 1, true, TANGENT, DSTORE>(X, p, aux + L * 256, L != 3, (L == 4) ? 1 : 0, false, sc, L * D_LAYER_STRIDE);
     }
 }
 
@@ -348,7 +366,7 @@ k_sdf_nabla(const float* __restrict__ blob, PointSrc src, float R_bg, float* __r
 // =======================================================================================
 // g <- (W^T g) . softplus'(z of the layer below) * scale:  NT_K k tiles (the layer's outputs), 16 or 14 output tiles
 template <int NT_K>
-__device__ __forceinline__ void run_layer_T(f32x4 (&X)[XT_MAX], Pipe& p, bool full16, const char* dws_below, float scale) {
+__device__ __forceinline__ void run_layer_T(f32x4 (&X)[XT_MAX], Pipe& p, bool full16, const Scratch& sc, int layer_below, float scale) {
     const int lane = lane_id();
     f32x4 acc[16];
 #pragma unroll
@@ -362,7 +380,7 @@ __device__ __forceinline__ void run_layer_T(f32x4 (&X)[XT_MAX], Pipe& p, bool fu
     // X is dead from here: its registers take the softplus' tiles (all loads in flight together), then the products
 #pragma unroll
     for (int T = 0; T < 16; ++T)
-        if (T < 14 || full16) X[T] = *reinterpret_cast<const f32x4*>(dws_below + T * D_TILE_STRIDE + lane * 16);
+        if (T < 14 || full16) X[T] = sc_load(sc, layer_below * D_LAYER_STRIDE + T * D_TILE_STRIDE);
 #pragma unroll
     for (int T = 0; T < 16; ++T)
         if (T < 14 || full16) {
@@ -410,7 +428,9 @@ k_sdf_grad(const float* __restrict__ blob, PointSrc src, float R_bg, float* __re
     Pipe p{blob, reinterpret_cast<const int*>(aux + AUX_FLOATS_MAX), smem, hdr[6], 0, 0, 0, 0, false};     // forward + reverse chunks
     p.wrap = (blockIdx.x + gridDim.x) < ntiles;
     pipe_start(p);
-    char* dws = ws + (size_t)blockIdx.x * GRADF_WS_PER_WG + wv * 1024;
+    Scratch sc;
+    sc.rsrc = __builtin_amdgcn_make_buffer_rsrc(ws + (size_t)blockIdx.x * GRADF_WS_PER_WG, 0, (int)GRADF_WS_PER_WG, 0x00020000);
+    sc.voff = wv * 1024 + lane * 16;
     const float rs2 = 0.70710678118654752440f;
 
     for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -418,7 +438,7 @@ k_sdf_grad(const float* __restrict__ blob, PointSrc src, float R_bg, float* __re
         const unsigned m = tile * 128u + wv * 16 + j;
         const Pt pt = fetch_point(src, m, false);
         f32x4 X[XT_MAX];
-        surface_hidden<false, true>(X, pt.x, pt.y, pt.z, g, -1, p, aux, dws);
+        surface_hidden<false, true>(X, pt.x, pt.y, pt.z, g, -1, p, aux, &sc);
         float sdf = dot_row16(X, aux + SURF_AUX_ROW, g) + aux[SURF_AUX_B8];
         if (m < src.M) {
             if (R_bg > 0.f) {                           // sdf[d_bg < sdf] = d_bg, nabla untouched (volsdf.py:351-356)
@@ -435,7 +455,7 @@ k_sdf_grad(const float* __restrict__ blob, PointSrc src, float R_bg, float* __re
         // d sdf / d z_7 = row . softplus'(z_7)
 #pragma unroll
         for (int T = 0; T < 16; ++T) {
-            const f32x4 d = *reinterpret_cast<const f32x4*>(dws + 7 * D_LAYER_STRIDE + T * D_TILE_STRIDE + lane * 16);
+            const f32x4 d = sc_load(sc, 7 * D_LAYER_STRIDE + T * D_TILE_STRIDE);
             const f32x4 row = *reinterpret_cast<const f32x4*>(aux + SURF_AUX_ROW + T * 16 + g * 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) X[T][r] = row[r] * d[r];
@@ -444,12 +464,12 @@ k_sdf_grad(const float* __restrict__ blob, PointSrc src, float R_bg, float* __re
 #pragma unroll
         for (int i = 0; i < 3; ++i) E[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma nounroll
-        for (int L = 7; L >= 5; --L) run_layer_T<16>(X, p, true, dws + (L - 1) * D_LAYER_STRIDE, 1.0f);
+        for (int L = 7; L >= 5; --L) run_layer_T<16>(X, p, true, sc, L - 1, 1.0f);
         run_tail_T(X, p, E, rs2);                                                           // layer 4, encoding columns
-        run_layer_T<16>(X, p, false, dws + 3 * D_LAYER_STRIDE, rs2);                        // layer 4, the 217 hidden columns
-        run_layer_T<14>(X, p, true, dws + 2 * D_LAYER_STRIDE, 1.0f);                        // layer 3 (217 outputs = 14 k tiles)
+        run_layer_T<16>(X, p, false, sc, 3, rs2);                        // layer 4, the 217 hidden columns
+        run_layer_T<14>(X, p, true, sc, 2, 1.0f);                        // layer 3 (217 outputs = 14 k tiles)
 #pragma nounroll
-        for (int L = 2; L >= 1; --L) run_layer_T<16>(X, p, true, dws + (L - 1) * D_LAYER_STRIDE, 1.0f);
+        for (int L = 2; L >= 1; --L) run_layer_T<16>(X, p, true, sc, L - 1, 1.0f);
         run_tail_T(X, p, E, 1.0f);                                                          // layer 0
         if (nabla_out) {
 #pragma unroll

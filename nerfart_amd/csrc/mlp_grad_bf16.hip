@@ -51,8 +51,16 @@ k_sdf_grad_bf16(const float* __restrict__ blob, PointSrc src, float R_bg, float*
     s.wrap = (blockIdx.x + gridDim.x) < ntiles;
     stream_start(s);
     GradCtx gc;
-    gc.ws = ws + (size_t)blockIdx.x * GRAD_WS_PER_WG + wv * 1024;
-    gc.ws_out = gc.ws;
+    // the workgroup's 448 KiB of scratch as one buffer: descriptor from kernel arguments and blockIdx only (provably uniform),
+    // wave, lane and the unit's offset (slot * 64 KiB + unit * 8 KiB) together in the 32-bit voffset
+#ifdef NERFART_NO_BUF_SCRATCH        // A/B only (tools/ab_variant.py): the round-2 addressing, a 64-bit lane pointer per unit
+    gc.buf = false;
+    gc.ws = gc.ws_out = ws + (size_t)blockIdx.x * GRAD_WS_PER_WG;
+#else
+    gc.buf = true;
+    gc.rsrc = __builtin_amdgcn_make_buffer_rsrc(ws + (size_t)blockIdx.x * GRAD_WS_PER_WG, 0, GRAD_WS_PER_WG, 0x00020000);
+    gc.ws = gc.ws_out = nullptr;
+#endif
 #ifdef NERFART_EXP_SCRATCH_SMALL    // timing experiment: every unit lands on the same L2-resident KiB (results wrong)
     gc.slot_stride = 0;
     gc.unit_stride = 0;
@@ -60,8 +68,9 @@ k_sdf_grad_bf16(const float* __restrict__ blob, PointSrc src, float R_bg, float*
     gc.slot_stride = 8 * 8192;
     gc.unit_stride = 8192;
 #endif
-    gc.voff = gc.voff_out = lane * 16;
-    gc.pend_ptr = gc.ws;
+    gc.voff = gc.voff_out = wv * 1024 + lane * 16;
+    gc.pend_ptr = nullptr;
+    gc.pend_soff = 0;
     const EpiCtx ec{0.f, 0.f, true};
     for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         s.wrap = (tile + gridDim.x) < ntiles;
@@ -122,14 +131,10 @@ k_sdf_grad_bf16(const float* __restrict__ blob, PointSrc src, float R_bg, float*
             u32x4 d0[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const char* ptr = gc.ws + uoff(gc, u);
 #if defined(NERFART_ABLATE_SCRATCH) || defined(NERFART_ABLATE_SCRATCH_LD)
                 d0[u] = u32x4{1u, 1u, 1u, 1u};
-                (void)ptr;
-#elif defined(NERFART_EXP_SCRATCH_NT) && (NERFART_EXP_SCRATCH_NT & 2)
-                d0[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ptr + gc.voff));
 #else
-                d0[u] = *reinterpret_cast<const u32x4*>(ptr + gc.voff);
+                d0[u] = unit_load(gc, u);
 #endif
             }
             Unit X[8];
@@ -156,11 +161,16 @@ k_sdf_grad_bf16(const float* __restrict__ blob, PointSrc src, float R_bg, float*
         }
         // d sdf / d x = J_enc^T E: lane (g, j), tile t, reg r holds d sdf / d enc[f], f = 16 t + 4 g + r - 9
         float part[3] = {0.f, 0.f, 0.f};
+        // the feature bookkeeping below depends on the lane only: hipcc hoisted all of it out of the tile loop (12 x frequency,
+        // component and validity masks = ~20 VGPRs and ~60 SGPR pairs held across the whole tile) and spilled it; an opaque copy of
+        // the lane group keeps the ~180 integer instructions here, where nothing else is live
+        int gj = g;
+        asm volatile("" : "+v"(gj));
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int f = 16 * t + 4 * g + r - 9;
+                const int f = 16 * t + 4 * gj + r - 9;
                 const bool ok = (f >= 0) && (f < 39);
                 const int q = (f >= 3) ? f - 3 : 0;
                 const int k = q / 6, rem = q - 6 * k;
