@@ -250,9 +250,10 @@ def main():
         if args.precision == "bf16x3":
             # what the matrix pipe executes: MFMA_MAC_SDF multiply-adds per point, each as `mfma_per_product` bf16 MFMAs
             # (hi.hi + hi.lo + lo.hi), as a fraction of the dense bf16 peak
-            roofline["note"] = ("measured limiter (DESIGN.md 4.1b, profiles/r02k_ablate_w32.log): weight bytes moved per column - 1.9 MB of split-bf16 "
-                                "fragments per 128-point tile through L2 -> LDS-DMA -> ds_read_b128 - not matrix-pipe time (5.7 of 9.2 ms per "
-                                "4 M points)")
+            roofline["note"] = ("measured limiters (DESIGN.md 4.1b): in isolation, weight bytes moved per column - 1.9 MB of split-bf16 fragments per "
+                                "128-point tile through L2 -> LDS-DMA -> ds_read_b128 (profiles/r02k_ablate_w32.log); in the sustained frame, the "
+                                "package power cap: 1.28 - 1.33 kW of 1.4 kW while rendering, shader clock ~2.1 GHz instead of the 2.4 GHz the "
+                                "peak assumes (profiles/r03l_power_probe.log) - 3 MFMAs per product at ~0.6 of the dense-bf16 rate")
             # ceilings for this kernel in the same algorithmic-flop units (profiles/r02s_ubench_coissue.txt, tools/ubench_coissue.hip):
             # 3 MFMAs per product at the measured MFMA-only rate (17.7 nominal cycles per 16x16x32 = 0.91 of peak), and the SIMD's
             # measured issue capacity for the kernel's own mix of MFMAs, fragment reads, LDS-DMA pieces and epilogue VALU (25.0 cycles)
