@@ -59,7 +59,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (fp32 mode, the other sharding mode)")
     ap.add_argument("--cpu-rays", type=int, default=2048)
+    ap.add_argument("--frame", default="480x270", help="HxW of a frame.  480x270 is BASELINE.json's metric (the default and the only size "
+                    "the driver's line is quoted on); 960x540 is cfg 5's frame: `--frame 960x540 --steps 90 --shard tiles` is its 90-view loop")
     args = ap.parse_args()
+    global H, W
+    H, W = (int(v) for v in args.frame.lower().split("x"))
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -345,11 +349,12 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "rays/sec at 480x270x128spp VolSDF render",
+            "metric": "rays/sec at %dx%dx128spp VolSDF render" % (H, W),
             "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong" if primary_tiles else "weak",
             "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16x3 (f32 split into 2 bf16 terms, f32 accumulate)", "data": "synthetic",
-            "config": {"workload": "configs[1]: volsdf_fangzhou_nature.yaml dims, 480x270 rays/frame, 128 coarse + 64 fine "
+            "config": {"workload": ("configs[1]" if (H, W) == (480, 270) else "configs[4] frame size" if (H, W) == (960, 540) else "custom frame") +
+                                   ": volsdf_fangzhou_nature.yaml dims, %dx%d rays/frame, 128 coarse + 64 fine " % (H, W) +
                                    "spp, pure renderer (no CLIP), synthetic random-weight scene beta=%g" % args.beta,
                        "rays_per_step_per_gpu": H * W, "samples_per_ray": N_SAMPLES + N_IMPORTANCE,
                        "parallelism": ("1 GPU" if world == 1 else

@@ -36,6 +36,15 @@ def _worker(rank, world, port, n_rays, tile, q):
     out = nd.render_sharded(_fake_render, o, d, tile=tile)
     _, _, ref = _fake_render(o, d)
     ok = all(torch.equal(out[k], ref[k]) for k in ("rgb", "depth_volume", "mask_volume", "normals_volume"))
+    # the same frame with the rays sharded where they are made (outside the step): identical result; the plan is cached
+    om, dm = nd.shard_rays(o, d, tile=tile)
+    out2 = nd.render_sharded(_fake_render, om, dm, tile=tile, n_rays=n_rays)
+    ok = ok and all(torch.equal(out2[k], ref[k]) for k in ("rgb", "depth_volume", "mask_volume", "normals_volume"))
+    plan = nd.shard_plan(n_rays, tile, o.device)
+    ok = ok and plan is nd.shard_plan(n_rays, tile, o.device) and om.shape[1] == plan.idx.numel()
+    ok = ok and torch.equal(torch.sort(torch.cat([nd.my_ray_indices(n_rays, tile, q, world) for q in range(world)])).values, torch.arange(n_rays))
+    g3 = nd.all_gather_tiles(torch.full((3, 2), float(rank)))
+    ok = ok and g3.shape == (world, 3, 2) and all(float(g3[q].mean()) == q for q in range(world))
     # gradient all-reduce
     p = [torch.nn.Parameter(torch.ones(5)), torch.nn.Parameter(torch.ones(2, 3))]
     for i, t in enumerate(p):
