@@ -9,7 +9,8 @@ DEV = "cuda"
 
 
 @pytest.mark.parametrize("n_mats,rows,a_cols,cs_rows", [(1, 64, 256, 64), (3, 1000, 256, 500), (7, 40000, 256, 20000), (2, 777, 64, 777),
-                                                      (1, 32, 64, 0), (4, 123456, 256, 123456)])
+                                                      (1, 32, 64, 0), (4, 123456, 256, 123456), (1, 1, 256, 1), (2, 31, 64, 7),
+                                                      (1, 33, 256, 33), (5, 8200, 64, 100)])
 def test_wgrad_matches_fp32_matmul(n_mats, rows, a_cols, cs_rows):
     from nerfart_amd import hip
     g = torch.Generator().manual_seed(rows + a_cols)
