@@ -262,7 +262,12 @@ def main():
             # 3 MFMAs per product at the measured MFMA-only rate (17.7 nominal cycles per 16x16x32 = 0.91 of peak), and the SIMD's
             # measured issue capacity for the kernel's own mix of MFMAs, fragment reads, LDS-DMA pieces and epilogue VALU (25.0 cycles)
             roofline["ceiling_frac"] = {"matrix_pipe_only": round(0.91 / 3, 4), "issue_capacity_for_this_mix": round(0.91 / 3 * 17.7 / 25.0, 4),
-                                        "source": "profiles/r02s_ubench_coissue.txt"}
+                                        "source": "profiles/r02s_ubench_coissue.txt",
+                                        # a synthetic stream with this kernel's mix (3 MFMAs + 2 ds_read_b128 + ~6 VALU per item, random
+                                        # operands) SUSTAINS 0.562 - 0.577 of the dense-bf16 peak in executed MFMA flops at 1.23 - 1.27 kW;
+                                        # MFMAs alone 0.957 at 1.32 kW (tools/ubench_power.hip) - compare with mfma_executed_frac below
+                                        "sustained_executed_frac_same_mix": 0.577, "sustained_executed_frac_mfma_only": 0.957,
+                                        "source_sustained": "profiles/r03u_ubench_power.txt"}
             roofline["mfma_per_product"] = 3
             roofline["mfma_executed_frac"] = round(3 * 2.0 * MFMA_MAC_SDF * (points / launches) / avg_s / 1e12 / peak, 4)
         # HBM traffic per launch is a PROFILED figure, not measured in this run (bench.py cannot read hardware counters): it
