@@ -301,14 +301,18 @@ def main():
         sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
         o, d = rays[args.warmup]
 
+        last_ref = {}
+
         def cpu_run(n):                               # n rays strided over the frame, ONE chunk (>= 2,048-ray chunks once calibrated)
             sel = torch.arange(0, H * W, (H * W) // n)[:n]
             oc, dc = o[0, sel].cpu(), d[0, sel].cpu()
             with torch.no_grad():
                 t1 = time.perf_counter()
-                orender.volsdf_render(sd, oc, dc, near=0.0, far=6.0, obj_bounding_radius=3.0, N_samples=N_SAMPLES,
-                                      N_importance=N_IMPORTANCE, max_upsample_steps=kw["max_upsample_steps"], chunk=max(n, 2048))
-                return time.perf_counter() - t1
+                ref = orender.volsdf_render(sd, oc, dc, near=0.0, far=6.0, obj_bounding_radius=3.0, N_samples=N_SAMPLES,
+                                            N_importance=N_IMPORTANCE, max_upsample_steps=kw["max_upsample_steps"], chunk=max(n, 2048))
+                dt1 = time.perf_counter() - t1
+            last_ref.update(sel=sel, ref=ref)
+            return dt1
         # calibration: the port's many small tensor ops do not scale to every core of a 2-socket host - pick the thread count
         # (never more than one per PHYSICAL core) that is fastest on 256 rays, then size the sample to about 20 s of CPU work
         cands = sorted({int(cores), min(int(cores), 32), min(int(cores), 8)}, reverse=True)
@@ -323,7 +327,20 @@ def main():
         cores = threads
         n_cpu = int(min(max(20.0 * 256 / t_cal, 512), args.cpu_rays * 2) // 256 * 256)      # about 20 s of CPU work
         tc = cpu_run(n_cpu)
+        # the timed sample doubles as a parity check of THIS run: the same rays through the HIP renderer against the oracle's result
+        sel, ref = last_ref["sel"].to(dev), last_ref["ref"]
+        with torch.no_grad():
+            g_rgb, g_depth, g_ex = render_fn(o[:, sel], d[:, sel], require_nablas=True, calc_normal=True, detailed_output=True, **kw)
+        same = (g_ex["iter_usage"][0].cpu() == ref["iter_usage"])
+        e_pix = (g_rgb[0].cpu() - ref["rgb"]).abs().max(dim=-1).values
+        parity = {"rays": int(sel.numel()), "same_upsampling_rounds_frac": round(float(same.float().mean()), 5),
+                  "max_abs_rgb_same_rounds": float(f"{float(e_pix[same].max()):.3e}"),
+                  "max_abs_rgb_all": float(f"{float(e_pix.max()):.3e}"), "rays_over_1e-3": int((e_pix > 1e-3).sum()),
+                  "psnr_db": round(float(-10 * torch.log10(((g_rgb[0].cpu() - ref["rgb"]) ** 2).mean().clamp_min(1e-20))), 1),
+                  "max_abs_depth_same_rounds": float(f"{float((g_depth[0].cpu() - ref['depth_volume'])[same].abs().max()):.3e}")}
+        del g_rgb, g_depth, g_ex
         cpu = {"value": round(n_cpu / tc, 1), "unit": "rays/s", "cores": int(cores), "kind": "port", "cpu_model": cpu_model,
+               "parity_of_this_run_on_the_sample": parity,
                "sample": f"{n_cpu} rays strided over the same 480x270 frame in one chunk, {N_SAMPLES}+{N_IMPORTANCE} spp, "
                          f"oracle/render.py volsdf_render on torch-CPU fp32, {int(cores)} threads (fastest of {cands} on a 256-ray calibration), {tc:.1f} s",
                "reference_in_survey_container": {"value": 93.0, "unit": "rays/s", "cores": 8, "cpu_model": "Intel Xeon @ 2.10GHz",
