@@ -84,7 +84,7 @@ int nerfart_radiance_fwd_rays(const float* rad_blob, int precision, int view_til
  * nerfart_radiance_bwd: d loss / d rgb[M,3] -> g_h7[M,256] (cotangent of the SDF net's layer-7 activation through the
  * geometry-feature rows), g_n[M,3] (cotangent of the normal input), and bwd_dump (same layout: the deltas of
  * R0, R1, R2, R3 - each in the slot of the activation it multiplies - and the geometry-feature cotangent): the operands
- * of the weight-gradient GEMMs (dW_l = delta_l^T act_{l-1}, plain library GEMMs; nerfart_amd/autodiff.py).
+ * of the weight-gradient reductions (dW_l = delta_l^T act_{l-1}: nerfart_wgrad_bf16 below; call sequence in nerfart_amd/autodiff.py).
  * At most 2^21 points per call. */
 long long nerfart_radiance_dump_bytes(long long M);
 int nerfart_radiance_fwd_dump(const float* rad_blob, int view_tiles, const float* pts, const float* view, long long M,
@@ -102,7 +102,8 @@ int nerfart_radiance_bwd(const float* rad_blob, long long M, const float* rgb, c
  * Both dumps are matrices [slot][2 Mp][256], Mp = M rounded up to 64: rows 0..Mp-1 of a slot hold the first, rows Mp..
  * the second quantity of the pair, per point; features in unit order; so dW_l is ONE GEMM over the stacked rows, read in
  * place.  At most 2^21 points per call.
- * The GEMMs and the weight_norm chain rule are host side (nerfart_amd/autodiff.py: surface_weight_grads_raw / _finish). */
+ * The reductions are nerfart_wgrad_bf16 calls; the un-permutation and the weight_norm chain rule are host side (nerfart_amd/autodiff.py:
+ * surface_weight_grads_raw / _finish). */
 long long nerfart_sdf_fwd2_dump_bytes(long long M);
 long long nerfart_sdf_bwd2_dump_bytes(long long M);
 int nerfart_sdf_fwd2(const float* surf_blob, const float* pts, const float* dir, long long M, void* f2_dump, void* stream);

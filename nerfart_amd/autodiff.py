@@ -5,7 +5,8 @@ neus.py:520-576).
 Two formulations live here:
 * the NATIVE pass 2 (`volsdf_backward_samples_native` / `neus_backward_samples_native`, `GradAccumulator`,
   `*_weight_grads_raw / _finish`): hand-written backward kernels (hip.radiance_fwd_dump / radiance_bwd / sdf_fwd2 /
-  sdf_bwd2 / *_composite_bwd) + plain library GEMMs over their point-major dumps, read in place; what `Trainer` runs
+  sdf_bwd2 / *_composite_bwd) + the hand-written weight-gradient reduction (nerfart_wgrad_bf16) over their point-major dumps, read
+  in place; what `Trainer` runs
   on split-bf16 models;
 * the AUTOGRAD formulation (`surface_forward*`, `radiance_forward`, `volsdf_render_samples`, `neus_render_samples`):
   PyTorch autograd over rocBLAS GEMMs, including the double backward through the SDF net that the eikonal term and
