@@ -490,3 +490,28 @@ def test_batchify_query_over_the_hip_point_query(pts):
     assert torch.equal(rad, rad1) and torch.equal(sdf, sdf1) and torch.equal(nab, nab1), "results do not depend on netchunk"
     sdf_only = batchify_query(lambda q, return_nablas: model.forward_surface(q)[0], x, chunk=500, dim_batchify=1, return_nablas=False)
     close("batchify forward_surface", sdf_only.reshape(-1), s_ref, 2e-5)
+
+
+def test_nabla_entry_point_is_reentrant_across_streams():
+    """kernels must be re-entrant per device and honour the current stream.  The reverse-mode scratch is the caller's
+    (one workspace per call from the caching allocator), so two streams may run nerfart_sdf_nabla_fwd at the same time: results
+    equal the sequential ones bit for bit, in both precisions."""
+    from nerfart_amd import hip, scene
+    g = torch.Generator().manual_seed(11)
+    xs = [(torch.rand(200_000, 3, generator=g) * 4 - 2).to(DEV) for _ in range(2)]
+    for precision, name in ((0, "fp32"), (1, "bf16x3")):
+        model, _, _ = scene.build_model("VolSDF", seed=0, beta=0.01, device=DEV, precision=name)
+        blob, _ = model.packed()
+        ref = [hip.sdf_nabla_fwd(blob, x, 3.0, precision=precision) for x in xs]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        out = [None, None]
+        for rep in range(3):
+            for i, st in enumerate(streams):
+                st.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(st):
+                    out[i] = hip.sdf_nabla_fwd(blob, xs[i], 3.0, precision=precision)
+            torch.cuda.synchronize()
+            for i in range(2):
+                for a, b in zip(out[i], ref[i]):
+                    assert torch.equal(a, b), f"{name}, stream {i}, repetition {rep}: concurrent call differs from the sequential one"
