@@ -127,12 +127,14 @@ k_merge_check(SamplerParams P, const float* __restrict__ dA, const float* __rest
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int slot = blockIdx.x, ray = act[slot];
     const int n = P.n, nu = P.n_up, nm = n + nu;
-    float* d_old = sm; float* s_old = sm + n; float* dn = sm + 2 * n; float* sn = dn + nu;
-    float* d = sn + nu; float* s = d + nm;       // merged
+    // LDS: the two depth rows (searched), then the merged rows; the sdf values are read once each, straight from global memory
+    // (round 3: 3 (n + n_up) floats instead of 4 - one more ray per CU in every round; results unchanged)
+    float* d_old = sm; float* dn = sm + n;
+    float* d = dn + nu; float* s = d + nm;       // merged
+    const float* s_old = sA + (size_t)ray * P.cap;
+    const float* sn = s_new + (size_t)slot * nu;
     load_row(d_old, dA + (size_t)ray * P.cap, n);
-    load_row(s_old, sA + (size_t)ray * P.cap, n);
     load_row(dn, d_new + (size_t)slot * nu, nu);
-    load_row(sn, s_new + (size_t)slot * nu, nu);
     __syncthreads();
     // stable merge by rank: old element i goes to i + #{new < d_old[i]}; new element k to k + #{old <= d_new[k]}
     for (int i = threadIdx.x; i < n; i += 64) {
@@ -150,7 +152,7 @@ k_merge_check(SamplerParams P, const float* __restrict__ dA, const float* __rest
     }
     const float mx = error_bound_scan(d, s, nm, P.alpha_net, P.beta_net, nullptr, false);
     if (!(mx > P.eps)) {
-        float* cdf = d_old;                      // old copies are dead; n + nu <= 2n + 2nu floats available
+        float* cdf = d_old;                      // the two depth rows are dead: exactly n + nu = nm floats
         opacity_cdf(d, s, nm, P.alpha_net, P.beta_net, cdf);
         __syncthreads();
         emit_final_samples(d, cdf, nm, u_final + (size_t)ray * P.u_final_stride, P.n_final, d_fine + (size_t)ray * P.n_final);
@@ -349,7 +351,7 @@ int nerfart_volsdf_merge_check(int n_active, int n, int cap, int n_up, int n_fin
                                int* act_out, int* act_count, void* stream) {
     if (n_active <= 0) return 0;
     SamplerParams P{n, cap, n_up, n_final, max_bisect, it, eps, alpha_net, beta_net, u_final_stride};
-    const size_t lds = ((size_t)4 * n + 4 * n_up) * sizeof(float);
+    const size_t lds = ((size_t)3 * n + 3 * n_up) * sizeof(float);
     if (int rc = set_lds((const void*)k_merge_check, lds)) return rc;
     hipLaunchKernelGGL(k_merge_check, dim3(n_active), dim3(64), lds, (hipStream_t)stream, P, dA, sA, dB, sB, act, d_new,
                        s_new, u_final, d_fine, beta_plus, beta_map, iter_usage, act_out, act_count);
