@@ -119,9 +119,21 @@ def test_sharded_render_and_finetune_step_over_rccl(tmp_path):
     import torch.multiprocessing as mp
     world = min(torch.cuda.device_count(), 8)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    mp.spawn(_nccl_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    # bounded: a collective that never completes must fail this test, not hang the GPU tier (the workers are killed by PID)
+    import time
+    ctx = mp.spawn(_nccl_worker, args=(world, port, str(tmp_path)), nprocs=world, join=False)
+    deadline = time.time() + 600
+    done = False
+    try:
+        while not done and time.time() < deadline:
+            done = ctx.join(timeout=5)
+    finally:
+        if not done:
+            for pr in ctx.processes:
+                if pr.is_alive():
+                    pr.kill()
     errs = [open(tmp_path / f).read() for f in os.listdir(tmp_path) if f.startswith("err")]
     assert not errs, errs[0]
+    assert done, "the RCCL workers did not finish within 10 minutes"
     assert len([f for f in os.listdir(tmp_path) if f.startswith("ok")]) == world
