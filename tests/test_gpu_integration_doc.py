@@ -1,0 +1,44 @@
+"""INTEGRATION.md section B is the binding a reference maintainer would paste into `models/frameworks/_nerfart_hip.py`: this test
+executes that very code block (only the library path is pointed at the in-tree build) and holds its two functions to the package's
+own wrappers - the documented argument lists cannot drift from include/nerfart_hip.h unnoticed."""
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _doc_binding():
+    text = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    code = next(b for b in blocks if "_nerfart_hip.py" in b and "def forward_surface" in b)
+    from nerfart_amd import hip
+    code = code.replace('C.CDLL("libnerfart_hip.so")', f'C.CDLL({hip.LIB_PATH!r})')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md#B", "exec"), ns)
+    return ns
+
+
+def test_documented_ctypes_binding_runs_and_matches_the_package():
+    from nerfart_amd import hip, scene
+    ns = _doc_binding()
+    model, _, _ = scene.build_model("VolSDF", seed=0, beta=0.01, device=DEV, precision="bf16x3")
+    surf, rad = model.packed()
+    assert ns["PREC"] == 1
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(1, 777, 3, generator=g) * 3 - 1.5).to(DEV)
+    v = torch.nn.functional.normalize(torch.randn(1, 777, 3, generator=g), dim=-1).to(DEV)
+    sdf_doc = ns["forward_surface"](surf, x, 3.0)
+    rgb_doc, sdf2_doc, nab_doc = ns["forward"](surf, rad, x, v, 3.0)
+    torch.cuda.synchronize()
+    sdf = hip.sdf_fwd(surf, x.reshape(-1, 3).contiguous(), 3.0, precision=1)
+    s2, nab, h7 = hip.sdf_nabla_fwd(surf, x.reshape(-1, 3).contiguous(), 3.0, precision=1)
+    rgb = hip.radiance_fwd(rad, 1, x.reshape(-1, 3).contiguous(), v.reshape(-1, 3).contiguous(), nab, h7, precision=1)
+    assert torch.equal(sdf_doc.reshape(-1), sdf) and torch.equal(sdf2_doc.reshape(-1), s2)
+    assert torch.equal(nab_doc.reshape(-1, 3), nab) and torch.equal(rgb_doc.reshape(-1, 3), rgb)
+    assert rgb_doc.shape == x.shape and sdf_doc.shape == x.shape[:-1]
