@@ -42,3 +42,27 @@ def test_documented_ctypes_binding_runs_and_matches_the_package():
     assert torch.equal(sdf_doc.reshape(-1), sdf) and torch.equal(sdf2_doc.reshape(-1), s2)
     assert torch.equal(nab_doc.reshape(-1, 3), nab) and torch.equal(rgb_doc.reshape(-1, 3), rgb)
     assert rgb_doc.shape == x.shape and sdf_doc.shape == x.shape[:-1]
+
+
+def test_documented_clip_binding_runs_and_matches_the_package():
+    """Section D's `EncodeImage` autograd function, executed as written, against clip_native.NativeImageEncoder (features and pixel
+    gradient bit for bit: both are the same two C entry points)."""
+    from nerfart_amd import hip, clip_vit, clip_native
+    text = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    code = next(b for b in blocks if "_nerfart_clip.py" in b and "class EncodeImage" in b)
+    code = code.replace('C.CDLL("libnerfart_hip.so")', f'C.CDLL({hip.LIB_PATH!r})')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md#D", "exec"), ns)
+    model = clip_vit.build_clip(DEV, seed=0)
+    blob = clip_native.pack_visual(model.state_dict(), DEV)
+    g = torch.Generator().manual_seed(2)
+    img = torch.randn(3, 3, 224, 224, generator=g).to(DEV)
+    cot = torch.randn(3, 512, generator=g).to(DEV)
+    a = img.clone().requires_grad_(True)
+    fa = ns["EncodeImage"].apply(a, blob)
+    fa.backward(cot)
+    b = img.clone().requires_grad_(True)
+    fb = clip_native.NativeImageEncoder(model)(b)
+    fb.backward(cot)
+    assert torch.equal(fa.detach(), fb.detach().float()) and torch.equal(a.grad, b.grad)
