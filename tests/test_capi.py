@@ -86,3 +86,29 @@ def test_new_entry_points_validate_their_arguments_without_a_gpu():
     offs = (C.c_longlong * 22)()
     total = lib.nerfart_vgg16_blob_layout(C.cast(offs, C.c_void_p))
     assert offs[21] == total and total > 2 * 2 * (64 * 64 + 9 * (64 * 64 + 64 * 128 + 128 * 128 + 128 * 256 + 2 * 256 * 256))
+
+
+def test_ctypes_signatures_have_the_headers_argument_counts_and_kinds():
+    """Every prototype of include/nerfart_hip.h against hip._SIGS: same number of arguments, pointers where the header has pointers,
+    64-bit integers where it says `long long`, floats where it says `float` - an argument added to the header (the workspace pair of
+    nerfart_sdf_nabla_fwd, round 3) cannot be forgotten in the binding."""
+    import ctypes as C
+    from nerfart_amd import hip
+    src = open(os.path.join(REPO, "include", "nerfart_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = re.findall(r"\b([a-z][a-z ]*?[\s\*]+)(nerfart_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S)
+    assert len(protos) >= 55
+    for ret, name, args in protos:
+        args = " ".join(args.split())
+        params = [] if args in ("", "void") else [a.strip() for a in args.split(",")]
+        restype, argtypes = hip._SIGS[name]
+        assert len(argtypes) == len(params), f"{name}: header has {len(params)} arguments, hip._SIGS {len(argtypes)}"
+        for p, t in zip(params, argtypes):
+            if "*" in p:
+                assert t is C.c_void_p or t is C.c_char_p, (name, p, t)
+            elif p.startswith("long long") or p.startswith("unsigned long long") or p.startswith("size_t"):
+                assert t is C.c_longlong, (name, p, t)
+            elif p.startswith("float"):
+                assert t is C.c_float, (name, p, t)
+            elif p.startswith("int") or p.startswith("unsigned"):
+                assert t is C.c_int, (name, p, t)
