@@ -33,3 +33,15 @@ def test_hip_module_has_no_fallback_branch():
     assert "raise ImportError" in src and "fallback" in src
     nets = open(os.path.join(REPO, "nerfart_amd", "nets.py")).read()
     assert "F.linear" not in nets and "softplus" not in nets, "nets.py must not carry an eager compute path"
+
+
+def test_every_cited_profile_exists():
+    """DESIGN.md / README.md / INTEGRATION.md cite their evidence as `profiles/<file>` (or a prefix): each citation resolves."""
+    import glob
+    missing = []
+    for doc in ("DESIGN.md", "README.md", "INTEGRATION.md"):
+        for m in set(re.findall(r"profiles/[A-Za-z0-9_.\-\*]+", open(os.path.join(REPO, doc)).read())):
+            pat = os.path.join(REPO, m.rstrip(".,;:)"))
+            if not glob.glob(pat) and not glob.glob(pat + "*"):
+                missing.append((doc, m))
+    assert not missing, missing
