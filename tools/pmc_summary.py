@@ -13,7 +13,7 @@ def main():
     kern = {}
     for f in files:
         for line in open(f):
-            m = re.match(r"\s*(\d+)\s+([0-9.e+\-]+)\s+([0-9.e+\-]+)\s+(\S+)\s+nerfart::(?:b16::)?(\S+)", line)
+            m = re.match(r"\s*(\d+)\s+([0-9.e+\-]+)\s+([0-9.e+\-]+)\s+(\S+)\s+nerfart::(?:b16::|wgrad::|style::|vgg::|clip::|gemm32::)?(\S+)", line)
             if not m:
                 continue
             n, _sum, avg, counter, name = m.groups()
