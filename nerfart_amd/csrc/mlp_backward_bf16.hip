@@ -83,10 +83,12 @@ k_sdf_fwd2_bf16(const float* __restrict__ blob, unsigned M, const float* __restr
         gc.slot_stride = (size_t)ntiles * 128 * 512;
         gc.unit_stride = 64;
         gc.voff = gc.voff_out = (((j & 1) ? ntiles * 64u : 0u) + tile * 64u + wv * 8 + (j >> 1)) * 512u + g * 16;
+        gc.voff_st2 = is_val ? gc.voff_out : 0xffffff00u;   // softplus' slots (8..15): value rows only, the reverse sweep reads those
+        gc.st2_bytes = ntiles * 64u * 512u - 448u;          // (a unit base is up to 448 B into row 0: the range ends with the value rows)
         // unit 7 of layer 3 (features 224..255 of a 217-wide layer) is never built: the reverse sweep still reads it (against
         // zero weights) - it must not hold a NaN
         *reinterpret_cast<u32x4*>(gc.ws_out + uoff(gc, 3 * 8 + 7) + gc.voff_out) = u32x4{0u, 0u, 0u, 0u};
-        *reinterpret_cast<u32x4*>(gc.ws_out + uoff(gc, 64 + 3 * 8 + 7) + gc.voff_out) = u32x4{0u, 0u, 0u, 0u};
+        st2_store(gc, gc.ws_out + uoff(gc, 64 + 3 * 8 + 7), u32x4{0u, 0u, 0u, 0u});
         Acc A, B;
         Unit x0, x0n, enc[2], none[1];
         encode_units_pair(px, py, pz, vx, vy, vz, g, is_val, enc);
@@ -125,7 +127,7 @@ k_sdf_fwd2_bf16(const float* __restrict__ blob, unsigned M, const float* __restr
                 hi[pr] = h; dd[pr] = dout;
             }
             *reinterpret_cast<u32x4*>(gc.ws_out + uoff(gc, 7 * 8 + u) + gc.voff_out) = hi;
-            *reinterpret_cast<u32x4*>(gc.ws_out + uoff(gc, 64 + 7 * 8 + u) + gc.voff_out) = dd;
+            st2_store(gc, gc.ws_out + uoff(gc, 64 + 7 * 8 + u), dd);
         }
     }
 }
@@ -181,7 +183,10 @@ k_sdf_bwd2_bf16(const float* __restrict__ blob, unsigned M, const float* __restr
         gc.unit_stride = 64;
         {
             const unsigned pt = tile * 64u + wv * 8 + (j >> 1);
-            gc.voff = (((j & 1) ? ntiles * 64u : 0u) + pt) * 512u + g * 16;
+            // both lanes of a pair read the point's softplus' from its value row and its tangent from its tangent row (the
+            // activations in the value rows and a second copy of softplus' are not needed here): 8 KiB per point instead of 16
+            gc.voff = pt * 512u + g * 16;
+            gc.voff2 = (ntiles * 64u + pt) * 512u + g * 16;
             gc.voff_out = (((j & 1) ? 0u : ntiles * 64u) + pt) * 512u + g * 16;
         }
         const float sb = valid ? gbar_sdf[m] : 0.f;
@@ -197,7 +202,7 @@ k_sdf_bwd2_bf16(const float* __restrict__ blob, unsigned M, const float* __restr
         Unit x0, x0n, none[1];
         {
             const u32x4 dd = *reinterpret_cast<const u32x4*>(gc.ws + uoff(gc, 64 + 7 * 8) + gc.voff);
-            const u32x4 aa = *reinterpret_cast<const u32x4*>(gc.ws + uoff(gc, 7 * 8) + gc.voff);
+            const u32x4 aa = *reinterpret_cast<const u32x4*>(gc.ws + uoff(gc, 7 * 8) + gc.voff2);
             u32x4 hi;
             x0 = pair_unit(A, 0, dd, aa, is_val, hi);
             *reinterpret_cast<u32x4*>(gc.ws_out + uoff(gc, 7 * 8) + gc.voff_out) = hi;
@@ -220,7 +225,7 @@ k_sdf_bwd2_bf16(const float* __restrict__ blob, unsigned M, const float* __restr
 #pragma unroll
         for (int u = 1; u < 8; ++u) {
             const u32x4 dd = *reinterpret_cast<const u32x4*>(gc.ws + uoff(gc, 64 + u) + gc.voff);
-            const u32x4 aa = *reinterpret_cast<const u32x4*>(gc.ws + uoff(gc, u) + gc.voff);
+            const u32x4 aa = *reinterpret_cast<const u32x4*>(gc.ws + uoff(gc, u) + gc.voff2);
             u32x4 hi;
             (void)pair_unit(A, u, dd, aa, is_val, hi);
             *reinterpret_cast<u32x4*>(gc.ws_out + uoff(gc, u) + gc.voff_out) = hi;

@@ -369,7 +369,10 @@ struct GradCtx {
     size_t slot_stride;
     unsigned unit_stride;
     unsigned voff;            // per-lane byte offset of loads
+    unsigned voff2 = 0;       // second-order reverse sweep: ... of the tangent loads (the softplus' loads use voff)
     unsigned voff_out;        // ... of stores
+    unsigned voff_st2 = 0;    // second-order forward sweep: ... of the softplus' stores: voff_out on value lanes, out of range on
+    unsigned st2_bytes = 0;   //     tangent lanes (a buffer store drops them: no branch inside the item stream); bytes of a slot's value rows
     int layer;                // layer whose weights are being applied (wave uniform)
     u32x4 dbuf[2];            // backward sweep: softplus' units, k-step parity double buffer
     u32x4 abuf[2];            // second-order reverse sweep: tangent units (bf16 hi parts)
@@ -394,13 +397,19 @@ __device__ __forceinline__ int rad_delta_slot(int layer) { return layer > 0 ? la
 __device__ __forceinline__ size_t uoff(const GradCtx& gc, int idx) {
     return (size_t)(idx >> 3) * gc.slot_stride + (size_t)(idx & 7) * gc.unit_stride;
 }
+// second-order forward sweep: softplus'(z) is the same number on both lanes of a (value, tangent) pair - only the value rows of
+// slots 8..15 hold it.  `base` = the unit's address in row 0 (wave uniform); tangent lanes carry an out-of-range offset
+__device__ __forceinline__ void st2_store(const GradCtx& gc, char* base, const u32x4 v) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, gc.st2_bytes, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)gc.voff_st2, 0, 0);
+}
 // (l, unit) of the second-order kernels: softplus' at slot 8 + l, tangent / activation hi parts at slot l
 __device__ __forceinline__ void d_load2(GradCtx& gc, int idx, int buf) {
 #ifdef NERFART_ABLATE_SCRATCH      // timing experiments only (tools/ablate_grad.py): no scratch / dump traffic, results wrong
     return;
 #endif
     gc.dbuf[buf] = *reinterpret_cast<const u32x4*>(gc.ws + uoff(gc, 64 + idx) + gc.voff);
-    gc.abuf[buf] = *reinterpret_cast<const u32x4*>(gc.ws + uoff(gc, idx) + gc.voff);
+    gc.abuf[buf] = *reinterpret_cast<const u32x4*>(gc.ws + uoff(gc, idx) + gc.voff2);
 }
 // Plain (compiler-visible) loads: hipcc then keeps its own vmcnt bookkeeping for them - with the LDS-DMA pieces it
 // cannot see this can only make its wait stricter.  (Hand-counted asm loads gave wrong gradients on random waves.)
@@ -539,7 +548,7 @@ struct Items {
                     else *reinterpret_cast<u32x4*>(gc.pend_ptr + gc.voff_out) = gc.dpend;
 #endif
                     constexpr int PM = (ks == 0) ? L::MODE : L::mode_of(HUP);        // (mode 10 layers use 10 for both kinds)
-                    if constexpr (PM == 10) *reinterpret_cast<u32x4*>(gc.pend_ptr + 8 * gc.slot_stride + gc.voff_out) = gc.dpend2;
+                    if constexpr (PM == 10) st2_store(gc, gc.pend_ptr + 8 * gc.slot_stride, gc.dpend2);
                 }
             }
             if constexpr (T == 0) {
