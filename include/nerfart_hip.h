@@ -295,6 +295,35 @@ long long nerfart_wgrad_workspace_bytes(int n_mats, long long rows, int a_cols);
 int nerfart_wgrad_bf16(const void* Z, long long z_stride, const void* A, long long a_stride, int n_mats, long long rows, int a_cols,
                        long long cs_rows, float* dW, float* cs, int accumulate, void* workspace, long long workspace_bytes, void* stream);
 
+/* ---- per-point glue of pass 2 (row a19; csrc/pass2_operands.hip): what autograd does between the network calls of
+ * volsdf.py:759-770, one pass each.
+ *   nerfart_ray_points: pts[R P,3] = rays_o + rays_dn * depth[R,P] (volsdf.py:503-506), view[R P,3] = rays_dn per sample (NULL: skip).
+ *   nerfart_volsdf_pass2_cotangents: from the compositor's g_sdf[R P], the radiance net's g_n[R P,3] (+ g_n_extra, may be NULL) and
+ *     pass 1's pts / sdf / nabla: sbar[R P] = g_sdf where the sphere clamp sdf = min(net, R_bg - |x|) kept the net (volsdf.py:97-100,
+ *     else 0), nbar[R P,3] = g_n + the eikonal term's gradient w 2 (|n| - 1) n / (|n| N) with N = the points of the ray's reference
+ *     patch (eik_group_rays rays per patch inside this launch, the last one ragged; <= 0: one patch), eik_ray[R] = each ray's share
+ *     of w * mean_patch((|n| - 1)^2) (their sum = the sum of the patches' eikonal losses).  w_eikonal = 0: no eikonal term.
+ *   nerfart_wgrad_operand_*: the narrow (a_cols = 64) operands of nerfart_wgrad_bf16 from fp32 data: hi parts bf16(x) in columns
+ *     0..c-1 and, when c <= 32, lo parts bf16(x - hi) in columns 32..32+c-1 (add the two halves of dW); rows M.. zero.
+ *       _embed_pair: [2 rows_pad, 64]: embed(pts) (models/base.py:46-64, multires < 0: identity) in rows 0.., its tangent along dir in
+ *                    rows rows_pad.. (the input side of SDF layers 0 and 4 for the stacked [value; tangent] dumps)
+ *       _inputs:     [rows_pad, 64]: [embed(x, multires_x) | embed(view, multires_view) | normals] (radiance layer 0)
+ *       _rgb_delta:  [rows_pad, 64]: g_rgb rgb (1 - rgb) (the output sigmoid's delta, 3 columns); also in fp32 to d4[M,3] (NULL: skip)
+ *                    and its sums over each block of 32 rows to block_sums[ceil(rows_pad / 32), 3] (their sum = the bias gradient)
+ *       _sbar_ones:  [2 rows_pad, 64]: sbar (1 column) in rows 0.., 1 in rows rows_pad.. (the sdf row of the last SDF layer) */
+int nerfart_ray_points(const float* rays_o, const float* rays_dn, const float* depth, long long n_rays, int P, float* pts, float* view,
+                       void* stream);
+int nerfart_volsdf_pass2_cotangents(const float* pts, const float* sdf, const float* g_sdf, const float* nabla, const float* g_n,
+                                    const float* g_n_extra, long long n_rays, int P, float R_bg, float w_eikonal,
+                                    long long eik_group_rays, float* sbar, float* nbar, float* eik_ray, void* stream);
+int nerfart_wgrad_operand_embed_pair(const float* pts, const float* dir, long long M, long long rows_pad, int multires, void* out,
+                                     void* stream);
+int nerfart_wgrad_operand_inputs(const float* x, int multires_x, const float* view, int multires_view, const float* normals, long long M,
+                                 long long rows_pad, void* out, void* stream);
+int nerfart_wgrad_operand_rgb_delta(const float* rgb, const float* g_rgb, long long M, long long rows_pad, void* out, float* d4,
+                                    float* block_sums, void* stream);
+int nerfart_wgrad_operand_sbar_ones(const float* sbar, long long M, long long rows_pad, void* out, void* stream);
+
 /* The GEMM kernel of the encoder on its own (tests): C[M,N] fp32 = A[M,K] fp16 . W[N,K]^T fp16; M, N, K multiples of 64. */
 int nerfart_gemm_f16_nt(const void* A, const void* W, int M, int N, int K, float* C, void* stream);
 

@@ -95,18 +95,8 @@ def _perms(device):
     return _PERMS[key]
 
 
-def _narrow64(cols, rows_pad: int, split: bool = True) -> torch.Tensor:
-    """fp32 column blocks [(tensor [n_i, c_i], first_row)] -> one bf16 [rows_pad, 64] operand of nerfart_wgrad_bf16: the hi parts in
-    columns 0 .. c-1 and (split) the lo parts x - hi in columns 32 .. 32 + c-1 - the caller adds the two halves of the result."""
-    c = cols[0][0].shape[1]
-    assert c <= (32 if split else 64)
-    out = torch.zeros(rows_pad, 64, dtype=torch.bfloat16, device=cols[0][0].device)
-    for t, r0 in cols:
-        hi = t.to(torch.bfloat16)
-        out[r0:r0 + t.shape[0], :c] = hi
-        if split:
-            out[r0:r0 + t.shape[0], 32:32 + c] = (t - hi.float()).to(torch.bfloat16)
-    return out
+def _embed_width(multires: int) -> int:
+    return 3 if multires < 0 else 3 + 6 * multires
 
 
 def _wgrad_narrow(Z: torch.Tensor, A64: torch.Tensor, c: int, split: bool, n_mats: int = 1, z_stride: int = 0, want_cs: bool = False, cs_rows: int = 0):
@@ -131,29 +121,33 @@ def _unperm(w: torch.Tensor, inv: torch.Tensor, rows: bool = True, cols: bool = 
     return w
 
 
-def radiance_weight_grads_raw(model, x, v, n, h7, rgb, g_rgb, dump, bdump):
-    """Plain GEMMs of the deltas (k_radiance_bwd_bf16's dump) with the activations (k_radiance_bf16<dump>'s), read in place;
-    the big operands stay in the kernels' unit order.  Returns the raw fp32 results - LINEAR in the cotangents, so the
+def radiance_weight_grads_raw(model, x, v, n, h7, rgb, g_rgb, dump, bdump, a7_units=None):
+    """Reductions of the deltas (k_radiance_bwd_bf16's dump) against the activations (k_radiance_bf16<dump>'s), read in place;
+    the big operands stay in the kernels' unit order, the narrow ones come from csrc/pass2_operands.hip in one pass each.
+    a7_units [>= M rows, 256] bf16: the layer-7 activation in unit order if the caller has it (k_sdf_fwd2_bf16 dumps it: slot 7,
+    value rows) - otherwise h7 is permuted and narrowed here.  Returns the raw fp32 results - LINEAR in the cotangents, so the
     results of several patches may be summed (GradAccumulator) before radiance_weight_grads_finish."""
+    from . import hip
     M = x.shape[0]
     acts = _dump_all(dump)                                                  # f, r0, r1, r2, r3   [5, M_pad, 256]
     deltas = _dump_all(bdump)                                               # d0, d1, d2, d3, g_f (0 for the padded points)
     Mp = acts.shape[1]
-    pad = lambda t: t if Mp == M else torch.cat([t, torch.zeros(Mp - M, t.shape[1], device=t.device, dtype=t.dtype)], dim=0)
-    d4 = g_rgb * rgb * (1.0 - rgb)
     rad = model.radiance_net
-    ex = torch.cat([embed(x, rad.embed_multires), embed(v, rad.embed_multires_view), n], dim=-1)
-    from . import hip
     slot = Mp * 512                                                         # bytes between the dumps' slots
-    bf = torch.bfloat16
     # (d0, f), (d1, r0), (d2, r1), (d3, r2) and the column sums of d0..d3 in one pass over the dumps (csrc/wgrad.hip)
     ww, cs03 = hip.wgrad(deltas[0], acts[0], 4, Mp, 256, slot, slot, cs_rows=Mp, want_cs=True)
-    wh7, cs4 = hip.wgrad(deltas[4], pad(h7).to(bf), 1, Mp, 256, 0, 0, cs_rows=Mp, want_cs=True)
+    if a7_units is None:
+        a7_units = torch.zeros(Mp, 256, dtype=torch.bfloat16, device=x.device)
+        a7_units[:M] = h7[:, _perms(x.device)[0]].to(torch.bfloat16)
+    rows7 = min(a7_units.shape[0], Mp)                                      # both cover the M points; rows beyond them are zero
+    wh7, cs4 = hip.wgrad(deltas[4], a7_units, 1, rows7, 256, 0, 0, cs_rows=rows7, want_cs=True)
     cs = torch.cat([cs03, cs4], dim=0)                                      # [5, 256]
-    w4 = _wgrad_narrow(acts[4], _narrow64([(d4, 0)], Mp), 3, True)[0][0].t()                # [3, 256] = d4^T r3
-    nex = ex.shape[1]
-    wex = _wgrad_narrow(deltas[0], _narrow64([(ex, 0)], Mp, nex <= 32), nex, nex <= 32)[0][0]  # [256, nex] = d0^T [x | v | n]
-    return [ww, cs, w4, d4.sum(0), wex, wh7[0]]
+    D4, b4, _ = hip.wgrad_operand_rgb_delta(rgb, g_rgb, Mp)                 # g_rgb rgb (1 - rgb): the output sigmoid; its column sums
+    w4 = _wgrad_narrow(acts[4], D4, 3, True)[0][0].t()                      # [3, 256] = d4^T r3
+    nex = _embed_width(rad.embed_multires) + _embed_width(rad.embed_multires_view) + 3
+    EX = hip.wgrad_operand_inputs(x, rad.embed_multires, v, rad.embed_multires_view, n, Mp)
+    wex = _wgrad_narrow(deltas[0], EX, nex, nex <= 32)[0][0]                # [256, nex] = d0^T [x | v | n]
+    return [ww, cs, w4, b4, wex, wh7[0]]
 
 
 def radiance_weight_grads_finish(model, raw):
@@ -167,13 +161,14 @@ def radiance_weight_grads_finish(model, raw):
         gw[l], gb[l] = _unperm(ww[l], inv), cs[l][inv]
     gw[0] = torch.cat([_unperm(wex, inv, cols=False), _unperm(ww[0], inv)], dim=1)
     gb[0] = cs[0][inv]
-    g_w8 = torch.cat([torch.zeros(1, 256, device=ww.device), _unperm(wh7, inv, cols=False)], dim=0)
+    g_w8 = torch.cat([torch.zeros(1, 256, device=ww.device), _unperm(wh7, inv)], dim=0)
     g_b8 = torch.cat([torch.zeros(1, device=ww.device), cs[4][inv]])
     return gw, gb, g_w8, g_b8
 
 
 def radiance_weight_grads(model, x, v, n, h7, rgb, g_rgb, dump, bdump):
-    return radiance_weight_grads_finish(model, radiance_weight_grads_raw(model, x, v, n, h7, rgb, g_rgb, dump, bdump))
+    return radiance_weight_grads_finish(model, radiance_weight_grads_raw(model, x.contiguous(), v.contiguous(), n.contiguous(), h7, rgb.contiguous(),
+                                                                          g_rgb.contiguous(), dump, bdump))
 
 
 _F2_SLOTS, _R2_SLOTS = 16, 8
@@ -192,46 +187,34 @@ def _dump_all(dump: torch.Tensor) -> torch.Tensor:
     return dump.view(torch.bfloat16).view(5, -1, 256)
 
 
-def embed_tangent(x, direction, multires: int):
-    """d embed(x) / d x . direction."""
-    f = _freqs(x.device, multires).to(x.dtype)
-    xf = x[..., None, :] * f
-    d = direction[..., None, :] * f
-    return torch.cat([direction, torch.stack([torch.cos(xf) * d, -torch.sin(xf) * d], dim=-2).flatten(-3)], dim=-1)
-
-
-def surface_weight_grads_raw(model, pts, sbar, hbar7, nbar):
-    """k_sdf_fwd2_bf16 / k_sdf_bwd2_bf16 + the GEMMs over their dumps for the cotangents (sbar of sdf [M], hbar7 of the
-    layer-7 activation [M,256], nbar of grad_x sdf [M,3]).  dW_l = zbar_l^T a_{l-1} + (t_l d_l)^T adot_{l-1} is ONE GEMM
+def surface_weight_grads_raw(model, pts, sbar, hbar7, nbar, return_a7: bool = False):
+    """k_sdf_fwd2_bf16 / k_sdf_bwd2_bf16 + the reductions over their dumps for the cotangents (sbar of sdf [M], hbar7 of the
+    layer-7 activation [M,256], nbar of grad_x sdf [M,3]).  dW_l = zbar_l^T a_{l-1} + (t_l d_l)^T adot_{l-1} is ONE reduction
     over the 2 Mp stacked rows of the two dumps, read in place; the big operands stay in unit order.  Returns the raw fp32
-    results - linear in the cotangents, so patches may be summed before surface_weight_grads_finish."""
+    results - linear in the cotangents, so patches may be summed before surface_weight_grads_finish; with return_a7 also the
+    layer-7 activation [Mp, 256] bf16 in unit order (a view of the forward dump) for radiance_weight_grads_raw."""
     from . import hip
     surf = model.implicit_surface
     surf_blob, _ = model.packed()
     M = pts.shape[0]
-    pts, nbar = pts.contiguous(), nbar.contiguous()
+    pts, nbar, sbar = pts.contiguous(), nbar.contiguous(), sbar.contiguous()
     f2 = hip.sdf_fwd2(surf_blob, pts, nbar)
-    r2 = hip.sdf_bwd2(surf_blob, hbar7.contiguous(), sbar.contiguous(), f2)
-    bf = torch.bfloat16
+    r2 = hip.sdf_bwd2(surf_blob, hbar7.contiguous(), sbar, f2)
     Mp = (M + 63) // 64 * 64                                            # the kernels' tiles; padded rows are zero where it matters
-    padr = lambda t: t if Mp == M else torch.cat([t, torch.zeros(Mp - M, *t.shape[1:], device=t.device, dtype=t.dtype)], dim=0)
-    e2 = torch.cat([padr(embed(pts, surf.embed_multires)), padr(embed_tangent(pts, nbar, surf.embed_multires))], dim=0)           # [e; edot] fp32
     RZ = _pair_all(r2, _R2_SLOTS, 8)                                    # [8, 2 Mp, 256]: 65535 * [zbar_l; t_l d_l]
     FA = _pair_all(f2, _F2_SLOTS, 8)                                    # [8, 2 Mp, 256]: [a_l; adot_l]
-    sbar = padr(sbar)
-    from . import hip
     slot = 2 * Mp * 512                                                 # bytes between the dumps' slots
     # layers 1..7 against the previous layer's (a | adot), with the column sums of zbar_1..7 (first Mp rows) in the same pass
     ww, cs17 = hip.wgrad(RZ[1], FA[0], 7, 2 * Mp, 256, slot, slot, cs_rows=Mp, want_cs=True)
     # layers 0 and 4 (four slots apart) against the encoding [e; edot], one shared narrow operand; column sums of zbar_0
-    nenc = e2.shape[1]
-    we, cs04 = _wgrad_narrow(RZ[0], _narrow64([(e2, 0)], 2 * Mp, nenc <= 32), nenc, nenc <= 32, n_mats=2, z_stride=4 * slot,
-                             want_cs=True, cs_rows=Mp)
+    nenc = _embed_width(surf.embed_multires)
+    E2 = hip.wgrad_operand_embed_pair(pts, nbar, Mp, surf.embed_multires)
+    we, cs04 = _wgrad_narrow(RZ[0], E2, nenc, nenc <= 32, n_mats=2, z_stride=4 * slot, want_cs=True, cs_rows=Mp)
     cs = torch.cat([cs04[0:1], cs17], dim=0)                            # [8, 256]: sum_p zbar_l
     # w8 row: a7^T sbar + column sums of adot7 = FA[7]^T [sbar; 1]
-    ones = torch.ones(Mp, 1, dtype=torch.float32, device=pts.device)
-    w8 = _wgrad_narrow(FA[7], _narrow64([(sbar[:, None], 0), (ones, Mp)], 2 * Mp), 1, True)[0][0][:, 0]
-    return [ww, we, cs, w8, sbar.sum()]
+    w8 = _wgrad_narrow(FA[7], hip.wgrad_operand_sbar_ones(sbar, Mp), 1, True)[0][0][:, 0]
+    raw = [ww, we, cs, w8, sbar.sum()]
+    return (raw, FA[7][:Mp]) if return_a7 else raw
 
 
 def surface_weight_grads_finish(model, raw):
@@ -347,8 +330,8 @@ def volsdf_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikon
     from . import hip
     _need_split_bf16(model, "volsdf_backward_samples_native")
     R, P = d_all.shape
-    pts = (rays_o[:, None, :] + rays_dn[:, None, :] * d_all[:, :, None]).reshape(-1, 3).contiguous()
-    v = rays_dn[:, None, :].expand(R, P, 3).reshape(-1, 3).contiguous()
+    d_all = d_all.contiguous()
+    pts, v = hip.ray_points(rays_o.contiguous(), rays_dn.contiguous(), d_all)
     surf_blob, rad_blob = model.packed()
     Rbg = model.obj_bounding_radius
     with torch.no_grad():
@@ -357,21 +340,19 @@ def volsdf_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikon
         if ab is None:
             alpha, beta = model.forward_ab()
             ab = (float(alpha), float(beta))
-        g_sdf, g_rad, g_ab = hip.volsdf_composite_bwd(d_all.contiguous(), sdf.reshape(R, P), rgb_pt.reshape(R, P, 3), ab[0], ab[1],
+        g_sdf, g_rad, g_ab = hip.volsdf_composite_bwd(d_all, sdf.reshape(R, P), rgb_pt.reshape(R, P, 3), ab[0], ab[1],
                                                       g_rgb.contiguous(), white_bkgd)
-        clamped = sdf >= (Rbg - pts.norm(dim=-1)) - 1e-6            # sdf = min(net, R - |x|): no gradient to the net where clamped
-        sbar = torch.where(clamped, torch.zeros_like(sdf), g_sdf.reshape(-1))
-        g_h7, g_n, bdump = hip.radiance_bwd(rad_blob, rgb_pt, g_rad.reshape(-1, 3), dump)
-        nbar = g_n
-        eik = torch.zeros((), device=pts.device)
-        if use_eikonal:
-            eik, g_eik = _eikonal_terms(nab, R, P, w_eikonal, eik_group_rays)
-            nbar = nbar + g_eik
-        if nbar_extra is not None:
-            nbar = nbar + nbar_extra.reshape(-1, 3)
+        g_rad = g_rad.reshape(-1, 3)
+        g_h7, g_n, bdump = hip.radiance_bwd(rad_blob, rgb_pt, g_rad, dump)
+        # sbar: no gradient to the net where sdf = min(net, R - |x|) took the sphere; nbar = g_n + the eikonal term's gradient
+        sbar, nbar, eik_ray = hip.volsdf_pass2_cotangents(pts, sdf.reshape(-1), g_sdf.reshape(-1), nab, g_n, R, P, Rbg,
+                                                          w_eikonal if use_eikonal else 0.0, eik_group_rays,
+                                                          g_n_extra=None if nbar_extra is None else nbar_extra.reshape(-1, 3).contiguous())
+        eik = eik_ray.sum()
         acc = accum if accum is not None else GradAccumulator()
-        acc.add("rad", radiance_weight_grads_raw(model, pts, v, nab, h7, rgb_pt, g_rad.reshape(-1, 3), dump, bdump))
-        acc.add("surf", surface_weight_grads_raw(model, pts, sbar, g_h7, nbar))
+        surf_raw, a7 = surface_weight_grads_raw(model, pts, sbar, g_h7, nbar, return_a7=True)
+        acc.add("surf", surf_raw)
+        acc.add("rad", radiance_weight_grads_raw(model, pts, v, nab, h7, rgb_pt, g_rad, dump, bdump, a7_units=a7))
         acc.add("ab", [g_ab])
     if accum is None:
         acc.flush(model)
@@ -387,10 +368,9 @@ def neus_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikonal
     from . import hip
     _need_split_bf16(model, "neus_backward_samples_native")
     R, P = d_all.shape
-    pts = (rays_o[:, None, :] + rays_dn[:, None, :] * d_all[:, :, None]).reshape(-1, 3).contiguous()
-    d_mid = 0.5 * (d_all[..., 1:] + d_all[..., :-1])
-    pts_m = (rays_o[:, None, :] + rays_dn[:, None, :] * d_mid[:, :, None]).reshape(-1, 3).contiguous()
-    v_m = rays_dn[:, None, :].expand(R, P - 1, 3).reshape(-1, 3).contiguous()
+    rays_o, rays_dn = rays_o.contiguous(), rays_dn.contiguous()
+    pts, _ = hip.ray_points(rays_o, rays_dn, d_all.contiguous(), want_view=False)
+    pts_m, v_m = hip.ray_points(rays_o, rays_dn, (0.5 * (d_all[..., 1:] + d_all[..., :-1])).contiguous())
     surf_blob, rad_blob = model.packed()
     with torch.no_grad():
         if s_val is None:
@@ -409,8 +389,9 @@ def neus_backward_samples_native(model, rays_o, rays_dn, d_all, g_rgb, w_eikonal
         # samples: cotangents of sdf (alpha) and of the nablas (eikonal); mid-points: of h7 and of the normal (radiance)
         acc = accum if accum is not None else GradAccumulator()
         acc.add("surf", surface_weight_grads_raw(model, pts, g_sdf.reshape(-1), torch.zeros(pts.shape[0], 256, device=pts.device), nbar))
-        acc.add("surf", surface_weight_grads_raw(model, pts_m, torch.zeros(pts_m.shape[0], device=pts.device), g_h7, g_n))
-        acc.add("rad", radiance_weight_grads_raw(model, pts_m, v_m, nab_m, h7_m, rgb_m, g_rad.reshape(-1, 3), dump, bdump))
+        surf_raw, a7 = surface_weight_grads_raw(model, pts_m, torch.zeros(pts_m.shape[0], device=pts.device), g_h7, g_n, return_a7=True)
+        acc.add("surf", surf_raw)
+        acc.add("rad", radiance_weight_grads_raw(model, pts_m, v_m, nab_m, h7_m, rgb_m, g_rad.reshape(-1, 3).contiguous(), dump, bdump, a7_units=a7))
         acc.add("s", [g_s])
     if accum is None:
         acc.flush(model)

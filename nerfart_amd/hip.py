@@ -49,6 +49,12 @@ _SIGS = {
     "nerfart_sdf_nabla_fwd_rays": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _ll, _p]),
     "nerfart_wgrad_workspace_bytes": (_ll, [_i, _ll, _i]),
     "nerfart_wgrad_bf16": (_i, [_p, _ll, _p, _ll, _i, _ll, _i, _ll, _p, _p, _i, _p, _ll, _p]),
+    "nerfart_ray_points": (_i, [_p, _p, _p, _ll, _i, _p, _p, _p]),
+    "nerfart_volsdf_pass2_cotangents": (_i, [_p, _p, _p, _p, _p, _p, _ll, _i, _f, _f, _ll, _p, _p, _p, _p]),
+    "nerfart_wgrad_operand_embed_pair": (_i, [_p, _p, _ll, _ll, _i, _p, _p]),
+    "nerfart_wgrad_operand_inputs": (_i, [_p, _i, _p, _i, _p, _ll, _ll, _p, _p]),
+    "nerfart_wgrad_operand_rgb_delta": (_i, [_p, _p, _ll, _ll, _p, _p, _p, _p]),
+    "nerfart_wgrad_operand_sbar_ones": (_i, [_p, _ll, _ll, _p, _p]),
     "nerfart_radiance_fwd": (_i, [_p, _i, _i, _p, _p, _ll, _p, _p, _p, _p]),
     "nerfart_radiance_fwd_rays": (_i, [_p, _i, _i, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "nerfart_get_rays": (_i, [_p, _p, _i, _i, _p, _i, _p, _p, _p]),
@@ -189,6 +195,66 @@ def wgrad(Z, A, n_mats: int, rows: int, a_cols: int, z_stride: int, a_stride: in
     _check(lib.nerfart_wgrad_bf16(Z.data_ptr(), int(z_stride), A.data_ptr(), int(a_stride), n_mats, rows, a_cols, int(cs_rows),
                                   _dev(dW), _dev(cs), 0, _dev(ws, torch.uint8), nb, _stream()), "nerfart_wgrad_bf16")
     return dW, cs
+
+
+# ---- per-point glue of pass 2 (csrc/pass2_operands.hip) ------------------------------------------
+def ray_points(rays_o, rays_dn, depth, want_view: bool = True):
+    """pts [R P, 3] = o + dn * depth, view [R P, 3] = dn per sample."""
+    R, P = depth.shape
+    pts = torch.empty(R * P, 3, dtype=torch.float32, device=depth.device)
+    view = torch.empty(R * P, 3, dtype=torch.float32, device=depth.device) if want_view else None
+    _check(lib.nerfart_ray_points(_dev(rays_o, name="rays_o"), _dev(rays_dn, name="rays_dn"), _dev(depth, name="depth"), R, P, _dev(pts),
+                                  _dev(view), _stream()), "nerfart_ray_points")
+    return pts, view
+
+
+def volsdf_pass2_cotangents(pts, sdf, g_sdf, nabla, g_n, R: int, P: int, R_bg: float, w_eikonal: float, eik_group_rays=None, g_n_extra=None):
+    """(sbar [R P], nbar [R P, 3], eik_ray [R]) - see include/nerfart_hip.h."""
+    dev = pts.device
+    sbar = torch.empty(R * P, dtype=torch.float32, device=dev)
+    nbar = torch.empty(R * P, 3, dtype=torch.float32, device=dev)
+    eik_ray = torch.empty(R, dtype=torch.float32, device=dev)
+    _check(lib.nerfart_volsdf_pass2_cotangents(_dev(pts, name="pts"), _dev(sdf, name="sdf"), _dev(g_sdf, name="g_sdf"), _dev(nabla, name="nabla"),
+                                               _dev(g_n, name="g_n"), _dev(g_n_extra, name="g_n_extra"), R, P, float(R_bg), float(w_eikonal),
+                                               int(eik_group_rays or 0), _dev(sbar), _dev(nbar), _dev(eik_ray), _stream()),
+           "nerfart_volsdf_pass2_cotangents")
+    return sbar, nbar, eik_ray
+
+
+def _operand(rows: int, device):
+    return torch.empty(rows, 64, dtype=torch.bfloat16, device=device)
+
+
+def wgrad_operand_embed_pair(pts, direction, rows_pad: int, multires: int):
+    out = _operand(2 * rows_pad, pts.device)
+    _check(lib.nerfart_wgrad_operand_embed_pair(_dev(pts, name="pts"), _dev(direction, name="dir"), pts.shape[0], rows_pad, int(multires),
+                                                out.data_ptr(), _stream()), "nerfart_wgrad_operand_embed_pair")
+    return out
+
+
+def wgrad_operand_inputs(x, multires_x: int, view, multires_view: int, normals, rows_pad: int):
+    out = _operand(rows_pad, x.device)
+    _check(lib.nerfart_wgrad_operand_inputs(_dev(x, name="x"), int(multires_x), _dev(view, name="view"), int(multires_view),
+                                            _dev(normals, name="normals"), x.shape[0], rows_pad, out.data_ptr(), _stream()),
+           "nerfart_wgrad_operand_inputs")
+    return out
+
+
+def wgrad_operand_rgb_delta(rgb, g_rgb, rows_pad: int, want_d4: bool = False):
+    """(operand [rows_pad, 64] bf16, column sums of d4 = g_rgb rgb (1 - rgb) [3], d4 [M, 3] or None)"""
+    out = _operand(rows_pad, rgb.device)
+    d4 = torch.empty(rgb.shape[0], 3, dtype=torch.float32, device=rgb.device) if want_d4 else None
+    sums = torch.empty((rows_pad + 31) // 32, 3, dtype=torch.float32, device=rgb.device)
+    _check(lib.nerfart_wgrad_operand_rgb_delta(_dev(rgb, name="rgb"), _dev(g_rgb, name="g_rgb"), rgb.shape[0], rows_pad, out.data_ptr(),
+                                               _dev(d4), _dev(sums), _stream()), "nerfart_wgrad_operand_rgb_delta")
+    return out, sums.sum(0), d4
+
+
+def wgrad_operand_sbar_ones(sbar, rows_pad: int):
+    out = _operand(2 * rows_pad, sbar.device)
+    _check(lib.nerfart_wgrad_operand_sbar_ones(_dev(sbar, name="sbar"), sbar.shape[0], rows_pad, out.data_ptr(), _stream()),
+           "nerfart_wgrad_operand_sbar_ones")
+    return out
 
 
 def radiance_fwd(rad_blob, view_tiles: int, pts, view, nabla, h7, precision: int = 0):
