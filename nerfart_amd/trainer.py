@@ -26,7 +26,7 @@ from .nets import NeuS, VolSDF
 
 class Trainer(nn.Module):
     def __init__(self, model, w_eikonal: float = 0.1, use_eikonal: bool = True, pass2_rays: int = 1200, native: bool = None,
-                 patches_per_launch: int = 4, freeze_radiance: bool = None):
+                 patches_per_launch: int = 4, freeze_radiance: bool = None, pass1_groups: int = 4):
         super().__init__()
         if not isinstance(model, (VolSDF, NeuS)):
             raise TypeError("Trainer expects a nerfart_amd VolSDF or NeuS model")
@@ -40,6 +40,9 @@ class Trainer(nn.Module):
         # native pass 2: this many of the reference's pass2_rays-ray patches share one set of kernel launches (the per-patch
         # eikonal means are kept); bounded by the kernels' 2^21 points per launch
         self.patches_per_launch = patches_per_launch
+        # render_keep (VolSDF): pass 1 runs this many of pass 2's launch groups per set of launches (the sampler's rounds each
+        # cost a host read; results are chunk-invariant bit for bit) and hands pass 2 per-group views of the kept state
+        self.pass1_groups = max(1, pass1_groups)
         self._kept = None
         # neus.py:455-456: NeuS fine-tuning trains only the SDF net (and ln_s); pass freeze_radiance=False for the
         # reconstruction objective (reconstruction_step), which trains everything
@@ -140,18 +143,19 @@ class Trainer(nn.Module):
         white = rk.get("white_bkgd", False)
         P = rk.get("N_samples", 128) + rk.get("N_importance", 64)
         step = self._launch_rays(P)
+        big = step * self.pass1_groups
         kept, rgbs = [], []
-        for i in range(0, o.shape[0], step):
-            oi, di = o[i:i + step], d_raw[i:i + step]
+        for i in range(0, o.shape[0], big):
+            oi, di = o[i:i + big], d_raw[i:i + big]
             dn = F.normalize(di, dim=-1)
-            depths = self._samples(oi, dn, di, rk)
+            depths = self._samples(oi, dn, di, rk).contiguous()
             R = oi.shape[0]
-            pts = (oi[:, None, :] + dn[:, None, :] * depths[:, :, None]).reshape(-1, 3).contiguous()
-            v = dn[:, None, :].expand(R, P, 3).reshape(-1, 3).contiguous()
+            pts, v = hip.ray_points(oi, dn, depths)                       # the same kernel gives pass 2 the same points
             sdf, nab, h7 = hip.sdf_nabla_fwd(surf_blob, pts, m.obj_bounding_radius, precision=m.precision_id)
             rgb_pt = hip.radiance_fwd(rad_blob, m.view_tiles, pts, v, nab, h7, precision=m.precision_id)
             rgb, _, _ = hip.volsdf_composite(depths, sdf.reshape(R, P), rgb_pt.reshape(R, P, 3), ab[0], ab[1], white)
-            kept.append((depths, sdf, nab, h7))
+            for j in range(0, R, step):                                   # pass 2's launch groups: views, released group by group
+                kept.append((depths[j:j + step], sdf[j * P:(j + step) * P], nab[j * P:(j + step) * P], h7[j * P:(j + step) * P]))
             rgbs.append(rgb)
         self._kept = kept
         return torch.cat(rgbs, 0) if rgbs else torch.zeros(0, 3, device=o.device)
