@@ -275,11 +275,15 @@ def main():
         # WRITE) KiB with the gfx950 FETCH_SIZE correction) and is reported as `traffic` only if that profile was taken on
         # the kernel sources this run executes (source hash recorded by tools/pmc_summary.py); otherwise it is marked stale.
         import glob
-        pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+        # (only profiles of THIS workload: the train-step / CLIP profiles hold the same kernel names at other launch sizes)
+        pm = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json"))
+                    if not any(t in os.path.basename(f) for t in ("_train_", "_clip_")))
         if pm:
             try:
                 js = json.load(open(pm[-1]))
                 kk = js["kernels"][kname]
+                if any("bench.py" not in c or "bench_" in c for c in js.get("commands", [])):
+                    raise ValueError("not a profile of bench.py")
                 fresh = js.get("csrc_sha256") == hip.csrc_sha256()
                 roofline["traffic_profiled"] = {"bytes_per_launch": int(kk["hbm_bytes_corrected_per_launch"]), "source": os.path.basename(pm[-1]),
                                                 "profile_csrc_sha256": js.get("csrc_sha256"), "matches_this_build": fresh,
