@@ -101,7 +101,8 @@ int nerfart_radiance_bwd(const float* rad_blob, long long M, const float* rgb, c
  *   nerfart_sdf_bwd2: gbar_h7[M,256], gbar_sdf[M], f2_dump -> r2_dump: 65535 * [zbar_l; t_l d_l] bf16, l = 0..7
  * Both dumps are matrices [slot][2 Mp][256], Mp = M rounded up to 64: rows 0..Mp-1 of a slot hold the first, rows Mp..
  * the second quantity of the pair, per point; features in unit order; so dW_l is ONE GEMM over the stacked rows, read in
- * place.  At most 2^21 points per call.
+ * place.  (The softplus' slots 8..15 of f2_dump hold one value per point: rows 0..Mp-1 only, rows Mp.. are never written or read.)
+ * At most 2^21 points per call.
  * The reductions are nerfart_wgrad_bf16 calls; the un-permutation and the weight_norm chain rule are host side (nerfart_amd/autodiff.py:
  * surface_weight_grads_raw / _finish). */
 long long nerfart_sdf_fwd2_dump_bytes(long long M);
