@@ -148,6 +148,21 @@ def test_rgb_delta_and_sbar_operands():
     assert bool((ones[:, 0] == 1.0).all()) and float(ones[:, 1:].abs().sum()) == 0.0
 
 
+def test_empty_inputs():
+    hip = _hip()
+    z3 = torch.zeros(0, 3, device=DEV)
+    pts, view = hip.ray_points(z3, z3, torch.zeros(0, 192, device=DEV))
+    assert pts.shape == (0, 3) and view.shape == (0, 3)
+    out = hip.wgrad_operand_embed_pair(z3, z3, 64, 6)                 # no points: the padded operand is all zero
+    assert out.shape == (128, 64) and float(out.float().abs().sum()) == 0.0
+    s = hip.wgrad_operand_sbar_ones(torch.zeros(0, device=DEV), 64).float()
+    assert float(s[:64].abs().sum()) == 0.0 and bool((s[64:, 0] == 1.0).all())
+    _, b4, _ = hip.wgrad_operand_rgb_delta(z3, z3, 128)
+    assert b4.tolist() == [0.0, 0.0, 0.0]
+    sbar, nbar, eik = hip.volsdf_pass2_cotangents(z3, torch.zeros(0, device=DEV), torch.zeros(0, device=DEV), z3, z3, 0, 192, 3.0, 0.1, 1200)
+    assert sbar.numel() == 0 and nbar.shape == (0, 3) and eik.numel() == 0
+
+
 def test_operand_argument_checks():
     hip = _hip()
     x = torch.zeros(10, 3, device=DEV)
