@@ -253,7 +253,7 @@ int nerfart_wgrad_operand_embed_pair(const float* pts, const float* dir, long lo
                                      void* stream) {
     if (rows_pad <= 0) return 0;
     if (check_rows(M, rows_pad, "wgrad_operand_embed_pair: need 0 <= M <= rows_pad < 2^28")) return 2;
-    if (!pts || !dir || !out || multires > 10) { set_last_error("wgrad_operand_embed_pair: null argument or multires > 10"); return 2; }
+    if ((M > 0 && (!pts || !dir)) || !out || multires > 10) { set_last_error("wgrad_operand_embed_pair: null argument or multires > 10"); return 2; }
     hipLaunchKernelGGL(k_operand_embed_pair, grid8(2 * rows_pad), dim3(256), 0, (hipStream_t)stream, pts, dir, M, rows_pad, multires,
                        (u32x4*)out);
     NERFART_HIP(hipGetLastError());
@@ -266,7 +266,7 @@ int nerfart_wgrad_operand_inputs(const float* x, int multires_x, const float* vi
     if (rows_pad <= 0) return 0;
     if (check_rows(M, rows_pad, "wgrad_operand_inputs: need 0 <= M <= rows_pad < 2^28")) return 2;
     const int c = (multires_x < 0 ? 3 : 3 + 6 * multires_x) + (multires_view < 0 ? 3 : 3 + 6 * multires_view) + 3;
-    if (!x || !view || !normals || !out || c > 64) { set_last_error("wgrad_operand_inputs: null argument or more than 64 columns"); return 2; }
+    if ((M > 0 && (!x || !view || !normals)) || !out || c > 64) { set_last_error("wgrad_operand_inputs: null argument or more than 64 columns"); return 2; }
     hipLaunchKernelGGL(k_operand_inputs, grid8(rows_pad), dim3(256), 0, (hipStream_t)stream, x, multires_x, view, multires_view, normals,
                        M, rows_pad, (u32x4*)out);
     NERFART_HIP(hipGetLastError());
@@ -279,7 +279,7 @@ int nerfart_wgrad_operand_rgb_delta(const float* rgb, const float* g_rgb, long l
                                     float* block_sums, void* stream) {
     if (rows_pad <= 0) return 0;
     if (check_rows(M, rows_pad, "wgrad_operand_rgb_delta: need 0 <= M <= rows_pad < 2^28")) return 2;
-    if (!rgb || !g_rgb || !out || !block_sums) { set_last_error("wgrad_operand_rgb_delta: null argument"); return 2; }
+    if ((M > 0 && (!rgb || !g_rgb)) || !out || !block_sums) { set_last_error("wgrad_operand_rgb_delta: null argument"); return 2; }
     hipLaunchKernelGGL(k_operand_rgb_delta, grid8(rows_pad), dim3(256), 0, (hipStream_t)stream, rgb, g_rgb, M, rows_pad, (u32x4*)out, d4,
                        block_sums);
     NERFART_HIP(hipGetLastError());
@@ -290,7 +290,7 @@ int nerfart_wgrad_operand_rgb_delta(const float* rgb, const float* g_rgb, long l
 int nerfart_wgrad_operand_sbar_ones(const float* sbar, long long M, long long rows_pad, void* out, void* stream) {
     if (rows_pad <= 0) return 0;
     if (check_rows(M, rows_pad, "wgrad_operand_sbar_ones: need 0 <= M <= rows_pad < 2^28")) return 2;
-    if (!sbar || !out) { set_last_error("wgrad_operand_sbar_ones: null argument"); return 2; }
+    if ((M > 0 && !sbar) || !out) { set_last_error("wgrad_operand_sbar_ones: null argument"); return 2; }
     hipLaunchKernelGGL(k_operand_sbar_ones, grid8(2 * rows_pad), dim3(256), 0, (hipStream_t)stream, sbar, M, rows_pad, (u32x4*)out);
     NERFART_HIP(hipGetLastError());
     return 0;
