@@ -308,11 +308,14 @@ _ws_cache = {}
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
-    """One cached byte buffer per device, grown on demand (288 GB of HBM: keep it resident)."""
-    key = str(device)
+    """One cached byte buffer per (device, stream), grown on demand (288 GB of HBM: keep it resident).  Per stream: the entry points
+    run asynchronously on torch's current stream, so two streams (or two host threads on their own streams) must not share scratch."""
+    key = (str(device), int(torch.cuda.current_stream(device).cuda_stream))
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
-        _ws_cache[key] = None
+        _ws_cache.pop(key, None)
+        while len(_ws_cache) >= 8:                                 # short-lived streams must not pin memory for good
+            _ws_cache.pop(next(iter(_ws_cache)))
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         _ws_cache[key] = ws
     return ws

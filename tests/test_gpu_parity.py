@@ -515,3 +515,43 @@ def test_nabla_entry_point_is_reentrant_across_streams():
             for i in range(2):
                 for a, b in zip(out[i], ref[i]):
                     assert torch.equal(a, b), f"{name}, stream {i}, repetition {rep}: concurrent call differs from the sequential one"
+
+
+def test_renderer_is_reentrant_across_threads_and_streams():
+    """The fused renderer from two host threads, each on its own stream (ctypes releases the GIL inside the entry point; every
+    up-sampling round has a host read): the Python host hands each stream its own workspace, so the two halves of a frame rendered
+    concurrently equal the sequential render bit for bit.  (A workspace shared per DEVICE raced: tools/exp_two_stream.py.)"""
+    import threading
+    from nerfart_amd import scene, rend_util
+    model, rk, render_fn = scene.build_model("VolSDF", seed=0, beta=0.01, device=DEV, precision="bf16x3")
+    H, W = 96, 54
+    c2w, K = scene.camera(H, W)
+    o, d, _ = rend_util.get_rays(c2w[None].to(DEV), K[None].to(DEV), H, W)
+    kw = {k: v for k, v in rk.items() if k != "rayschunk"}
+    args = dict(require_nablas=True, calc_normal=True, detailed_output=False, **kw)
+    ref_rgb, ref_depth, _ = render_fn(o, d, **args)
+    torch.cuda.synchronize()
+    N = o.shape[1]
+    bounds = [(0, N // 2), (N // 2, N)]
+    for rep in range(3):
+        out, err = [None, None], []
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        ev = torch.cuda.Event()
+        ev.record()
+
+        def work(t):
+            try:
+                with torch.cuda.stream(streams[t]):
+                    streams[t].wait_event(ev)
+                    a, b = bounds[t]
+                    out[t] = render_fn(o[:, a:b].contiguous(), d[:, a:b].contiguous(), **args)[:2]
+            except Exception as e:                                  # surface failures of the worker threads
+                err.append(e)
+        th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        torch.cuda.synchronize()
+        assert not err, err
+        rgb = torch.cat([out[0][0], out[1][0]], dim=1)
+        depth = torch.cat([out[0][1], out[1][1]], dim=1)
+        assert torch.equal(rgb, ref_rgb) and torch.equal(depth, ref_depth), f"repetition {rep}"
