@@ -208,8 +208,18 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= per) return;
     const float* p = part + (size_t)mat * n_split * per + i;
-    float s = 0.f;
-    for (int k = 0; k < n_split; ++k) s += p[(size_t)k * per];
+    // eight partials in flight per thread (the loop is latency bound otherwise: up to 512 dependent-looking loads, 0.10 ms per call
+    // and 19 ms per training step in profiles/r04j_train_kernel_stats.txt); fixed summation order
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 8 <= n_split; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(p + (size_t)(k + j) * per);
+        s0 += v[0] + v[4]; s1 += v[1] + v[5]; s2 += v[2] + v[6]; s3 += v[3] + v[7];
+    }
+    for (; k < n_split; ++k) s0 += p[(size_t)k * per];
+    const float s = (s0 + s1) + (s2 + s3);
     if (i < 256 * NA) {
         float* o = dW + (size_t)mat * 256 * NA + i;
         *o = accumulate ? *o + s : s;
