@@ -216,7 +216,8 @@ int nerfart_neus_render_fwd(const float* surf_blob, const float* rad_blob, int p
  * LayerNorm / softmax / residual stream in fp32.
  *   blob      : the `visual.*` parameters packed by nerfart_amd/clip_native.py in the section order
  *               nerfart_clip_vitb32_blob_layout() reports (offsets[203] in bytes, last = total size; returns the total):
- *               fp16 matrices and their transposes (0 conv1, 2 + 8 l + j the four linear maps of block l, 98 proj), then
+ *               fp16 matrices, each stored once (0 conv1, 2 + 8 l + {0, 2, 4, 6} the four linear maps of block l, 99 proj; the odd
+ *               sections, once the transposed copies, are empty: the backward GEMMs read the forward matrices in place), then
  *               fp32 vectors (100 class / positional embeddings, LayerNorm parameters, biases) - list in csrc/clip_vit.hip.
  *   img       : [B, 3, 224, 224] fp32, already resized and normalised (the reference's `preprocess`).
  *   feat_out  : [B, 512] fp32 (un-normalised features, as encode_image returns them).
@@ -327,6 +328,9 @@ int nerfart_wgrad_operand_sbar_ones(const float* sbar, long long M, long long ro
 
 /* The GEMM kernel of the encoder on its own (tests): C[M,N] fp32 = A[M,K] fp16 . W[N,K]^T fp16; M, N, K multiples of 64. */
 int nerfart_gemm_f16_nt(const void* A, const void* W, int M, int N, int K, float* C, void* stream);
+/* ... and C[M,N] = A[M,K] . Wt[K,N] (second operand read with its reduction index as the row: the backward GEMMs on the forward
+ * weight matrices, through ds_read_b64_tr_b16). */
+int nerfart_gemm_f16_nn(const void* A, const void* Wt, int M, int N, int K, float* C, void* stream);
 
 #ifdef __cplusplus
 }

@@ -26,8 +26,8 @@ def blob_layout():
 
 
 def pack_visual(state, device) -> torch.Tensor:
-    """`visual.*` entries of a CLIP state dict -> the weight blob (uint8 tensor on `device`): fp16 matrices with their
-    transposes, fp32 vectors, in the section order of csrc/clip_vit.hip."""
+    """`visual.*` entries of a CLIP state dict -> the weight blob (uint8 tensor on `device`): fp16 matrices (each stored
+    once), fp32 vectors, in the section order of csrc/clip_vit.hip."""
     offs, total = blob_layout()
     blob = torch.zeros(total, dtype=torch.uint8, device=device)
 
@@ -40,10 +40,8 @@ def pack_visual(state, device) -> torch.Tensor:
         assert offs[i] + n <= offs[i + 1], (i, n, offs[i + 1] - offs[i])
         blob[offs[i]: offs[i] + n] = t.view(torch.uint8)
 
-    def put_pair(i, w):                       # W [N, K] and W^T [K, N], fp16
-        w = w.to(torch.float16)
-        put(i, w, torch.float16)
-        put(i + 1, w.t(), torch.float16)
+    def put_pair(i, w):                       # W [N, K] fp16, once: the backward GEMM reads it in place (section i + 1 is empty)
+        put(i, w.to(torch.float16), torch.float16)
 
     if g("conv1.weight").shape != (WIDTH, 3, PATCH, PATCH) or g("positional_embedding").shape != (50, WIDTH) or g("proj").shape != (WIDTH, OUT):
         raise ValueError("clip_native: not a ViT-B/32 visual tower (conv1 768x3x32x32, 50 positions, proj 768x512)")
@@ -58,9 +56,7 @@ def pack_visual(state, device) -> torch.Tensor:
         for j, n in enumerate(("ln_1.weight", "ln_1.bias", "attn.in_proj_bias", "attn.out_proj.bias", "ln_2.weight", "ln_2.bias",
                                "mlp.c_fc.bias", "mlp.c_proj.bias")):
             put(f + j, g(p + n), torch.float32)
-    proj = g("proj").to(torch.float16)
-    put(98, proj.t(), torch.float16)
-    put(99, proj, torch.float16)
+    put(99, g("proj").to(torch.float16), torch.float16)          # [768, 512]: forward reads it as Wt[K, N], backward as W[N, K]
     put(100, g("class_embedding"), torch.float32)
     put(101, g("positional_embedding"), torch.float32)
     put(102, g("ln_pre.weight"), torch.float32)
@@ -127,6 +123,16 @@ def gemm_f16_nt(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     N = w.shape[0]
     c = torch.empty(M, N, dtype=torch.float32, device=a.device)
     _check(hip.lib.nerfart_gemm_f16_nt(_ptr(a.contiguous()), _ptr(w.contiguous()), M, N, K, _ptr(c), _stream()), "nerfart_gemm_f16_nt")
+    return c
+
+
+def gemm_f16_nn(a: torch.Tensor, wt: torch.Tensor) -> torch.Tensor:
+    """a [M, K] fp16 . wt [K, N] fp16 -> [M, N] fp32: the same kernel with the second operand's reduction index as its ROW (what
+    the backward GEMMs do with the forward weight matrices; tests)."""
+    M, K = a.shape
+    N = wt.shape[1]
+    c = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    _check(hip.lib.nerfart_gemm_f16_nn(_ptr(a.contiguous()), _ptr(wt.contiguous()), M, N, K, _ptr(c), _stream()), "nerfart_gemm_f16_nn")
     return c
 
 

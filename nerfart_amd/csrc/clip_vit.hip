@@ -17,7 +17,7 @@
 //   k_gemm<EPI, A_F32>   C[M,N] = A[M,K] . W[N,K]^T, 64x64x64 tiles, 4 waves x (32x32) on mfma 32x32x16 f16, LDS double
 //                        buffer (row stride 72 halfs: the 16-byte fragment reads of 16 consecutive rows hit 16 disjoint
 //                        bank quads), fused epilogues: bias, residual add, QuickGELU (+ pre-activation kept for backward),
-//                        QuickGELU' multiply; backward uses the same kernel on pre-transposed weights.
+//                        QuickGELU' multiply; backward uses the same kernel on the SAME matrices (BT: transposing LDS reads).
 //   k_attn_fwd / k_attn_bwd   one workgroup per (image, head): Q, K, V (50 x 64, zero padded to 64) and their transposes in
 //                        LDS, S = Q K^T, softmax rows in fp32, O = P V;  backward recomputes P, then dP = dO V^T,
 //                        dS = P o (dP - rowsum(P o dP)) / 8, dQ = dS K, dK = dS^T Q, dV = P^T dO - five 64^3 products on MFMA.
@@ -35,12 +35,14 @@ constexpr int D = 768, L = 50, NH = 12, HD = 64, DM = 3072, NL = 12, DOUT = 512,
 constexpr float LN_EPS = 1e-5f;
 
 // ---------------------------------------------------------------------------------------------------------------
-// Weight blob: sections in a fixed order, each 256-byte aligned.  fp16 matrices are row-major [rows, cols]; "T" sections
-// hold the transposed matrix (the backward GEMMs' operand).  nerfart_clip_vitb32_blob_layout() returns the offsets.
-//   0 conv [768,3072]   1 convT [3072,768]
-//   2 + 8 l + j, l < 12: j = 0 in_proj W [2304,768], 1 its T, 2 out_proj W [768,768], 3 T, 4 c_fc W [3072,768], 5 T,
-//                        6 c_proj W [768,3072], 7 T
-//   98 projT [512,768]  99 proj [768,512]
+// Weight blob: sections in a fixed order, each 256-byte aligned.  fp16 matrices are row-major [rows, cols], stored ONCE: a
+// backward GEMM reads its forward matrix in place (gemm_f16.h, BT: transposing LDS reads).  The odd sections below held the
+// transposed copies in round 2 (352 MB blob); they are empty now (176 MB) and keep their numbers.
+// nerfart_clip_vitb32_blob_layout() returns the offsets.
+//   0 conv [768,3072]   1 (empty)
+//   2 + 8 l + j, l < 12: j = 0 in_proj W [2304,768], 2 out_proj W [768,768], 4 c_fc W [3072,768], 6 c_proj W [768,3072];
+//                        j = 1, 3, 5, 7 (empty)
+//   98 (empty)  99 proj [768,512]
 //   fp32: 100 class_embedding [768]  101 positional_embedding [50,768]  102 ln_pre.weight  103 ln_pre.bias
 //   104 + 8 l + j: j = 0 ln_1.weight, 1 ln_1.bias, 2 in_proj_bias [2304], 3 out_proj.bias, 4 ln_2.weight, 5 ln_2.bias,
 //                  6 c_fc.bias [3072], 7 c_proj.bias
@@ -48,12 +50,14 @@ constexpr float LN_EPS = 1e-5f;
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int N_SECTIONS = 202;
 static long long section_bytes(int i) {
-    if (i == 0 || i == 1) return 2LL * D * PK;
+    if (i == 0) return 2LL * D * PK;
+    if (i == 1 || i == 98) return 0;
     if (i >= 2 && i < 98) {
         const int j = (i - 2) & 7;
+        if (j & 1) return 0;
         return 2LL * D * (j < 2 ? 3 * D : (j < 4 ? D : DM));
     }
-    if (i == 98 || i == 99) return 2LL * D * DOUT;
+    if (i == 99) return 2LL * D * DOUT;
     if (i == 100) return 4LL * D;
     if (i == 101) return 4LL * L * D;
     if (i == 102 || i == 103 || i == 200 || i == 201) return 4LL * D;
@@ -438,6 +442,15 @@ int nerfart_gemm_f16_nt(const void* A, const void* W, int M, int N, int K, float
     return gemm<EPI_F32, A_F16>((hipStream_t)stream, A, K, (const half_t*)W, M, N, K, e);
 }
 
+// C[M, N] fp32 = A[M, K] fp16 . Wt[K, N] fp16: the same kernel reading the second operand with its reduction index as the ROW
+// (what the backward GEMMs do with the forward weight matrices).
+int nerfart_gemm_f16_nn(const void* A, const void* Wt, int M, int N, int K, float* C, void* stream) {
+    if ((M | N | K) & 63) { set_last_error("nerfart_gemm_f16_nn: M, N, K must be multiples of 64"); return 1; }
+    Epi e{};
+    e.out_f32 = C; e.ldo = N; e.m_valid = M;
+    return gemm<EPI_F32, A_F16, true>((hipStream_t)stream, A, K, (const half_t*)Wt, M, N, K, e);
+}
+
 int nerfart_clip_vitb32_image_fwd(const void* blob, const float* img, int B, float* feat_out, int keep_for_bwd, void* workspace,
                                   long long workspace_bytes, void* stream) {
     if (check_args(blob, workspace, B, workspace_bytes, keep_for_bwd)) return 1;
@@ -488,7 +501,7 @@ int nerfart_clip_vitb32_image_fwd(const void* blob, const float* img, int B, flo
     }
     hipLaunchKernelGGL(k_lnpost, dim3((B + 3) / 4), dim3(256), 0, st, xfin, bl.f(200), bl.f(201), x0, B);
     { Epi e{}; e.out_f32 = feat_out; e.ldo = DOUT; e.m_valid = B;
-      if (gemm<EPI_F32, A_F16>(st, x0, D, bl.h(98), w.Bp, DOUT, D, e)) return 1; }
+      if (gemm<EPI_F32, A_F16, true>(st, x0, D, bl.h(99), w.Bp, DOUT, D, e)) return 1; }
     NERFART_HIP(hipGetLastError());
     return 0;
 }
@@ -536,22 +549,22 @@ int nerfart_clip_vitb32_image_bwd(const void* blob, int B, const float* g_feat, 
         const int s = 2 + 8 * l, f = 104 + 8 * l;
         // MLP branch: d act = dx W2 -> x gelu'(pre) -> d ln_2 out = . W1 -> dx += LN'
         { Epi e{}; e.out_f16 = act; e.aux_f16 = pre; e.ldo = DM; e.m_valid = M;
-          if (gemm<EPI_GELUBWD_F16, A_F32>(st, dx, D, bl.h(s + 7), Mp, DM, D, e)) return 1; }
+          if (gemm<EPI_GELUBWD_F16, A_F32, true>(st, dx, D, bl.h(s + 6), Mp, DM, D, e)) return 1; }
         { Epi e{}; e.out_f32 = t; e.ldo = D; e.m_valid = M;
-          if (gemm<EPI_F32, A_F16>(st, act, DM, bl.h(s + 5), Mp, D, DM, e)) return 1; }
+          if (gemm<EPI_F32, A_F16, true>(st, act, DM, bl.h(s + 4), Mp, D, DM, e)) return 1; }
         hipLaunchKernelGGL(k_ln_bwd, dim3(rows4), dim3(256), 0, st, t, xmid, bl.f(f + 4), dx, M);
         // attention branch: d attn = dx Wo -> attention backward -> d ln_1 out = dqkv Wqkv -> dx += LN'
         { Epi e{}; e.out_f16 = att; e.ldo = D; e.m_valid = M;
-          if (gemm<EPI_F16, A_F32>(st, dx, D, bl.h(s + 3), Mp, D, D, e)) return 1; }
+          if (gemm<EPI_F16, A_F32, true>(st, dx, D, bl.h(s + 2), Mp, D, D, e)) return 1; }
         hipLaunchKernelGGL(k_attn_bwd, dim3(B * NH), dim3(256), ATTN_BWD_LDS, st, qkv, att, dqkv);
         { Epi e{}; e.out_f32 = t; e.ldo = D; e.m_valid = M;
-          if (gemm<EPI_F32, A_F16>(st, dqkv, 3 * D, bl.h(s + 1), Mp, D, 3 * D, e)) return 1; }
+          if (gemm<EPI_F32, A_F16, true>(st, dqkv, 3 * D, bl.h(s + 0), Mp, D, 3 * D, e)) return 1; }
         hipLaunchKernelGGL(k_ln_bwd, dim3(rows4), dim3(256), 0, st, t, xin, bl.f(f + 0), dx, M);
     }
     NERFART_HIP(hipMemsetAsync(y, 0, (size_t)2 * Mp * D, st));
     hipLaunchKernelGGL(k_lnpre_bwd, dim3(rows4), dim3(256), 0, st, dx, xemb, bl.f(102), y, M);
     { Epi e{}; e.out_f32 = dpatch; e.ldo = PK; e.m_valid = B * NP;
-      if (gemm<EPI_F32, A_F16>(st, y, D, bl.h(1), w.Pp, PK, D, e)) return 1; }
+      if (gemm<EPI_F32, A_F16, true>(st, y, D, bl.h(0), w.Pp, PK, D, e)) return 1; }
     hipLaunchKernelGGL(k_unpatchify, dim3(B * NP), dim3(256), 0, st, dpatch, scale, g_img, B);
     NERFART_HIP(hipGetLastError());
     return 0;

@@ -3,6 +3,10 @@
 //   C[M, N] = A[M, K] . W[N, K]^T      64 x 64 x 64 tiles, 256 threads = 4 waves x (32 x 32) on v_mfma_f32_32x32x16_f16, fp32
 //   accumulate, LDS double buffer (row stride 72 halfs: the 16-byte fragment reads of 16 consecutive rows hit 16 disjoint bank
 //   quads), global -> register -> LDS staging of tile k + 1 under the MFMAs of tile k, one barrier per k tile.
+//   BT = true:  C[M, N] = A[M, K] . Wt[K, N] with Wt row-major (the reduction index is Wt's ROW): the backward GEMMs read the
+//   forward weight matrices in place - the tile is staged as it lies in memory ([k][n]) and the B fragments come out of LDS through
+//   ds_read_b64_tr_b16, the 4 x 4 transposing read (16 lanes fetch 4 rows x 16 columns, lane c receives the 4 rows of column c;
+//   two reads = the 8 k-values of a 32x32x16 operand).  Round 2 kept a transposed copy of every matrix in the blob for this.
 //
 // A sources (template ASRC): fp16 matrix; fp32 matrix converted while staging; IMPLICIT 3 x 3 convolution: row m is pixel
 // (b, y, x) of an NHWC fp16 image, column k = (ky, kx, c) is channel c of the neighbour (y + ky - 1, x + kx - 1) (zero outside):
@@ -43,8 +47,21 @@ __device__ __forceinline__ float quick_gelu_grad(float x) {
     return s * (1.0f + 1.702f * x * (1.0f - s));
 }
 
-template <int EPI, int ASRC>
-__global__ __launch_bounds__(256) void k_gemm(const void* __restrict__ Av, int lda, const half_t* __restrict__ W, int K, Epi e) {
+// 8 halfs of one column out of a row-major [k][n] LDS tile: rows k0 .. k0 + 7 of this lane's column (addr = the lane's 8-byte piece
+// of the first 4 x 16 block: row (lane & 15) >> 2, columns 4 (lane & 3) ..; the second block lies 4 rows = ROWS4 bytes further)
+template <int OFF, int ROWS4>
+__device__ __forceinline__ half8 frag_tr(unsigned addr) {
+    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    u32x2_ a, b;
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b) : "v"(addr), "i"(OFF), "i"(OFF + ROWS4) : "memory");
+    const u32x4_ r = {a[0], a[1], b[0], b[1]};
+    return __builtin_bit_cast(half8, r);
+}
+
+template <int EPI, int ASRC, bool BT = false>
+__global__ __launch_bounds__(256) void k_gemm(const void* __restrict__ Av, int lda, const half_t* __restrict__ W, int K, int ldw, Epi e) {
     __shared__ __attribute__((aligned(16))) half_t As[2][64][LS];
     __shared__ __attribute__((aligned(16))) half_t Bs[2][64][LS];
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
@@ -84,7 +101,8 @@ __global__ __launch_bounds__(256) void k_gemm(const void* __restrict__ Av, int l
             ra0 = *reinterpret_cast<const half8*>(p);
             ra1 = *reinterpret_cast<const half8*>(p + 8);
         }
-        const half_t* q = W + (size_t)(bn + lr) * K + k0 + lc;
+        // W[N, K]: row bn + lr, columns k0 + lc ..;  Wt[K, N] (BT): row k0 + lr, columns bn + lc ..  (ldw = the row stride)
+        const half_t* q = BT ? W + (size_t)(k0 + lr) * ldw + bn + lc : W + (size_t)(bn + lr) * ldw + k0 + lc;
         rb0 = *reinterpret_cast<const half8*>(q);
         rb1 = *reinterpret_cast<const half8*>(q + 8);
     };
@@ -99,6 +117,9 @@ __global__ __launch_bounds__(256) void k_gemm(const void* __restrict__ Av, int l
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     const int wm = (w >> 1) * 32, wn = (w & 1) * 32, r = l & 31, h8 = (l >> 5) * 8;
     const int nk = K / 64;
+    // BT: this lane's piece of the first 4 x 16 block of k-step 0 (bytes from the start of a Bs buffer)
+    const unsigned bt_lane = (unsigned)(((h8 + ((l & 15) >> 2)) * LS + wn + 16 * ((l >> 4) & 1) + 4 * (l & 3)) * 2);
+    const unsigned bs0 = (unsigned)(size_t)&Bs[0][0][0];
     fetch(0);
     stage(0);
     __syncthreads();
@@ -108,7 +129,14 @@ __global__ __launch_bounds__(256) void k_gemm(const void* __restrict__ Av, int l
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const half8 a = *reinterpret_cast<const half8*>(&As[buf][wm + r][16 * s + h8]);
-            const half8 b = *reinterpret_cast<const half8*>(&Bs[buf][wn + r][16 * s + h8]);
+            half8 b;
+            if constexpr (BT) {
+                const unsigned ba = bs0 + buf * (64 * LS * 2) + bt_lane;
+                b = s == 0 ? frag_tr<0, 4 * LS * 2>(ba) : s == 1 ? frag_tr<16 * LS * 2, 4 * LS * 2>(ba)
+                  : s == 2 ? frag_tr<32 * LS * 2, 4 * LS * 2>(ba) : frag_tr<48 * LS * 2, 4 * LS * 2>(ba);
+            } else {
+                b = *reinterpret_cast<const half8*>(&Bs[buf][wn + r][16 * s + h8]);
+            }
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
         }
         if (kt + 1 < nk) stage(buf ^ 1);
@@ -135,9 +163,10 @@ __global__ __launch_bounds__(256) void k_gemm(const void* __restrict__ Av, int l
 }
 
 // A_F16 / A_F32: A is [Mp, lda];  A_CONV3: A is the NHWC image, lda unused, K = 9 C.  Mp, N, K multiples of 64.
-template <int EPI, int ASRC>
+// BT: W is Wt[K, N] row-major (a forward weight matrix [out = K, in = N] read in place by its backward GEMM).
+template <int EPI, int ASRC, bool BT = false>
 static int gemm(hipStream_t st, const void* A, int lda, const half_t* W, int Mp, int N, int K, const Epi& e) {
-    hipLaunchKernelGGL((k_gemm<EPI, ASRC>), dim3(N / 64, Mp / 64), dim3(256), 0, st, A, lda, W, K, e);
+    hipLaunchKernelGGL((k_gemm<EPI, ASRC, BT>), dim3(N / 64, Mp / 64), dim3(256), 0, st, A, lda, W, K, BT ? N : K, e);
     return check_hip(hipGetLastError(), "k_gemm launch");
 }
 

@@ -90,6 +90,7 @@ _SIGS = {
     "nerfart_clip_vitb32_image_fwd": (_i, [_p, _p, _i, _p, _i, _p, _ll, _p]),
     "nerfart_clip_vitb32_image_bwd": (_i, [_p, _i, _p, _p, _p, _ll, _p]),
     "nerfart_gemm_f16_nt": (_i, [_p, _p, _i, _i, _i, _p, _p]),
+    "nerfart_gemm_f16_nn": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "nerfart_vgg16_blob_layout": (_ll, [_p]),
     "nerfart_vgg16_workspace_bytes": (_ll, [_i, _i, _i]),
     "nerfart_vgg16_l1_fwd": (_i, [_p, _p, _i, _i, _p, _i, _p, _ll, _p]),

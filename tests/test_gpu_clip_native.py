@@ -27,6 +27,24 @@ def test_gemm_kernel_matches_matmul():
         assert err < 2e-3 * max(1.0, ref.abs().max().item())
 
 
+def test_gemm_kernel_with_the_weight_read_in_place_matches_matmul():
+    """C = A . Wt with Wt [K, N] row-major (the backward GEMMs on the forward weight matrices: B fragments through the
+    transposing LDS read); the result must also equal, bit for bit, the NT kernel on the explicitly transposed operand - same
+    products, same accumulation order."""
+    from nerfart_amd import clip_native
+    g = torch.Generator().manual_seed(1)
+    for (M, N, K) in ((64, 64, 64), (128, 192, 256), (832, 768, 2304), (64, 768, 512), (832, 3072, 768)):
+        a = torch.randn(M, K, generator=g).half()
+        wt = (torch.randn(K, N, generator=g) * 0.05).half()
+        wt[:, 1::2] *= 0.5                                           # columns differ in scale: a permuted column cannot pass
+        c = clip_native.gemm_f16_nn(a.to(DEV), wt.to(DEV))
+        ref = a.double() @ wt.double()
+        err = (c.cpu().double() - ref).abs().max().item()
+        print(f"  gemm nn {M}x{N}x{K}: max abs err {err:.2e} (ref max {ref.abs().max().item():.2f})")
+        assert err < 2e-3 * max(1.0, ref.abs().max().item())
+        assert torch.equal(c, clip_native.gemm_f16_nt(a.to(DEV), wt.t().contiguous().to(DEV)))
+
+
 def _models():
     from nerfart_amd import clip_vit
     gpu = clip_vit.build_clip(DEV, seed=0)                           # fp16 weights, as clip.load on a GPU
