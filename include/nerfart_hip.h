@@ -15,14 +15,14 @@
  *     there and in DESIGN.md): `surf_blob` = SDF net, `rad_blob` = geometry-feature rows + radiance net.
  *   - `precision` selects the matrix-core path AND the blob format it expects:
  *       0 = fp32-exact (v_mfma_f32_16x16x4_f32; blobs from surface_plan()/radiance_plan()).  nerfart_sdf_nabla_fwd* runs
- *           REVERSE mode here too (k_sdf_grad: forward sweep + transposed chunks of the same blob, softplus' parked as fp32 in a
- *           256 MiB library scratch per (device, stream)); precision 3 (these two entry points only) selects the forward-mode
- *           tangent quads of k_sdf_nabla on the same blob (cross-checks),
+ *           REVERSE mode (k_sdf_grad: forward sweep + transposed chunks of the same blob, softplus' parked as fp32 in the
+ *           caller's workspace); precision 3 (these two entry points only) selects the forward-mode tangent quads of
+ *           k_sdf_nabla on the same blob (cross-checks),
  *       1 = split bf16 "bf16x3" (3 x v_mfma_f32_16x16x32_bf16 per k-step on hi/lo operand splits, ~2^-16
  *           relative per product; blobs from surface_plan_bf16()/radiance_plan_bf16()).  nerfart_sdf_nabla_fwd*
- *           then runs REVERSE mode (forward sweep + transposed-weight sweep in one kernel) and keeps one 117 MiB
- *           scratch per (device, stream) inside the library for the life of the process; precision 2 (these two
- *           entry points only) selects the forward-mode tangent kernel on the same blob (cross-checks).
+ *           then runs REVERSE mode too (forward sweep + transposed-weight sweep in one kernel, softplus' as unorm16 in the
+ *           caller's workspace); precision 2 (these two entry points only) selects the forward-mode tangent kernel on the
+ *           same blob (cross-checks).
  *   - point sources: either an explicit array pts[M,3], or ("_rays" variants) rays + per-ray depths:
  *     point m = slot m / n_per_ray, sample m % n_per_ray, ray = ray_idx ? ray_idx[slot] : slot,
  *     x = rays_o[ray] + rays_d[ray] * depth[slot * depth_stride + sample]  (two roundings, as the
@@ -35,6 +35,9 @@
 extern "C" {
 #endif
 
+/* 2 (round 4).  History: 1 -> 2: nerfart_sdf_nabla_fwd[_rays] take a caller-owned workspace; the CLIP blob stores every matrix once; the
+ * VGG blob is fp32; the CLIP / VGG entry points take blob_bytes and reject blobs of another layout; new: the ray-level backward
+ * (nerfart_*_render_bwd, nerfart_sdf_param_bwd, nerfart_fold_weight_grads, nerfart_weight_norm_bwd). */
 int nerfart_abi_version(void);
 const char* nerfart_last_error(void);
 
@@ -219,6 +222,8 @@ int nerfart_neus_render_fwd(const float* surf_blob, const float* rad_blob, int p
  *               fp16 matrices, each stored once (0 conv1, 2 + 8 l + {0, 2, 4, 6} the four linear maps of block l, 99 proj; the odd
  *               sections, once the transposed copies, are empty: the backward GEMMs read the forward matrices in place), then
  *               fp32 vectors (100 class / positional embeddings, LayerNorm parameters, biases) - list in csrc/clip_vit.hip.
+ *   blob_bytes: the size of the caller's blob; must equal the layout's total, so a blob packed to an older layout (ABI 1 stored
+ *               transposed copies too) is rejected instead of read.
  *   img       : [B, 3, 224, 224] fp32, already resized and normalised (the reference's `preprocess`).
  *   feat_out  : [B, 512] fp32 (un-normalised features, as encode_image returns them).
  *   workspace : nerfart_clip_vitb32_workspace_bytes(B, keep_for_bwd) bytes of device memory.  With keep_for_bwd != 0 the
@@ -227,9 +232,9 @@ int nerfart_neus_render_fwd(const float* surf_blob, const float* rad_blob, int p
  *               each with its own workspace. */
 long long nerfart_clip_vitb32_blob_layout(long long* offsets);
 long long nerfart_clip_vitb32_workspace_bytes(int B, int keep_for_bwd);
-int nerfart_clip_vitb32_image_fwd(const void* blob, const float* img, int B, float* feat_out, int keep_for_bwd, void* workspace,
+int nerfart_clip_vitb32_image_fwd(const void* blob, long long blob_bytes, const float* img, int B, float* feat_out, int keep_for_bwd, void* workspace,
                                   long long workspace_bytes, void* stream);
-int nerfart_clip_vitb32_image_bwd(const void* blob, int B, const float* g_feat, float* g_img, void* workspace, long long workspace_bytes,
+int nerfart_clip_vitb32_image_bwd(const void* blob, long long blob_bytes, int B, const float* g_feat, float* g_img, void* workspace, long long workspace_bytes,
                                   void* stream);
 /* ---- image side of the style losses (rows a20-a22; csrc/style_heads.hip).
  * nerfart_resample_fwd: one stage of the reference's torchvision `preprocess` chains (criteria/clip_loss.py:166-168,
@@ -275,7 +280,7 @@ int nerfart_sphere_trace_step(const float* sdf, int n_rays, const float* far, fl
  * implicit-GEMM 3 x 3 convolutions on v_mfma_f32_32x32x2_f32 (fp32 operands as the reference's net; csrc/vgg_conv.hip), L1
  * between prediction and target features.
  *   blob : nerfart_vgg16_blob_layout() sections (offsets[22] bytes; packed by nerfart_amd/vgg.py): per conv l = 0..6 forward
- *          weights, backward (tap-flipped, channel-transposed) weights, bias - all fp32.
+ *          weights, backward (tap-flipped, channel-transposed) weights, bias - all fp32; blob_bytes must equal the layout's total.
  *   img2 : [2, 3, H, W] fp32 = the ImageNet-normalised, resized prediction then target (perp_loss.py:41-45); H, W multiples of 4,
  *          H W / 16 a multiple of 64 (224 x 224 in the reference).
  * nerfart_vgg16_l1_fwd writes loss_out[0] (device) = mean |relu3_3(pred) - relu3_3(target)|; with keep_for_bwd the workspace
@@ -283,9 +288,9 @@ int nerfart_sphere_trace_step(const float* sdf, int n_rays, const float* far, fl
  * into g_img [1, 3, H, W] = d loss / d img2[0]. */
 long long nerfart_vgg16_blob_layout(long long* offsets);
 long long nerfart_vgg16_workspace_bytes(int H, int W, int keep_for_bwd);
-int nerfart_vgg16_l1_fwd(const void* blob, const float* img2, int H, int W, float* loss_out, int keep_for_bwd, void* workspace,
+int nerfart_vgg16_l1_fwd(const void* blob, long long blob_bytes, const float* img2, int H, int W, float* loss_out, int keep_for_bwd, void* workspace,
                          long long workspace_bytes, void* stream);
-int nerfart_vgg16_l1_bwd(const void* blob, int H, int W, const float* upstream, float* g_img, void* workspace, long long workspace_bytes, void* stream);
+int nerfart_vgg16_l1_bwd(const void* blob, long long blob_bytes, int H, int W, const float* upstream, float* g_img, void* workspace, long long workspace_bytes, void* stream);
 
 /* ---- weight-gradient reductions of pass 2 (row a19; what autograd accumulates through volsdf.py:759-770): for n_mats matrix
  * pairs, dW[m] [256, a_cols] fp32 = Z_m^T A_m over `rows` rows and, if cs != NULL, cs[m] [256] = column sums of the first cs_rows
@@ -300,9 +305,9 @@ int nerfart_wgrad_bf16(const void* Z, long long z_stride, const void* A, long lo
 /* ---- per-point glue of pass 2 (row a19; csrc/pass2_operands.hip): what autograd does between the network calls of
  * volsdf.py:759-770, one pass each.
  *   nerfart_ray_points: pts[R P,3] = rays_o + rays_dn * depth[R,P] (volsdf.py:503-506), view[R P,3] = rays_dn per sample (NULL: skip).
- *   nerfart_volsdf_pass2_cotangents: from the compositor's g_sdf[R P], the radiance net's g_n[R P,3] (+ g_n_extra, may be NULL) and
+ *   nerfart_volsdf_pass2_cotangents: from the compositor's g_sdf[R P], the radiance net's g_n[R P,3] (+ g_n_extra; either may be NULL = zero) and
  *     pass 1's pts / sdf / nabla: sbar[R P] = g_sdf where the sphere clamp sdf = min(net, R_bg - |x|) kept the net (volsdf.py:97-100,
- *     else 0), nbar[R P,3] = g_n + the eikonal term's gradient w 2 (|n| - 1) n / (|n| N) with N = the points of the ray's reference
+ *     else 0; R_bg <= 0: no sphere, NeuS), nbar[R P,3] = g_n + the eikonal term's gradient w 2 (|n| - 1) n / (|n| N) with N = the points of the ray's reference
  *     patch (eik_group_rays rays per patch inside this launch, the last one ragged; <= 0: one patch), eik_ray[R] = each ray's share
  *     of w * mean_patch((|n| - 1)^2) (their sum = the sum of the patches' eikonal losses).  w_eikonal = 0: no eikonal term.
  *   nerfart_wgrad_operand_*: the narrow (a_cols = 64) operands of nerfart_wgrad_bf16 from fp32 data: hi parts bf16(x) in columns
@@ -325,6 +330,63 @@ int nerfart_wgrad_operand_inputs(const float* x, int multires_x, const float* vi
 int nerfart_wgrad_operand_rgb_delta(const float* rgb, const float* g_rgb, long long M, long long rows_pad, void* out, float* d4,
                                     float* block_sums, void* stream);
 int nerfart_wgrad_operand_sbar_ones(const float* sbar, long long M, long long rows_pad, void* out, void* stream);
+
+/* ---- B1 "bwd": the RAY-LEVEL backward of the renderer (csrc/render_backward.hip).  What `rgb.backward(gradient)` +
+ * `eikonal.backward()` through render_fn do for one patch of rays in the reference (models/frameworks/volsdf.py:759-770,
+ * neus.py:520-576) is one call: the whole pass-2 kernel sequence above (points, [SDF + nabla + h7], radiance forward with dumps,
+ * compositor backward, radiance backward, cotangents, second-order SDF sweeps, weight-gradient reductions) on the caller's stream,
+ * out of one caller-owned workspace.  Split-bf16 blobs (precision 1) only.
+ *
+ *   raw       : the RAW parameter-gradient buffer, nerfart_pass2_raw_layout(offsets[14]) floats (offsets = float offset of each
+ *               section, last = total; returns the total): the fp32 results of the reductions in the kernels' unit order, bias column
+ *               sums, and 4 scalars (section 12: d loss / d alpha, d loss / d beta [VolSDF], d loss / d s [NeuS], the sum of the
+ *               patches' eikonal losses).  Every call ACCUMULATES into it: zero it once per optimiser step, call once per launch group
+ *               (n_rays * P <= 2^21), then nerfart_fold_weight_grads once.  Everything downstream is linear in it, so ranks may also
+ *               all-reduce the raw buffer instead of the parameter gradients.
+ *   rays_d    : un-normalised, as nerfart_*_render_fwd takes them; d_all [n_rays, P]: the sample depths pass 1 drew (d_all_out of
+ *               the forward; sampling carries no gradient, volsdf.py:479).
+ *   g_rgb     : d loss / d rgb [n_rays, 3]; g_acc [n_rays] or NULL: d loss / d mask_volume (the mask BCE of neus.py:600-603);
+ *               g_n_extra [n_rays, P, 3] or NULL: a further cotangent of the nablas (VolSDF reconstruction objective, volsdf.py:803-806).
+ *   *_state   : what pass 1 computed at these samples (sdf_out / nabla_out of the forward, and for VolSDF the layer-7 activation h7
+ *               [n_rays P, 256] of nerfart_sdf_nabla_fwd) - same weights, identical values; all NULL: recomputed here.
+ *   w_eikonal : weight of mean((|nabla| - 1)^2) (0: no eikonal term); eik_group_rays: the rays are several reference patches of
+ *               that many rays in one launch, each with its OWN mean (<= 0: one patch).
+ *   train_radiance == 0: the radiance net is frozen (neus.py:455-456): only the SDF net's gradients (incl. the geometry-feature
+ *               rows of its last layer) are produced.
+ * nerfart_sdf_param_bwd: the SDF net's share on its own - parameter gradients of  sbar . sdf + hbar7 . h7 + nbar . grad_x sdf  at
+ *   pts [M, 3] (sbar [M] / hbar7 [M, 256] may be NULL = zero; M <= 2^21): the free eikonal points of volsdf.py:799-806.
+ * nerfart_fold_weight_grads: raw -> `folded`, the gradients of the FOLDED weights W = g v / |v| and of the biases in the reference's
+ *   feature order, laid out by nerfart_folded_grads_layout(multires, multires_view, offsets[29]): (dW_l [out_l, in_l], db_l [out_l])
+ *   for the SDF net's layers 0..8, then the radiance net's 0..4; offsets in floats, last = total (returned).  multires = the SDF
+ *   net's embed_multires (6), multires_view = the radiance net's embed_multires_view (-1 | 4).
+ * nerfart_weight_norm_bwd: nn.utils.weight_norm's chain rule for one layer (models/base.py:226-227): dW [out, in] ->
+ *   g_weight_v [out, in], g_weight_g [out] (either may be NULL; accumulate != 0 adds to them). */
+long long nerfart_pass2_raw_layout(long long* offsets);
+long long nerfart_volsdf_render_bwd_workspace_bytes(int n_rays, int P, int have_state);
+int nerfart_volsdf_render_bwd(const float* surf_blob, const float* rad_blob, int view_tiles, int multires, const float* rays_o, const float* rays_d,
+                              int n_rays, int P, const float* d_all, const float* g_rgb, const float* g_acc, const float* g_n_extra,
+                              const float* sdf_state, const float* nabla_state, const float* h7_state, float R_bg, float alpha, float beta,
+                              int white_bkgd, float w_eikonal, int eik_group_rays, int train_radiance, float* raw, void* workspace,
+                              long long workspace_bytes, void* stream);
+long long nerfart_neus_render_bwd_workspace_bytes(int n_rays, int P, int have_state);
+int nerfart_neus_render_bwd(const float* surf_blob, const float* rad_blob, int view_tiles, int multires, const float* rays_o, const float* rays_d,
+                            int n_rays, int P, const float* d_all, const float* g_rgb, const float* g_acc, const float* sdf_state,
+                            const float* nabla_state, float s, int white_bkgd, float w_eikonal, int eik_group_rays, int train_radiance, float* raw,
+                            void* workspace, long long workspace_bytes, void* stream);
+long long nerfart_sdf_param_bwd_workspace_bytes(long long M);
+int nerfart_sdf_param_bwd(const float* surf_blob, int multires, const float* pts, long long M, const float* sbar, const float* hbar7, const float* nbar,
+                          float* raw, void* workspace, long long workspace_bytes, void* stream);
+/* the radiance net's share on its own (B2 "bwd", parameter level): RadianceNet.forward (models/base.py:372-391) on [pts, view, nabla,
+ * W8[1:] h7 + b8[1:]] with its backward - rgb_out [M,3], g_h7_out [M,256], g_n_out [M,3] (each may be NULL) and, accumulated into
+ * raw, the gradients of the radiance net (train_radiance != 0) and of the geometry-feature rows of the last SDF layer. */
+long long nerfart_radiance_param_bwd_workspace_bytes(long long M);
+int nerfart_radiance_param_bwd(const float* rad_blob, int view_tiles, const float* pts, const float* view, const float* nabla, const float* h7,
+                               long long M, const float* g_rgb, float* rgb_out, float* g_h7_out, float* g_n_out, int train_radiance, float* raw,
+                               void* workspace, long long workspace_bytes, void* stream);
+long long nerfart_folded_grads_layout(int multires, int multires_view, long long* offsets);
+int nerfart_fold_weight_grads(const float* raw, int multires, int multires_view, float* folded, void* stream);
+int nerfart_weight_norm_bwd(const float* dW, const float* weight_v, const float* weight_g, int out_features, int in_features, float* g_weight_v,
+                            float* g_weight_g, int accumulate, void* stream);
 
 /* The GEMM kernel of the encoder on its own (tests): C[M,N] fp32 = A[M,K] fp16 . W[N,K]^T fp16; M, N, K multiples of 64. */
 int nerfart_gemm_f16_nt(const void* A, const void* W, int M, int N, int K, float* C, void* stream);

@@ -85,14 +85,14 @@ def image_fwd(blob, images, keep: bool):
     nbytes = hip.lib.nerfart_clip_vitb32_workspace_bytes(B, int(keep))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=images.device)
     feat = torch.empty(B, OUT, dtype=torch.float32, device=images.device)
-    _check(hip.lib.nerfart_clip_vitb32_image_fwd(_ptr(blob), _ptr(images), B, _ptr(feat), int(keep), _ptr(ws), nbytes, _stream()),
+    _check(hip.lib.nerfart_clip_vitb32_image_fwd(_ptr(blob), blob.numel() * blob.element_size(), _ptr(images), B, _ptr(feat), int(keep), _ptr(ws), nbytes, _stream()),
            "nerfart_clip_vitb32_image_fwd")
     return feat, ws
 
 
 def image_bwd(blob, ws, B, g_feat):
     g_img = torch.empty(B, 3, RES, RES, dtype=torch.float32, device=g_feat.device)
-    _check(hip.lib.nerfart_clip_vitb32_image_bwd(_ptr(blob), B, _ptr(g_feat), _ptr(g_img), _ptr(ws), ws.numel(), _stream()),
+    _check(hip.lib.nerfart_clip_vitb32_image_bwd(_ptr(blob), blob.numel() * blob.element_size(), B, _ptr(g_feat), _ptr(g_img), _ptr(ws), ws.numel(), _stream()),
            "nerfart_clip_vitb32_image_bwd")
     return g_img
 

@@ -422,6 +422,13 @@ static int check_args(const void* blob, const void* ws, int B, long long ws_byte
     if (ws_bytes < work_layout(B, keep).total) { set_last_error("clip_vitb32: workspace too small (nerfart_clip_vitb32_workspace_bytes)"); return 1; }
     return 0;
 }
+// a blob packed to another layout (the round-2 blob carried transposed copies: 352 MB) must be rejected, not read
+static int check_blob_bytes(long long blob_bytes) {
+    long long off[N_SECTIONS + 1];
+    blob_layout(off);
+    if (blob_bytes != off[N_SECTIONS]) { set_last_error("clip_vitb32: blob_bytes differs from nerfart_clip_vitb32_blob_layout(): blob packed to another layout / ABI version"); return 1; }
+    return 0;
+}
 
 }  // namespace clip
 }  // namespace nerfart
@@ -451,9 +458,9 @@ int nerfart_gemm_f16_nn(const void* A, const void* Wt, int M, int N, int K, floa
     return gemm<EPI_F32, A_F16, true>((hipStream_t)stream, A, K, (const half_t*)Wt, M, N, K, e);
 }
 
-int nerfart_clip_vitb32_image_fwd(const void* blob, const float* img, int B, float* feat_out, int keep_for_bwd, void* workspace,
+int nerfart_clip_vitb32_image_fwd(const void* blob, long long blob_bytes, const float* img, int B, float* feat_out, int keep_for_bwd, void* workspace,
                                   long long workspace_bytes, void* stream) {
-    if (check_args(blob, workspace, B, workspace_bytes, keep_for_bwd)) return 1;
+    if (check_args(blob, workspace, B, workspace_bytes, keep_for_bwd) || check_blob_bytes(blob_bytes)) return 1;
     hipStream_t st = (hipStream_t)stream;
     Blob bl;
     bl.base = (const char*)blob;
@@ -506,9 +513,9 @@ int nerfart_clip_vitb32_image_fwd(const void* blob, const float* img, int B, flo
     return 0;
 }
 
-int nerfart_clip_vitb32_image_bwd(const void* blob, int B, const float* g_feat, float* g_img, void* workspace, long long workspace_bytes,
+int nerfart_clip_vitb32_image_bwd(const void* blob, long long blob_bytes, int B, const float* g_feat, float* g_img, void* workspace, long long workspace_bytes,
                                   void* stream) {
-    if (check_args(blob, workspace, B, workspace_bytes, 1)) return 1;
+    if (check_args(blob, workspace, B, workspace_bytes, 1) || check_blob_bytes(blob_bytes)) return 1;
     hipStream_t st = (hipStream_t)stream;
     Blob bl;
     bl.base = (const char*)blob;

@@ -104,10 +104,11 @@ k_volsdf_cotangents(const float* __restrict__ pts, const float* __restrict__ sdf
         const long long m = r * P + p;
         const float x = pts[3 * m], y = pts[3 * m + 1], z = pts[3 * m + 2];
         const float s = sdf[m];
-        const bool clamped = s >= (R_bg - sqrtf(x * x + y * y + z * z)) - 1e-6f;
+        const bool clamped = R_bg > 0.f && s >= (R_bg - sqrtf(x * x + y * y + z * z)) - 1e-6f;      // R_bg <= 0: no sphere (NeuS)
         sbar[m] = clamped ? 0.f : g_sdf[m];
         const float nx = nab[3 * m], ny = nab[3 * m + 1], nz = nab[3 * m + 2];
-        float bx = g_n[3 * m], by = g_n[3 * m + 1], bz = g_n[3 * m + 2];
+        float bx = 0.f, by = 0.f, bz = 0.f;
+        if (g_n) { bx = g_n[3 * m]; by = g_n[3 * m + 1]; bz = g_n[3 * m + 2]; }
         if (w_eik != 0.f) {
             const float nn = sqrtf(nx * nx + ny * ny + nz * nz);
             const float err = nn - 1.0f;
@@ -235,12 +236,12 @@ int nerfart_ray_points(const float* rays_o, const float* rays_dn, const float* d
 
 // VolSDF pass 2, between the radiance net's backward and the second-order SDF sweep.  w_eikonal 0: no eikonal term.
 // eik_group_rays: rays per reference patch inside this launch (<= 0: the launch is one patch).  eik_ray [n_rays]: each ray's share of
-// the eikonal loss (sum them); g_n_extra may be NULL.
+// the eikonal loss (sum them); g_n / g_n_extra may be NULL (zero); R_bg <= 0: no sphere clamp (NeuS: sbar = g_sdf).
 int nerfart_volsdf_pass2_cotangents(const float* pts, const float* sdf, const float* g_sdf, const float* nabla, const float* g_n,
                                     const float* g_n_extra, long long n_rays, int P, float R_bg, float w_eikonal,
                                     long long eik_group_rays, float* sbar, float* nbar, float* eik_ray, void* stream) {
     if (n_rays <= 0 || P <= 0) return 0;
-    if (!pts || !sdf || !g_sdf || !nabla || !g_n || !sbar || !nbar || !eik_ray) { set_last_error("pass2_cotangents: null argument"); return 2; }
+    if (!pts || !sdf || !g_sdf || !nabla || !sbar || !nbar || !eik_ray) { set_last_error("pass2_cotangents: null argument"); return 2; }
     if (n_rays * P >= (1ll << 31)) { set_last_error("pass2_cotangents: n_rays * P must stay below 2^31"); return 2; }
     hipLaunchKernelGGL(k_volsdf_cotangents, dim3((unsigned)n_rays), dim3(64), 0, (hipStream_t)stream, pts, sdf, g_sdf, nabla, g_n,
                        g_n_extra, n_rays, P, R_bg, w_eikonal, eik_group_rays, sbar, nbar, eik_ray);

@@ -179,9 +179,10 @@ long long nerfart_vgg16_blob_layout(long long* offsets) { return blob_layout(off
 long long nerfart_vgg16_workspace_bytes(int H, int W, int keep_for_bwd) { return (H >= 8 && W >= 8) ? work_layout(H, W, keep_for_bwd).total : 0; }
 
 // img2 [2, 3, H, W] fp32: the normalised (and resized) prediction, then the target.  loss_out[0] = mean |relu3_3(pred) - relu3_3(target)|.
-int nerfart_vgg16_l1_fwd(const void* blob, const float* img2, int H, int W, float* loss_out, int keep_for_bwd, void* workspace,
+int nerfart_vgg16_l1_fwd(const void* blob, long long blob_bytes, const float* img2, int H, int W, float* loss_out, int keep_for_bwd, void* workspace,
                          long long workspace_bytes, void* stream) {
     if (check_geo(H, W)) return 1;
+    if (blob && blob_bytes != blob_layout(nullptr)) { set_last_error("vgg16_l1_fwd: blob_bytes differs from nerfart_vgg16_blob_layout(): blob packed to another layout / ABI version"); return 1; }
     const Work w = work_layout(H, W, keep_for_bwd);
     if (!blob || !workspace || workspace_bytes < w.total) { set_last_error("vgg16_l1_fwd: null blob / workspace too small"); return 1; }
     hipStream_t st = (hipStream_t)stream;
@@ -219,8 +220,9 @@ int nerfart_vgg16_l1_fwd(const void* blob, const float* img2, int H, int W, floa
 }
 
 // g_img [1, 3, H, W] = upstream[0] (device scalar; NULL = 1) * d loss / d (normalised prediction), from the kept workspace.
-int nerfart_vgg16_l1_bwd(const void* blob, int H, int W, const float* upstream, float* g_img, void* workspace, long long workspace_bytes, void* stream) {
+int nerfart_vgg16_l1_bwd(const void* blob, long long blob_bytes, int H, int W, const float* upstream, float* g_img, void* workspace, long long workspace_bytes, void* stream) {
     if (check_geo(H, W)) return 1;
+    if (blob && blob_bytes != blob_layout(nullptr)) { set_last_error("vgg16_l1_bwd: blob_bytes differs from nerfart_vgg16_blob_layout(): blob packed to another layout / ABI version"); return 1; }
     const Work w = work_layout(H, W, 1);
     if (!blob || !workspace || workspace_bytes < w.total) { set_last_error("vgg16_l1_bwd: null blob / workspace too small"); return 1; }
     hipStream_t st = (hipStream_t)stream;

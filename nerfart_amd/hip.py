@@ -87,14 +87,14 @@ _SIGS = {
     "nerfart_neus_render_fwd": (_i, [_p, _p, _i, _i, _p, _p, _i, _f, _f, _i, _i, _i, _i, _i] + [_p] * 2 + [_i] + [_p] * 12 + [_p, _ll, _p]),
     "nerfart_clip_vitb32_blob_layout": (_ll, [_p]),
     "nerfart_clip_vitb32_workspace_bytes": (_ll, [_i, _i]),
-    "nerfart_clip_vitb32_image_fwd": (_i, [_p, _p, _i, _p, _i, _p, _ll, _p]),
-    "nerfart_clip_vitb32_image_bwd": (_i, [_p, _i, _p, _p, _p, _ll, _p]),
+    "nerfart_clip_vitb32_image_fwd": (_i, [_p, _ll, _p, _i, _p, _i, _p, _ll, _p]),
+    "nerfart_clip_vitb32_image_bwd": (_i, [_p, _ll, _i, _p, _p, _p, _ll, _p]),
     "nerfart_gemm_f16_nt": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "nerfart_gemm_f16_nn": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "nerfart_vgg16_blob_layout": (_ll, [_p]),
     "nerfart_vgg16_workspace_bytes": (_ll, [_i, _i, _i]),
-    "nerfart_vgg16_l1_fwd": (_i, [_p, _p, _i, _i, _p, _i, _p, _ll, _p]),
-    "nerfart_vgg16_l1_bwd": (_i, [_p, _i, _i, _p, _p, _p, _ll, _p]),
+    "nerfart_vgg16_l1_fwd": (_i, [_p, _ll, _p, _i, _i, _p, _i, _p, _ll, _p]),
+    "nerfart_vgg16_l1_bwd": (_i, [_p, _ll, _i, _i, _p, _p, _p, _ll, _p]),
     "nerfart_first_crossing": (_i, [_p, _p, _i, _i, _f, _p, _p, _p, _p, _p, _p]),
     "nerfart_secant_update": (_i, [_p, _i, _f, _p, _p, _p, _p]),
     "nerfart_root_finish": (_i, [_p, _p, _i, _p, _p, _p, _p, _f, _i, _p, _p, _p]),
@@ -102,6 +102,18 @@ _SIGS = {
     "nerfart_resample_fwd": (_i, [_p] + [_i] * 11 + [_p, _p, _p, _p, _i, _i, _i, _p]),
     "nerfart_resample_bwd": (_i, [_p] + [_i] * 11 + [_p, _p, _p, _p, _i, _i, _i, _p]),
     "nerfart_clip_style_heads": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _p, _p, _p]),
+    "nerfart_pass2_raw_layout": (_ll, [_p]),
+    "nerfart_volsdf_render_bwd_workspace_bytes": (_ll, [_i, _i, _i]),
+    "nerfart_volsdf_render_bwd": (_i, [_p, _p, _i, _i, _p, _p, _i, _i] + [_p] * 7 + [_f, _f, _f, _i, _f, _i, _i, _p, _p, _ll, _p]),
+    "nerfart_neus_render_bwd_workspace_bytes": (_ll, [_i, _i, _i]),
+    "nerfart_neus_render_bwd": (_i, [_p, _p, _i, _i, _p, _p, _i, _i] + [_p] * 5 + [_f, _i, _f, _i, _i, _p, _p, _ll, _p]),
+    "nerfart_sdf_param_bwd_workspace_bytes": (_ll, [_ll]),
+    "nerfart_sdf_param_bwd": (_i, [_p, _i, _p, _ll, _p, _p, _p, _p, _p, _ll, _p]),
+    "nerfart_radiance_param_bwd_workspace_bytes": (_ll, [_ll]),
+    "nerfart_radiance_param_bwd": (_i, [_p, _i, _p, _p, _p, _p, _ll, _p, _p, _p, _p, _i, _p, _p, _ll, _p]),
+    "nerfart_folded_grads_layout": (_ll, [_i, _i, _p]),
+    "nerfart_fold_weight_grads": (_i, [_p, _i, _i, _p, _p]),
+    "nerfart_weight_norm_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p, _i, _p]),
 }
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)          # AttributeError here = header / library mismatch
@@ -306,19 +318,21 @@ def lin_table(n: int, device) -> torch.Tensor:
 
 
 _ws_cache = {}
+_ws_lock = __import__("threading").Lock()
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
     """One cached byte buffer per (device, stream), grown on demand (288 GB of HBM: keep it resident).  Per stream: the entry points
     run asynchronously on torch's current stream, so two streams (or two host threads on their own streams) must not share scratch."""
     key = (str(device), int(torch.cuda.current_stream(device).cuda_stream))
-    ws = _ws_cache.get(key)
-    if ws is None or ws.numel() < nbytes:
-        _ws_cache.pop(key, None)
-        while len(_ws_cache) >= 8:                                 # short-lived streams must not pin memory for good
-            _ws_cache.pop(next(iter(_ws_cache)))
-        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        _ws_cache[key] = ws
+    with _ws_lock:                                                 # two host threads on their own streams may grow / evict at once
+        ws = _ws_cache.get(key)
+        if ws is None or ws.numel() < nbytes:
+            _ws_cache.pop(key, None)
+            while len(_ws_cache) >= 8:                             # short-lived streams must not pin memory for good
+                _ws_cache.pop(next(iter(_ws_cache)), None)
+            ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            _ws_cache[key] = ws
     return ws
 
 
@@ -424,6 +438,104 @@ def neus_composite_bwd(sdf, rad_mid, s: float, g_rgb, white_bkgd: bool = False, 
     _check(lib.nerfart_neus_composite_bwd(R, P, _dev(sdf), _dev(rad_mid), float(s), int(bool(white_bkgd)), _dev(g_rgb), _dev(g_acc, name="g_acc"),
                                           _dev(g_sdf), _dev(g_rad), _dev(g_s), _stream()), "nerfart_neus_composite_bwd")
     return g_sdf, g_rad, g_s
+
+
+# ---- B1 "bwd": the ray-level backward (csrc/render_backward.hip) --------------------------------------------------
+RAW_SECTIONS = ("surf_ww", "surf_we", "surf_cs0", "surf_cs17", "surf_w8", "surf_b8", "rad_ww", "rad_cs", "rad_w4", "rad_b4", "rad_wex", "rad_wh7",
+                "scalars")
+RAW_G_ALPHA, RAW_G_BETA, RAW_G_S, RAW_EIKONAL = 0, 1, 2, 3            # entries of the `scalars` section
+
+
+def raw_layout():
+    """({section: float offset}, total floats) of the raw parameter-gradient buffer (nerfart_pass2_raw_layout)."""
+    offs = (C.c_longlong * (len(RAW_SECTIONS) + 1))()
+    total = int(lib.nerfart_pass2_raw_layout(offs))
+    return {k: int(offs[i]) for i, k in enumerate(RAW_SECTIONS)}, total
+
+
+def new_raw(device) -> torch.Tensor:
+    """A zeroed raw buffer: the entry points below ACCUMULATE into it (one buffer per optimiser step)."""
+    return torch.zeros(raw_layout()[1], dtype=torch.float32, device=device)
+
+
+def volsdf_render_bwd(surf_blob, rad_blob, view_tiles: int, multires: int, rays_o, rays_d, d_all, g_rgb, raw, *, R_bg: float, alpha: float,
+                      beta: float, white_bkgd: bool = False, w_eikonal: float = 0.0, eik_group_rays: int = 0, train_radiance: bool = True,
+                      g_acc=None, g_n_extra=None, state=None):
+    """rgb.backward(g_rgb) + eikonal.backward() of one launch group of VolSDF rays (volsdf.py:759-770) -> accumulated into `raw`.
+    rays_d un-normalised; d_all [R, P] from pass 1; state = (sdf [R P], nabla [R P, 3], h7 [R P, 256]) kept from pass 1 or None."""
+    R, P = d_all.shape
+    sdf, nab, h7 = state if state is not None else (None, None, None)
+    nb = int(lib.nerfart_volsdf_render_bwd_workspace_bytes(R, P, int(state is not None)))
+    ws = _workspace(nb, d_all.device)
+    _check(lib.nerfart_volsdf_render_bwd(
+        _dev(surf_blob), _dev(rad_blob), int(view_tiles), int(multires), _dev(rays_o, name="rays_o"), _dev(rays_d, name="rays_d"), R, P,
+        _dev(d_all, name="d_all"), _dev(g_rgb, name="g_rgb"), _dev(g_acc, name="g_acc"), _dev(g_n_extra, name="g_n_extra"),
+        _dev(sdf, name="sdf_state"), _dev(nab, name="nabla_state"), _dev(h7, name="h7_state"), float(R_bg), float(alpha), float(beta),
+        int(bool(white_bkgd)), float(w_eikonal), int(eik_group_rays or 0), int(bool(train_radiance)), _dev(raw, name="raw"), ws.data_ptr(),
+        ws.numel(), _stream()), "nerfart_volsdf_render_bwd")
+
+
+def neus_render_bwd(surf_blob, rad_blob, view_tiles: int, multires: int, rays_o, rays_d, d_all, g_rgb, raw, *, s: float, white_bkgd: bool = False,
+                    w_eikonal: float = 0.0, eik_group_rays: int = 0, train_radiance: bool = False, g_acc=None, state=None):
+    """The same for NeuS (neus.py:520-576): state = (sdf [R P], nabla [R P, 3]) at the samples or None."""
+    R, P = d_all.shape
+    sdf, nab = state if state is not None else (None, None)
+    nb = int(lib.nerfart_neus_render_bwd_workspace_bytes(R, P, int(state is not None)))
+    ws = _workspace(nb, d_all.device)
+    _check(lib.nerfart_neus_render_bwd(
+        _dev(surf_blob), _dev(rad_blob), int(view_tiles), int(multires), _dev(rays_o, name="rays_o"), _dev(rays_d, name="rays_d"), R, P,
+        _dev(d_all, name="d_all"), _dev(g_rgb, name="g_rgb"), _dev(g_acc, name="g_acc"), _dev(sdf, name="sdf_state"), _dev(nab, name="nabla_state"),
+        float(s), int(bool(white_bkgd)), float(w_eikonal), int(eik_group_rays or 0), int(bool(train_radiance)), _dev(raw, name="raw"),
+        ws.data_ptr(), ws.numel(), _stream()), "nerfart_neus_render_bwd")
+
+
+def sdf_param_bwd(surf_blob, multires: int, pts, nbar, raw, sbar=None, hbar7=None):
+    """Parameter gradients of sbar . sdf + hbar7 . h7 + nbar . grad_x sdf at pts [M, 3], accumulated into `raw`."""
+    M = pts.shape[0]
+    nb = int(lib.nerfart_sdf_param_bwd_workspace_bytes(M))
+    ws = _workspace(nb, pts.device)
+    _check(lib.nerfart_sdf_param_bwd(_dev(surf_blob), int(multires), _dev(pts, name="pts"), M, _dev(sbar, name="sbar"), _dev(hbar7, name="hbar7"),
+                                     _dev(nbar, name="nbar"), _dev(raw, name="raw"), ws.data_ptr(), ws.numel(), _stream()), "nerfart_sdf_param_bwd")
+
+
+def radiance_param_bwd(rad_blob, view_tiles: int, pts, view, nabla, h7, g_rgb, raw, train_radiance: bool = True):
+    """(rgb [M,3], g_h7 [M,256], g_n [M,3]); the radiance net's (and the geometry-feature rows') gradients accumulated into `raw`."""
+    M = pts.shape[0]
+    dev = pts.device
+    rgb = torch.empty(M, 3, dtype=torch.float32, device=dev)
+    g_h7 = torch.empty(M, 256, dtype=torch.float32, device=dev)
+    g_n = torch.empty(M, 3, dtype=torch.float32, device=dev)
+    nb = int(lib.nerfart_radiance_param_bwd_workspace_bytes(M))
+    ws = _workspace(nb, dev)
+    _check(lib.nerfart_radiance_param_bwd(_dev(rad_blob), int(view_tiles), _dev(pts, name="pts"), _dev(view, name="view"), _dev(nabla, name="nabla"),
+                                          _dev(h7, name="h7"), M, _dev(g_rgb, name="g_rgb"), _dev(rgb), _dev(g_h7), _dev(g_n), int(bool(train_radiance)),
+                                          _dev(raw, name="raw"), ws.data_ptr(), ws.numel(), _stream()), "nerfart_radiance_param_bwd")
+    return rgb, g_h7, g_n
+
+
+def folded_grads_layout(multires: int, multires_view: int):
+    """(offsets [29], total): float offsets of (dW_l, db_l) for the SDF net's layers 0..8, then the radiance net's 0..4."""
+    offs = (C.c_longlong * 29)()
+    total = int(lib.nerfart_folded_grads_layout(int(multires), int(multires_view), offs))
+    return [int(o) for o in offs], total
+
+
+def fold_weight_grads(raw, multires: int, multires_view: int):
+    """raw -> (folded [total] fp32, offsets): gradients of the folded weights / biases in the reference's feature order."""
+    offs, total = folded_grads_layout(multires, multires_view)
+    folded = torch.empty(total, dtype=torch.float32, device=raw.device)
+    _check(lib.nerfart_fold_weight_grads(_dev(raw, name="raw"), int(multires), int(multires_view), _dev(folded), _stream()), "nerfart_fold_weight_grads")
+    return folded, offs
+
+
+def weight_norm_bwd(dW, weight_v, weight_g):
+    """(g_weight_v [out, in], g_weight_g [out, 1]) of nn.utils.weight_norm for d loss / d W = dW [out, in]."""
+    out_f, in_f = weight_v.shape
+    g_v = torch.empty_like(weight_v)
+    g_g = torch.empty_like(weight_g)
+    _check(lib.nerfart_weight_norm_bwd(_dev(dW, name="dW"), _dev(weight_v, name="weight_v"), _dev(weight_g, name="weight_g"), out_f, in_f, _dev(g_v),
+                                       _dev(g_g), 0, _stream()), "nerfart_weight_norm_bwd")
+    return g_v, g_g
 
 
 def volsdf_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, near, far, R_bg, alpha, beta, eps=0.1,

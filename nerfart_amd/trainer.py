@@ -147,16 +147,17 @@ class Trainer(nn.Module):
         kept, rgbs = [], []
         for i in range(0, o.shape[0], big):
             oi, di = o[i:i + big], d_raw[i:i + big]
-            dn = F.normalize(di, dim=-1)
-            depths = self._samples(oi, dn, di, rk).contiguous()
-            R = oi.shape[0]
-            pts, v = hip.ray_points(oi, dn, depths)                       # the same kernel gives pass 2 the same points
-            sdf, nab, h7 = hip.sdf_nabla_fwd(surf_blob, pts, m.obj_bounding_radius, precision=m.precision_id)
-            rgb_pt = hip.radiance_fwd(rad_blob, m.view_tiles, pts, v, nab, h7, precision=m.precision_id)
-            rgb, _, _ = hip.volsdf_composite(depths, sdf.reshape(R, P), rgb_pt.reshape(R, P, 3), ab[0], ab[1], white)
-            for j in range(0, R, step):                                   # pass 2's launch groups: views, released group by group
-                kept.append((depths[j:j + step], sdf[j * P:(j + step) * P], nab[j * P:(j + step) * P], h7[j * P:(j + step) * P]))
-            rgbs.append(rgb)
+            dn = hip.normalize_dirs(di)                                   # the kernel nerfart_volsdf_render_bwd normalises with: same points
+            depths = self._samples(oi, dn, di, rk).contiguous()           # one set of sampler launches for pass1_groups launch groups
+            for j in range(0, oi.shape[0], step):                         # pass 2's launch groups: their OWN tensors, freed group by group
+                dj = depths[j:j + step].contiguous()
+                Rj = dj.shape[0]
+                pts, v = hip.ray_points(oi[j:j + step], dn[j:j + step], dj)
+                sdf, nab, h7 = hip.sdf_nabla_fwd(surf_blob, pts, m.obj_bounding_radius, precision=m.precision_id)
+                rgb_pt = hip.radiance_fwd(rad_blob, m.view_tiles, pts, v, nab, h7, precision=m.precision_id)
+                rgb, _, _ = hip.volsdf_composite(dj, sdf.reshape(Rj, P), rgb_pt.reshape(Rj, P, 3), ab[0], ab[1], white)
+                kept.append((dj, sdf, nab, h7))
+                rgbs.append(rgb)
         self._kept = kept
         return torch.cat(rgbs, 0) if rgbs else torch.zeros(0, 3, device=o.device)
 
@@ -193,7 +194,6 @@ class Trainer(nn.Module):
                 bounds = [(i, min(i + step, N)) for i in range(0, N, step)]
             for gi, (i0, i1) in enumerate(bounds):
                 o, d_raw, g = o_all[i0:i1], d_all_[i0:i1], g_all[i0:i1]
-                dn = F.normalize(d_raw, dim=-1)
                 state = None
                 if kept is not None:
                     depths, state = kept[gi][0], kept[gi][1:]
@@ -202,12 +202,12 @@ class Trainer(nn.Module):
                     depths = depths_all[i0:i1].contiguous()
                 else:
                     with torch.no_grad():
-                        depths = self._samples(o, dn, d_raw, render_kwargs)
+                        depths = self._samples(o, hip.normalize_dirs(d_raw), d_raw, render_kwargs)
                 if self.is_neus:
-                    eik = autodiff.neus_backward_samples_native(self.model, o, dn, depths, g, self.w_eikonal, self.use_eikonal, white,
+                    eik = autodiff.neus_backward_samples_native(self.model, o, d_raw, depths, g, self.w_eikonal, self.use_eikonal, white,
                                                                 s_val=s_val, accum=accum, eik_group_rays=self.pass2_rays, state=state)
                 else:
-                    eik = autodiff.volsdf_backward_samples_native(self.model, o, dn, depths, g, self.w_eikonal, self.use_eikonal, white,
+                    eik = autodiff.volsdf_backward_samples_native(self.model, o, d_raw, depths, g, self.w_eikonal, self.use_eikonal, white,
                                                                   ab=ab, accum=accum, state=state, eik_group_rays=self.pass2_rays)
                 eik_sum = eik_sum + eik
                 n += -(-(i1 - i0) // self.pass2_rays)
@@ -291,13 +291,11 @@ class Trainer(nn.Module):
             accum = autodiff.GradAccumulator()
             for i in range(0, N, self.pass2_rays):
                 sl = slice(i, i + self.pass2_rays)
-                autodiff.volsdf_backward_samples_native(m, o[sl], dn[sl], depths[sl].contiguous(), g_rgb[sl], use_eikonal=False,
+                autodiff.volsdf_backward_samples_native(m, o[sl], d[sl], depths[sl].contiguous(), g_rgb[sl], use_eikonal=False,
                                                         white_bkgd=kw.get("white_bkgd", False), ab=ab, nbar_extra=nbar_extra[sl],
                                                         accum=accum)
             with torch.no_grad():
-                pe = eikonal_points.reshape(-1, 3).float().contiguous()
-                accum.add("surf", autodiff.surface_weight_grads_raw(m, pe, torch.zeros(pe.shape[0], device=pe.device),
-                                                                    torch.zeros(pe.shape[0], 256, device=pe.device), g_eik))
+                autodiff.surface_param_backward(m, eikonal_points.reshape(-1, 3).float().contiguous(), g_eik.contiguous(), accum=accum)
             accum.flush(m)
         else:
             for i in range(0, N, self.pass2_rays):
@@ -348,7 +346,7 @@ class Trainer(nn.Module):
         if self.native:
             if N * P > (1 << 21):
                 raise ValueError("reconstruction_step (NeuS): at most 2^21 sample points per step (the eikonal mean spans the batch)")
-            autodiff.neus_backward_samples_native(m, o, dn, depths, g_rgb, w_eikonal, True, white, g_acc=g_acc)
+            autodiff.neus_backward_samples_native(m, o, d, depths, g_rgb, w_eikonal, True, white, g_acc=g_acc)
         else:
             out = autodiff.neus_render_samples(m, o, dn, depths, white_bkgd=white, calc_normal=False)
             nn_g = out["implicit_nablas"].reshape(-1, 3).norm(dim=-1)

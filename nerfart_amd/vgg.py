@@ -143,7 +143,7 @@ class _VGGL1(torch.autograd.Function):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         loss = torch.empty(1, dtype=torch.float32, device=x.device)
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        rc = hip.lib.nerfart_vgg16_l1_fwd(C.c_void_p(blob.data_ptr()), C.c_void_p(img2.data_ptr()), H, W, C.c_void_p(loss.data_ptr()), int(keep),
+        rc = hip.lib.nerfart_vgg16_l1_fwd(C.c_void_p(blob.data_ptr()), blob.numel() * blob.element_size(), C.c_void_p(img2.data_ptr()), H, W, C.c_void_p(loss.data_ptr()), int(keep),
                                           C.c_void_p(ws.data_ptr()), nbytes, st)
         if rc != 0:
             raise RuntimeError("nerfart_vgg16_l1_fwd: " + hip.lib.nerfart_last_error().decode())
@@ -160,7 +160,7 @@ class _VGGL1(torch.autograd.Function):
         up = g.detach().float().reshape(1).contiguous()
         gi = torch.empty(1, 3, H, W, dtype=torch.float32, device=up.device)
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        rc = hip.lib.nerfart_vgg16_l1_bwd(C.c_void_p(ctx.blob.data_ptr()), H, W, C.c_void_p(up.data_ptr()), C.c_void_p(gi.data_ptr()),
+        rc = hip.lib.nerfart_vgg16_l1_bwd(C.c_void_p(ctx.blob.data_ptr()), ctx.blob.numel() * ctx.blob.element_size(), H, W, C.c_void_p(up.data_ptr()), C.c_void_p(gi.data_ptr()),
                                           C.c_void_p(ctx.ws.data_ptr()), ctx.ws.numel(), st)
         if rc != 0:
             raise RuntimeError("nerfart_vgg16_l1_bwd: " + hip.lib.nerfart_last_error().decode())

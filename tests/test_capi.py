@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(hip.lib, s), f"{s} declared in include/nerfart_hip.h but not exported by {hip.LIB_PATH}"
     assert set(hip._SIGS) == set(syms), "ctypes signature table and header disagree"
-    assert hip.ABI_VERSION == 1
+    assert hip.ABI_VERSION == 2
 
 
 def test_library_is_gfx950_code_object():
@@ -67,9 +67,9 @@ def test_new_entry_points_validate_their_arguments_without_a_gpu():
     def err():
         return lib.nerfart_last_error().decode()
     assert lib.nerfart_gemm_f16_nt(null, null, 65, 64, 64, null, null) != 0 and "multiples of 64" in err()
-    assert lib.nerfart_vgg16_l1_fwd(null, null, 100, 100, null, 0, null, 0, null) != 0 and "H and W" in err()
-    assert lib.nerfart_vgg16_l1_fwd(null, null, 224, 224, null, 0, null, 0, null) != 0 and "workspace" in err()
-    assert lib.nerfart_clip_vitb32_image_fwd(null, null, 4, null, 1, null, 0, null) != 0 and "null" in err()
+    assert lib.nerfart_vgg16_l1_fwd(null, 0, null, 100, 100, null, 0, null, 0, null) != 0 and "H and W" in err()
+    assert lib.nerfart_vgg16_l1_fwd(null, 0, null, 224, 224, null, 0, null, 0, null) != 0 and "workspace" in err()
+    assert lib.nerfart_clip_vitb32_image_fwd(null, 0, null, 4, null, 1, null, 0, null) != 0 and "null" in err()
     assert lib.nerfart_clip_vitb32_workspace_bytes(0, 1) == 0
     assert lib.nerfart_clip_vitb32_workspace_bytes(16, 1) > 12 * 16 * 50 * 768 * 4
     assert lib.nerfart_resample_fwd(null, 2, 3, 8, 8, 0, 0, 8, 8, 4, 4, 1, null, null, null, null, 3, 4, 4, null) != 0 and "n_src" in err()
@@ -112,3 +112,15 @@ def test_ctypes_signatures_have_the_headers_argument_counts_and_kinds():
                 assert t is C.c_float, (name, p, t)
             elif p.startswith("int") or p.startswith("unsigned"):
                 assert t is C.c_int, (name, p, t)
+
+
+def test_render_bwd_entry_points_validate_their_arguments_without_a_gpu():
+    from nerfart_amd import hip
+    lib, null = hip.lib, None
+    assert lib.nerfart_volsdf_render_bwd(null, null, 1, 6, null, null, 4, 192, null, null, null, null, null, null, null, 3.0, 100.0, 0.01, 0, 0.1, 0, 1,
+                                         null, null, 0, null) != 0 and b"null" in lib.nerfart_last_error()
+    assert lib.nerfart_volsdf_render_bwd(null, null, 1, 6, null, null, 20000, 192, null, null, null, null, null, null, null, 3.0, 100.0, 0.01, 0, 0.1, 0, 1,
+                                         null, null, 0, null) != 0 and b"2^21" in lib.nerfart_last_error()
+    assert lib.nerfart_neus_render_bwd(null, null, 2, 6, null, null, 4, 128, null, null, null, null, null, 20.0, 0, 0.1, 0, 0, null, null, 0, null) != 0
+    assert b"view_tiles" in lib.nerfart_last_error()
+    assert lib.nerfart_volsdf_render_bwd_workspace_bytes(1200, 192, 1) < lib.nerfart_volsdf_render_bwd_workspace_bytes(1200, 192, 0)
