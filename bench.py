@@ -209,24 +209,57 @@ def main():
                                    "vs_ref_3090": round(H * W / t32 / 6480.0, 2)}
         secondary["bf16x3_vs_fp32_pixels"] = pix
         del m32, f32
-        # the other single-GPU configurations of BASELINE.json, one warm-up + one timed frame each (bench lines of their own: tools/)
-        def one_frame(fn, Hh, Ww, **extra):
-            c2w_, K_ = scene.camera(Hh, Ww, angle=angles[1])
-            oo, dd, _ = rend_util.get_rays(c2w_[None].to(dev), K_[None].to(dev), Hh, Ww)
-            fn(oo, dd, calc_normal=True, detailed_output=False, **extra)
+        # the other single-GPU configurations of BASELINE.json: one warm-up frame, then N_SEC timed frames on N_SEC views of the orbit
+        # (bench lines of their own: tools/bench_neus.py, tools/bench_train.py)
+        N_SEC = 3
+
+        def frames(fn, Hh, Ww, **extra):
+            views = []
+            for s_ in range(N_SEC + 1):
+                c2w_, K_ = scene.camera(Hh, Ww, angle=angles[(11 * s_ + 1) % len(angles)])
+                views.append(rend_util.get_rays(c2w_[None].to(dev), K_[None].to(dev), Hh, Ww)[:2])
+            fn(*views[0], calc_normal=True, detailed_output=False, **extra)
             torch.cuda.synchronize()
             t_ = time.perf_counter()
-            fn(oo, dd, calc_normal=True, detailed_output=False, **extra)
+            for oo, dd in views[1:]:
+                fn(oo, dd, calc_normal=True, detailed_output=False, **extra)
             torch.cuda.synchronize()
-            return time.perf_counter() - t_
-        t5 = one_frame(render_fn, 960, 540, require_nablas=True, **kw)
-        secondary["cfg5_frame_960x540"] = {"value": round(960 * 540 / t5, 1), "unit": "rays/s", "ms_per_step": round(t5 * 1e3, 2), "steps": 1,
+            return (time.perf_counter() - t_) / N_SEC
+        t5 = frames(render_fn, 960, 540, require_nablas=True, **kw)
+        secondary["cfg5_frame_960x540"] = {"value": round(960 * 540 / t5, 1), "unit": "rays/s", "ms_per_step": round(t5 * 1e3, 2), "steps": N_SEC,
                                            "what": "configs[4] frame size (518,400 rays, VolSDF 128 + 64 spp) on ONE GPU"}
         mn, rkn, fn_n = scene.build_model("NeuS", seed=0, beta=None, device=dev, precision=args.precision)
-        t4 = one_frame(fn_n, H, W, **{k: v for k, v in rkn.items() if k != "rayschunk"})
-        secondary["cfg4_neus_480x270"] = {"value": round(H * W / t4, 1), "unit": "rays/s", "ms_per_step": round(t4 * 1e3, 2), "steps": 1,
-                                          "what": "configs[3]: neus_fangzhou_vangogh.yaml dims, 64 + 64 spp, 704.8 MFLOP/ray algorithmic"}
+        t4 = frames(fn_n, H, W, **{k: v for k, v in rkn.items() if k != "rayschunk"})
+        F_NEUS = 128 * F_SDF + 128 * (F_SDF + F_NABLA) + 127 * (F_SDF + F_NABLA + 542720)          # 704.8 MFLOP per ray
+        secondary["cfg4_neus_480x270"] = {"value": round(H * W / t4, 1), "unit": "rays/s", "ms_per_step": round(t4 * 1e3, 2), "steps": N_SEC,
+                                          "end_to_end_tflops": round(H * W * F_NEUS / t4 / 1e12, 1),
+                                          "frac_of_bf16_peak_end_to_end": round(H * W * F_NEUS / t4 / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                                          "what": "configs[3]: neus_fangzhou_vangogh.yaml dims, 64 + 64 spp, 704.8 MFLOP/ray algorithmic; "
+                                                  "kernel-level evidence: profiles/r05*_neus_kernel_stats.txt"}
         del mn, fn_n
+        # BASELINE configs[2] (SURVEY cfg 3): the fine-tune step - HIP pass 1 with kept state, CLIP + VGG style losses on the hand-written
+        # kernels, native pass 2 (nerfart_volsdf_render_bwd per launch group), Adam.  One warm-up + N_SEC timed steps; the dominant
+        # pass-2 kernel (k_wgrad<256>, HBM bound) priced from the library's own event records of these steps.
+        from nerfart_amd import bench_util
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        ctx3 = bench_util.finetune_setup(dev, H, W, beta=args.beta, angle=angles[2])
+        m3, loss3, eik3, prof3 = bench_util.finetune_steps(ctx3, N_SEC, warmup=1, profile=True)
+        wg_ms, wg_n, wg_bytes = prof3["k_wgrad256"]
+        secondary["cfg3_finetune_step"] = {
+            "value": round(sum(m3), 4), "unit": "s/step", "higher_is_better": False, "steps": N_SEC, "rays_per_s": round(H * W / sum(m3), 1),
+            "pass1_render_s": round(m3[0], 4), "style_losses_fwd_bwd_s": round(m3[1], 4), "pass2_render_bwd_s": round(m3[2], 4), "adam_s": round(m3[3], 4),
+            "loss": round(loss3, 5), "eikonal": round(float(eik3), 7), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+            "roofline_pass2_dominant": None if wg_n == 0 else {
+                "bound": "hbm", "kernel": "k_wgrad<256>", "achieved": round(wg_bytes / (wg_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(wg_bytes / (wg_ms * 1e-3) / 8e12, 4), "launches_per_step": int(wg_n // N_SEC), "ms_per_step": round(wg_ms / N_SEC, 2),
+                "algorithmic_GB_per_step": round(wg_bytes / N_SEC / 1e9, 1),
+                "what": "weight-gradient reductions over the point-major bf16 dumps: both operands read once (DESIGN.md 4.3)"},
+            "mlp_kernel_ms_per_step": {k: round(v[0] / N_SEC, 2) for k, v in prof3.items()},
+            "what": "configs[2]: volsdf_fangzhou_vangogh.yaml train step at 480x270 (render + CLIP directional / contrastive / PatchNCE + VGG "
+                    "perceptual, backward, Adam), seeded random-weight CLIP ViT-B/32 + VGG16, perturb=False, split-bf16 kernels"}
+        del ctx3
+        torch.cuda.empty_cache()
 
     # algorithmic work of one of this rank's frames (uses the iter_usage the renderer reports)
     _, ex = step(args.warmup, detailed=True)
@@ -291,7 +324,7 @@ def main():
                 roofline["traffic"] = int(kk["hbm_bytes_corrected_per_launch"]) if fresh else None
             except Exception:
                 pass
-    kernels_ms = {k: round(v[0] / args.steps, 3) for k, v in prof.items()}
+    kernels_ms = {k: round(v[0] / args.steps, 3) for k, v in prof.items() if k != "k_wgrad256"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -342,6 +375,24 @@ def main():
                   "max_abs_rgb_all": float(f"{float(e_pix.max()):.3e}"), "rays_over_1e-3": int((e_pix > 1e-3).sum()),
                   "psnr_db": round(float(-10 * torch.log10(((g_rgb[0].cpu() - ref["rgb"]) ** 2).mean().clamp_min(1e-20))), 1),
                   "max_abs_depth_same_rounds": float(f"{float((g_depth[0].cpu() - ref['depth_volume'])[same].abs().max()):.3e}")}
+        # the exact-fp32 mode against the oracle on the SAME rays: says whether a ray past 1e-3 is the split-bf16 arithmetic or
+        # Algorithm 1's own discontinuities (a ray that flips under any change of rounding; tools/fp32_outlier.py)
+        if args.precision == "bf16x3" and not args.no_secondary:
+            m32, _, f32 = scene.build_model("VolSDF", seed=0, beta=args.beta, device=dev, precision="fp32")
+            with torch.no_grad():
+                r32, d32, x32 = f32(o[:, sel], d[:, sel], require_nablas=True, calc_normal=True, detailed_output=True, **kw)
+            same32 = (x32["iter_usage"][0].cpu() == ref["iter_usage"])
+            e32 = (r32[0].cpu() - ref["rgb"]).abs().max(dim=-1).values
+            over16 = (e_pix > 1e-3).nonzero().flatten().tolist()
+            secondary.setdefault("fp32_exact", {})["parity_vs_oracle_same_rays"] = {
+                "rays": int(sel.numel()), "same_upsampling_rounds_frac": round(float(same32.float().mean()), 5),
+                "rays_over_1e-3": int((e32 > 1e-3).sum()), "max_abs_rgb_all": float(f"{float(e32.max()):.3e}"),
+                "max_abs_rgb_same_rounds": float(f"{float(e32[same32].max()):.3e}"),
+                "psnr_db": round(float(-10 * torch.log10(((r32[0].cpu() - ref["rgb"]) ** 2).mean().clamp_min(1e-20))), 1),
+                "bf16x3_rays_over_1e-3": [{"ray": int(sel[i]), "bf16x3_err": float(f"{float(e_pix[i]):.3e}"), "fp32_err": float(f"{float(e32[i]):.3e}"),
+                                           "rounds_oracle_bf16x3_fp32": [float(ref["iter_usage"][i]), float(g_ex["iter_usage"][0, i]), float(x32["iter_usage"][0, i])]}
+                                          for i in over16[:16]]}
+            del m32, f32, r32, d32, x32
         del g_rgb, g_depth, g_ex
         cpu = {"value": round(n_cpu / tc, 1), "unit": "rays/s", "cores": int(cores), "kind": "port", "cpu_model": cpu_model,
                "parity_of_this_run_on_the_sample": parity,
@@ -359,18 +410,24 @@ def main():
         o1, d1, _ = rend_util.get_rays(c2w1[None].to(dev), K1[None].to(dev), H1, W1)
         with torch.no_grad():
             t1 = time.perf_counter()
-            orender.volsdf_render(sd, o1[0].cpu(), d1[0].cpu(), near=0.0, far=6.0, obj_bounding_radius=3.0, N_samples=32,
-                                  N_importance=N_IMPORTANCE, max_upsample_steps=kw["max_upsample_steps"], chunk=4096)
+            ref1 = orender.volsdf_render(sd, o1[0].cpu(), d1[0].cpu(), near=0.0, far=6.0, obj_bounding_radius=3.0, N_samples=32,
+                                         N_importance=N_IMPORTANCE, max_upsample_steps=kw["max_upsample_steps"], chunk=4096)
             tc1 = time.perf_counter() - t1
         kw1 = dict(kw, N_samples=32)
         render_fn(o1, d1, require_nablas=True, calc_normal=True, detailed_output=False, **kw1)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        render_fn(o1, d1, require_nablas=True, calc_normal=True, detailed_output=False, **kw1)
+        rgb1, _, ex1 = render_fn(o1, d1, require_nablas=True, calc_normal=True, detailed_output=True, **kw1)
         torch.cuda.synchronize()
         tg1 = time.perf_counter() - t1
+        e1 = (rgb1[0].cpu() - ref1["rgb"]).abs().max(dim=-1).values
+        same1 = ex1["iter_usage"][0].cpu() == ref1["iter_usage"]
         cpu["cfg1_64x64_32spp_in_full"] = {"value": round(H1 * W1 / tc1, 1), "unit": "rays/s", "cores": int(cores), "seconds": round(tc1, 2),
                                            "hip_same_rays": {"value": round(H1 * W1 / tg1, 1), "unit": "rays/s", "ms": round(tg1 * 1e3, 2)},
+                                           "parity_all_4096_rays": {"same_upsampling_rounds_frac": round(float(same1.float().mean()), 5),
+                                                                    "rays_over_1e-3": int((e1 > 1e-3).sum()), "max_abs_rgb_all": float(f"{float(e1.max()):.3e}"),
+                                                                    "max_abs_rgb_same_rounds": float(f"{float(e1[same1].max()):.3e}"),
+                                                                    "psnr_db": round(float(-10 * torch.log10(((rgb1[0].cpu() - ref1["rgb"]) ** 2).mean().clamp_min(1e-20))), 1)},
                                            "reference_in_survey_container": {"value": 278.0, "unit": "rays/s", "cores": 8}}
 
     if rank == 0:

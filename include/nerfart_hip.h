@@ -41,9 +41,10 @@ extern "C" {
 int nerfart_abi_version(void);
 const char* nerfart_last_error(void);
 
-/* Optional launch profiling (bench.py): between begin and end every chained-MLP launch is bracketed by HIP
- * events on its own stream; end() returns per kernel class c = 0 k_sdf_only, 1 k_sdf_nabla, 2 k_radiance the
- * summed elapsed ms, launch count and points processed (host arrays of 3). */
+/* Optional launch profiling (bench.py): between begin and end every chained-MLP launch and every 256-column weight-gradient
+ * launch is bracketed by HIP events on its own stream; end() returns per kernel class c = 0 k_sdf_only, 1 k_sdf_nabla / k_sdf_grad,
+ * 2 k_radiance (units = points processed), 3 k_wgrad<256> (units = algorithmic bytes: both bf16 operands read once) the summed
+ * elapsed ms, launch count and units (host arrays of 4). */
 int nerfart_profile_begin(void);
 int nerfart_profile_end(double* ms, long long* launches, long long* units);
 

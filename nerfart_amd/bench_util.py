@@ -1,0 +1,69 @@
+"""Timing harness of the fine-tune step (BASELINE configs[2] / SURVEY cfg 3) shared by bench.py (`secondary.cfg3_finetune_step`) and
+tools/bench_train.py: 480 x 270 rays, VolSDF dims, seeded random-weight CLIP ViT-B/32 + VGG16 (no checkpoint is on disk), perturb=False.
+
+    pass 1   Trainer.render_keep: the HIP renderer's stages, per-point state kept in HBM for pass 2
+    style    criteria.StyleLoss: CLIP directional + contrastive + PatchNCE heads and the VGG16 perceptual term, forward + backward to
+             d loss / d rgb, all on the hand-written kernels (text features cached: constants of a run)
+    pass 2   Trainer.backward_patches: nerfart_volsdf_render_bwd per launch group of 4 reference patches, one fold per step
+    adam     torch.optim.Adam.step (the reference's optimiser, models/base.py:486-507)
+"""
+import time
+
+import torch
+
+
+def finetune_setup(dev, H: int, W: int, beta: float = 0.01, with_vgg: bool = True, pass2_rays: int = 1200, patches_per_launch: int = 4,
+                   angle: float = 0.0):
+    from . import scene, rend_util, criteria, clip_vit, vgg
+    from .trainer import Trainer
+    model, rk, render_fn = scene.build_model("VolSDF", seed=0, beta=beta, device=dev, precision="bf16x3")
+    c2w, K = scene.camera(H, W, angle=angle)
+    o, d, _ = rend_util.get_rays(c2w[None].to(dev), K[None].to(dev), H, W)
+    feats = criteria.ClipFeatures(model=clip_vit.build_clip(dev, seed=0), device=dev, synthetic=True)
+    style = criteria.StyleLoss(feats, (H, W), neg_texts=[f"negative prompt {i}" for i in range(16)],
+                               perceptual=vgg.VGGPerceptualLoss().to(dev) if with_vgg else None)
+    with torch.no_grad():
+        target, _, _ = render_fn(o, d, detailed_output=False, require_nablas=True, calc_normal=True, **{k: v for k, v in rk.items() if k != "rayschunk"})
+    # the "photo" the render is compared with: the render itself, low-pass perturbed (pred == gt would make the directional loss 0/0,
+    # as in the reference)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    noise = torch.nn.functional.interpolate(torch.randn(1, 3, H // 8, W // 8, generator=g), size=(H, W), mode="bicubic", align_corners=False)
+    target = (target.reshape(1, H, W, 3) + 0.1 * noise.permute(0, 2, 3, 1).to(dev)).clamp(0, 1).reshape(1, -1, 3)
+    tr = Trainer(model, pass2_rays=pass2_rays, patches_per_launch=patches_per_launch)
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-5)
+    return dict(model=model, rk=rk, render_fn=render_fn, o=o, d=d, style=style, target=target, trainer=tr, opt=opt, H=H, W=W)
+
+
+def finetune_steps(ctx, steps: int, warmup: int = 1, keep: bool = True, profile: bool = False):
+    """`warmup` untimed + `steps` timed fine-tune steps.  Returns (mean seconds of [pass 1, style, pass 2, adam], last loss, last
+    eikonal, launch-profile dict or None).  profile: nerfart_profile_begin / _end around the timed steps."""
+    from . import hip
+    tr, opt, o, d, rk, H, W = ctx["trainer"], ctx["opt"], ctx["o"], ctx["d"], ctx["rk"], ctx["H"], ctx["W"]
+    to_img = lambda t: t.reshape(1, H, W, 3).permute(0, 3, 1, 2)
+    times, loss, eik = [], None, None
+    for it in range(warmup + steps):
+        if profile and it == warmup:
+            torch.cuda.synchronize()
+            hip.profile_begin()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        if keep:
+            rgb, depths_all = tr.render_keep(o, d, **rk), None
+            kept, tr._kept = tr._kept, None
+        else:
+            rgb, depths_all = tr.render_image(ctx["render_fn"], o, d, want_depths=True, **rk)
+            kept = None
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        rgb = rgb.detach().reshape(1, -1, 3).requires_grad_(True)
+        loss = ctx["style"](to_img(rgb), to_img(ctx["target"].reshape(1, -1, 3)))
+        loss.backward()
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        opt.zero_grad()
+        eik = tr.backward_patches(o, d, rgb.grad.detach()[0], depths_all=depths_all, kept=kept, **rk)
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+        opt.step()
+        torch.cuda.synchronize(); t4 = time.perf_counter()
+        if it >= warmup:
+            times.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3))
+    prof = hip.profile_end() if profile else None
+    mean = [sum(x[i] for x in times) / len(times) for i in range(4)]
+    return mean, float(loss.detach()), eik, prof

@@ -41,13 +41,14 @@ int nerfart_profile_begin(void) {
     nerfart::g_prof_on = true;
     return 0;
 }
-// ms[c], launches[c], units[c] for c = 0 (k_sdf_only), 1 (k_sdf_nabla), 2 (k_radiance); units = points.
+// ms[c], launches[c], units[c] for c = 0 (k_sdf_only), 1 (k_sdf_nabla / k_sdf_grad), 2 (k_radiance): units = points;
+// c = 3 (k_wgrad<256>): units = algorithmic bytes (both operands once).  Host arrays of 4.
 int nerfart_profile_end(double* ms, long long* launches, long long* units) {
     nerfart::g_prof_on = false;
-    for (int c = 0; c < 3; ++c) { ms[c] = 0.0; launches[c] = 0; units[c] = 0; }
+    for (int c = 0; c < 4; ++c) { ms[c] = 0.0; launches[c] = 0; units[c] = 0; }
     for (auto& r : nerfart::g_prof) {
         float t = 0.f;
-        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess && r.cls >= 0 && r.cls < 3) {
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess && r.cls >= 0 && r.cls < 4) {
             ms[r.cls] += t; launches[r.cls] += 1; units[r.cls] += r.units;
         }
         (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);

@@ -272,7 +272,11 @@ int nerfart_wgrad_bf16(const void* Z, long long z_stride, const void* A, long lo
     const size_t lds = (size_t)2 * KT * 512 + (size_t)2 * KT * a_cols * 2;
     if (a_cols == 256) {
         NERFART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        // launch profiling class 3 (bench.py's cfg 3 roofline): units = the ALGORITHMIC bytes of the launch, both bf16 operands read once
+        void* ph = nullptr;
+        if (profile_enabled()) profile_open(3, (long long)n_mats * rows * (256 + 256) * 2, st, &ph);
         hipLaunchKernelGGL(k_wgrad<256>, dim3(g.n_split, n_mats), dim3(THREADS), lds, st, g);
+        profile_close(ph, st);
     } else {
         NERFART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_wgrad<64>, dim3(g.n_split, n_mats), dim3(THREADS), lds, st, g);

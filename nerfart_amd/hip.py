@@ -159,10 +159,11 @@ def profile_begin():
 
 
 def profile_end():
-    """-> {kernel: (ms, launches, points)} for the chained-MLP kernels launched since profile_begin()."""
-    ms = (C.c_double * 3)(); ln = (C.c_longlong * 3)(); un = (C.c_longlong * 3)()
+    """-> {kernel: (ms, launches, units)} for the chained-MLP kernels (units = points) and k_wgrad<256> (units = algorithmic bytes)
+    launched since profile_begin()."""
+    ms = (C.c_double * 4)(); ln = (C.c_longlong * 4)(); un = (C.c_longlong * 4)()
     lib.nerfart_profile_end(ms, ln, un)
-    return {k: (ms[i], ln[i], un[i]) for i, k in enumerate(("k_sdf_only", "k_sdf_nabla", "k_radiance"))}
+    return {k: (ms[i], ln[i], un[i]) for i, k in enumerate(("k_sdf_only", "k_sdf_nabla", "k_radiance", "k_wgrad256"))}
 
 
 # ---- point queries -----------------------------------------------------------------------

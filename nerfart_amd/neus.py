@@ -102,4 +102,6 @@ def get_model(args, render_target=None):
     # neus.py:455-456: the radiance net is frozen when fine-tuning, trained otherwise
     trainer = Trainer(model, freeze_radiance=bool(t.get("is_finetune", False)))
     trainer.render_fn = renderer
+    if bool(t.get("is_finetune", False)) and "finetune" in args:
+        trainer.configure_style_loss(args, render_target if render_target is not None else [960, 540])     # neus.py:432-446
     return model, trainer, render_kwargs_train, render_kwargs_test, renderer

@@ -115,7 +115,7 @@ def surface_render(rays_o, rays_d, model, calc_normal=True, rayschunk=8192, netc
         N = o.shape[-2]
         step = max(1, min(int(rayschunk) if rayschunk else N, ((1 << 31) - 1) // max(n_steps, 1)))
         parts = []
-        for s in range(0, N, step):
+        for s in range(0, max(N, 1), step):                             # N == 0 (an empty ray batch): one empty slice, the kernels' n <= 0 path
             oc, dc = o[..., s:s + step, :].contiguous(), dn[..., s:s + step, :].contiguous()
             cfg = {k: (v[..., s:s + step] if torch.is_tensor(v) and v.dim() >= 1 and v.shape[-1] == N else v) for k, v in ray_casting_cfgs.items()}
             if ray_casting_algo == "root_finding":

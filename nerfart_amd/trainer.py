@@ -15,6 +15,8 @@ pass 1's: reusing them is the consistent estimator; `Trainer(native=False)` re-s
 reference patches share one launch group (per-patch eikonal means kept); NeuS keeps `radiance_net` frozen exactly
 like neus.py:455-456.
 """
+import warnings
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -22,6 +24,9 @@ import torch.nn.functional as F
 from . import autodiff, hip
 from . import dist as nd
 from .nets import NeuS, VolSDF
+
+
+_WARNED_AUTOGRAD = False
 
 
 class Trainer(nn.Module):
@@ -33,15 +38,18 @@ class Trainer(nn.Module):
         self.model = model
         self.is_neus = isinstance(model, NeuS)
         self.w_eikonal, self.use_eikonal, self.pass2_rays = w_eikonal, use_eikonal, pass2_rays
-        # native: pass 2 entirely on the hand-written kernels + GEMMs (VolSDF, split-bf16 blobs); otherwise autograd over
-        # the per-sample networks with the native compositing / radiance kernels where available
-        # (None: decided by the model's precision at the time of the step - set_precision may be called after get_model)
+        # native (None = True): pass 2 on the ray-level C entry points (csrc/render_backward.hip).  They read split-bf16 blobs, so a
+        # training step on another precision is REFUSED (fp32-exact is an inference precision here) - checked when the step runs,
+        # because set_precision may be called after get_model.  native=False is the torch-autograd formulation over library GEMMs:
+        # the cross-check the native kernels are tested against, never chosen silently (it warns when it runs).
         self._native = native
+        self._style_cfg = None
         # native pass 2: this many of the reference's pass2_rays-ray patches share one set of kernel launches (the per-patch
         # eikonal means are kept); bounded by the kernels' 2^21 points per launch
         self.patches_per_launch = patches_per_launch
-        # render_keep (VolSDF): pass 1 runs this many of pass 2's launch groups per set of launches (the sampler's rounds each
-        # cost a host read; results are chunk-invariant bit for bit) and hands pass 2 per-group views of the kept state
+        # render_keep (VolSDF): pass 1 SAMPLES this many of pass 2's launch groups per set of sampler launches (its rounds each cost
+        # a host read; results are chunk-invariant bit for bit); the per-point state is then evaluated group by group into tensors
+        # of its own, which pass 2 releases as it consumes them (1 KiB per point: ~1 GB per 4 x 1200-ray group at P = 192)
         self.pass1_groups = max(1, pass1_groups)
         self._kept = None
         # neus.py:455-456: NeuS fine-tuning trains only the SDF net (and ln_s); pass freeze_radiance=False for the
@@ -52,16 +60,34 @@ class Trainer(nn.Module):
 
     @property
     def native(self) -> bool:
-        """Pass 2 on the hand-written kernels.  Those entry points (radiance_fwd_dump / radiance_bwd / sdf_fwd2 / sdf_bwd2 and
-        the state render_keep hands them) read split-bf16 blobs only: forcing native=True on another precision would feed them
-        an fp32-layout blob, so that combination is an error, checked every time the flag is read (set_precision may be
-        called after the trainer is built)."""
-        if self._native is None:
-            return self.model.precision == "bf16x3"
-        if self._native and self.model.precision != "bf16x3":
-            raise RuntimeError(f"Trainer(native=True) needs model.set_precision('bf16x3'); the model is at {self.model.precision!r} "
-                               "(use native=False / native=None for the autograd formulation)")
-        return self._native
+        """Pass 2 on the hand-written kernels (the default).  The backward entry points and the state render_keep hands them read
+        split-bf16 blobs only, so a model at another precision cannot train natively: that is an ERROR (no silent switch to library
+        GEMMs), raised every time the flag is read.  Trainer(native=False) selects the autograd cross-check explicitly."""
+        if self._native is False:
+            global _WARNED_AUTOGRAD
+            if not _WARNED_AUTOGRAD:
+                _WARNED_AUTOGRAD = True
+                warnings.warn("Trainer(native=False): pass 2 runs torch autograd over library GEMMs (the cross-check formulation), "
+                              "not the hand-written kernels")
+            return False
+        if self.model.precision != "bf16x3":
+            raise RuntimeError(f"training steps run on the split-bf16 kernels: call model.set_precision('bf16x3') (the model is at "
+                               f"{self.model.precision!r}; 'fp32' is an inference precision - nerfart_*_render_bwd reads bf16x3 blobs). "
+                               "Trainer(native=False) is the torch-autograd cross-check.")
+        return True
+
+    # ---- the losses of the fine-tune objective (the reference loads them in Trainer.__init__, volsdf.py:638-645) -----------------
+    def configure_style_loss(self, args, target_hw):
+        """Remember the config the style losses are built from; they are built on first use (a render-only run with an
+        `is_finetune: True` YAML never loads CLIP / VGG - the reference does)."""
+        self._style_cfg = (args, tuple(target_hw))
+
+    def _ensure_style_loss(self):
+        if getattr(self, "style_loss", None) is None and self._style_cfg is not None:
+            from . import criteria
+            args, hw = self._style_cfg
+            self.style_loss = criteria.build_style_loss(args, hw, device=next(self.model.parameters()).device)
+        return getattr(self, "style_loss", None)
 
     # ---- pass 1 ---------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -373,12 +399,13 @@ class Trainer(nn.Module):
           the native pass 2 is deferred into that backward call (`_DeferredBackward`): `losses` holds loss_img, loss_eikonal
           (loss_mask), total as tensors, and `total.backward()` accumulates the gradients.
 
-        Returns OrderedDict(losses=..., extras={'scalars': {...}, 'select_inds': ...}).  `render_fn` / `style_loss` default to
-        the attributes `self.render_fn` / `self.style_loss` the caller set (the reference builds its losses in __init__)."""
+        Returns OrderedDict(losses=..., extras={'scalars': {...}, 'select_inds': ...}).  `render_fn` defaults to `self.render_fn`;
+        `style_loss` to `self.style_loss`, which get_model configures from the YAML (built on first use: the reference builds its
+        losses in __init__, volsdf.py:638-645)."""
         from collections import OrderedDict
         from . import rend_util
         render_fn = render_fn if render_fn is not None else getattr(self, "render_fn", None)
-        style_loss = style_loss if style_loss is not None else getattr(self, "style_loss", None)
+        style_loss = style_loss if style_loss is not None else (self._ensure_style_loss() if bool(args.training.is_finetune) else None)
         if render_fn is None:
             raise ValueError("Trainer.forward: set trainer.render_fn (the render_fn get_model returned) or pass render_fn=")
         dev = next(self.model.parameters()).device
@@ -391,7 +418,8 @@ class Trainer(nn.Module):
         rk = {k: v for k, v in render_kwargs_train.items() if k not in ("H", "W")}
         if finetune:
             if style_loss is None:
-                raise ValueError("Trainer.forward (fine-tune): set trainer.style_loss (criteria.StyleLoss) or pass style_loss=")
+                raise ValueError("Trainer.forward (fine-tune): no style loss - get_model(args, [H, W]) configures it from the YAML when "
+                                 "training.is_finetune; otherwise set trainer.style_loss (criteria.StyleLoss) or pass style_loss=")
             self.w_eikonal, self.use_eikonal = args.finetune.w_eikonal, bool(args.finetune.use_eikonal)
             out = self.finetune_step(render_fn, rays_o, rays_d, target_rgb, H, style_loss, optimizer=optimizer, **rk)
             losses = torch.tensor(out["loss"], device=dev)

@@ -87,8 +87,9 @@ class SingleRenderer(nn.Module):
 def get_model(args, render_target=None):
     """(volsdf.py:943-994) args: the YAML config as an attribute dict (nerfart_amd/config.py).
     Returns (model, trainer, render_kwargs_train, render_kwargs_test, render_fn).  trainer = trainer.Trainer with
-    `render_fn` set; its `style_loss` (criteria.StyleLoss: needs the CLIP / VGG checkpoints and tokenizer) is the caller's to
-    set before fine-tuning - the reference loads them inside Trainer.__init__ (volsdf.py:638-645)."""
+    `render_fn` set and, when `training.is_finetune`, the style losses configured from the YAML as the reference's
+    Trainer.__init__ does (volsdf.py:638-645; criteria.build_style_loss - built at the first fine-tune step, so render.py with
+    such a YAML loads no CLIP / VGG)."""
     m, t = args.model, args.training
     model_config = {
         "use_nerfplusplus": m.setdefault("outside_scene", "builtin") == "nerf++",
@@ -126,4 +127,6 @@ def get_model(args, render_target=None):
     from .trainer import Trainer
     trainer = Trainer(model)
     trainer.render_fn = renderer
+    if bool(t.get("is_finetune", False)) and "finetune" in args:
+        trainer.configure_style_loss(args, render_target if render_target is not None else [960, 540])     # volsdf.py:634-635
     return model, trainer, render_kwargs_train, render_kwargs_test, renderer

@@ -53,3 +53,21 @@ def test_base_yaml_merges_nested_sections(tmp_path):
     assert c.expname == "mine" and c.training.lr == 5.0e-4 and c.training.num_iters == 100
     assert c.training.scheduler.type == "multistep" and c.training.scheduler.gamma == 0.1
     assert c.model.W == 256 and c.data.downscale == 2
+
+
+def test_get_model_configures_but_does_not_load_the_style_losses():
+    """An `is_finetune: True` YAML (volsdf_fangzhou_vangogh.yaml's flag): get_model hands the trainer the config its losses are built
+    from (volsdf.py:638-645) without touching CLIP / VGG - render.py with such a YAML must not need the checkpoints."""
+    from nerfart_amd import scene, frameworks
+    for fw in ("VolSDF", "NeuS"):
+        cfg = scene.synthetic_config(fw)
+        cfg.training.is_finetune = True
+        cfg.finetune = {"src_text": "photo", "target_text": "painting", "clip_checkpoint": "/nonexistent/ViT-B-32.pt"}
+        model, trainer, _, _, render_fn = frameworks.get_model(cfg, [480, 270])
+        assert trainer._style_cfg[1] == (480, 270) and getattr(trainer, "style_loss", None) is None
+        import pytest
+        with pytest.raises(FileNotFoundError, match="ViT-B-32"):
+            trainer._ensure_style_loss()
+        cfg.training.is_finetune = False
+        _, trainer2, _, _, _ = frameworks.get_model(cfg, [480, 270])
+        assert trainer2._style_cfg is None

@@ -104,3 +104,14 @@ def test_full_frame_surface_render_and_sdf_volume():
     ref_v = nets.surface_forward(sd, pts)[0].reshape(N, N, N)
     _close("sdf volume 64^3", vol, ref_v, 1e-4)
     assert (vol[N // 2, N // 2, N // 2] < 0) and (vol[0, 0, 0] > 0)                       # inside at the centre, outside at the corner
+
+
+@pytest.mark.parametrize("algo", ["root_finding", "sphere_tracing"])
+def test_surface_render_accepts_an_empty_ray_batch(algo):
+    """A rank (or a mask selection) with no rays: zero-sized outputs, as the kernels' n <= 0 path gives everywhere else."""
+    from nerfart_amd import scene, ray_casting as rc
+    model, _, _ = scene.build_model("VolSDF", seed=0, beta=0.01, device=DEV, precision="bf16x3")
+    o = torch.zeros(1, 0, 3, device=DEV)
+    cfgs = dict(near=0.0, far=6.0, N_steps=64, N_secant_steps=4) if algo == "root_finding" else dict(near=0.0, far=6.0, N_iters=10)
+    col, dep, ex = rc.surface_render(o, o.clone(), model, calc_normal=True, ray_casting_algo=algo, ray_casting_cfgs=cfgs)
+    assert col.shape == (1, 0, 3) and dep.shape == (1, 0) and ex["mask_surface"].shape == (1, 0) and ex["normals_surface"].shape == (1, 0, 3)

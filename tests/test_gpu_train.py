@@ -20,7 +20,12 @@ def test_pass2_gradients_match_reference_G11(golden, precision):
     model, rk, render_fn = scene.build_model("VolSDF", seed=0, beta=0.01, device=DEV, precision=precision)
     H, W = int(golden["G9_H"]), int(golden["G9_W"])
     o, d, _ = rend_util.get_rays(tt(golden["G9_c2w"])[None].to(DEV), tt(golden["G9_K"])[None].to(DEV), H, W)
-    tr = Trainer(model, w_eikonal=0.1, use_eikonal=True, pass2_rays=1200)
+    # bf16x3: the native pass 2 (the product path).  fp32: the torch-autograd cross-check, which must be asked for explicitly - the
+    # formulation every native kernel is compared with is itself held to the reference's gradients here
+    tr = Trainer(model, w_eikonal=0.1, use_eikonal=True, pass2_rays=1200, native=None if precision == "bf16x3" else False)
+    if precision == "fp32":
+        with pytest.raises(RuntimeError, match="bf16x3"):          # no silent switch of formulation: fp32 models do not train natively
+            Trainer(model, pass2_rays=1200).backward_patches(o[0, :4], d[0, :4], tt(golden["G11_gvec"]).to(DEV), **rk)
     model.zero_grad()
     tr.backward_patches(o[0, :4], d[0, :4], tt(golden["G11_gvec"]).to(DEV), **rk)
     for name, p in model.named_parameters():
@@ -461,6 +466,36 @@ def test_trainer_forward_with_the_reference_call_shape(tmp_path):
     gn = sum(float(p.grad.norm()) for p in model.parameters() if p.grad is not None)
     assert np.isfinite(gn) and gn > 0
     opt.step()
+
+
+def test_get_model_builds_the_style_losses_for_trainer_forward():
+    """`model, trainer, ... = get_model(args, [H, W])` with an `is_finetune: True` config, then `trainer.forward(...)` exactly as train.py
+    does - NO hand-wired style_loss: get_model configures the losses from the YAML as the reference's Trainer.__init__ does
+    (volsdf.py:638-645), they are built at the first fine-tune step (CLIP heads + VGG term on the hand-written kernels; seeded random
+    weights through `finetune.synthetic_style`), and a render-only use of the same config never builds them."""
+    from nerfart_amd import scene, frameworks, criteria
+    cfg = scene.synthetic_config("VolSDF")
+    cfg.training.is_finetune = True
+    cfg.data.downscale = 2
+    cfg.finetune = {"src_text": "photo", "target_text": "painting, oil on canvas", "w_clip": 1.0, "w_perceptual": 2.0, "w_contrastive": 0.2,
+                    "w_patchnce": 0.1, "w_eikonal": 0.1, "use_eikonal": True, "synthetic_style": True}
+    H, W = 480, 270                                                # the PatchNCE crop ranges need the reference's frame size
+    torch.manual_seed(0)
+    model, trainer, rk_train, rk_test, render_fn = frameworks.get_model(cfg, [H, W])
+    model.load_state_dict(scene.perturb_state(model.state_dict(), beta=0.01, seed=1))
+    model.to(DEV).set_precision("bf16x3")
+    assert getattr(trainer, "style_loss", None) is None and trainer._style_cfg is not None      # configured, not loaded
+    c2w, K = scene.camera(H, W)
+    model_input = {"intrinsics": K[None], "c2w": c2w[None]}
+    ground_truth = {"rgb": torch.rand(1, H * W, 3, generator=torch.Generator().manual_seed(2))}
+    rkt = dict({k: v for k, v in rk_test.items() if k != "rayschunk"}, H=H, W=W)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    import random
+    random.seed(0)
+    ret = trainer(cfg, torch.tensor([0]), model_input, ground_truth, rkt, 0, optimizer=opt)
+    assert isinstance(trainer.style_loss, criteria.StyleLoss) and trainer.style_loss.perceptual is not None
+    assert ret["losses"].ndim == 0 and torch.isfinite(ret["losses"]) and float(ret["losses"]) > 0
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0 for p in model.parameters())
 
 
 @pytest.mark.parametrize("fw", ["VolSDF", "NeuS"])
