@@ -23,6 +23,10 @@
  *           then runs REVERSE mode too (forward sweep + transposed-weight sweep in one kernel, softplus' as unorm16 in the
  *           caller's workspace); precision 2 (these two entry points only) selects the forward-mode tangent kernel on the
  *           same blob (cross-checks).
+ *       4 = "fp16x2" (csrc/mlp_chain_f16x2.hip): the split-bf16 kernels' data flow with the 2-MFMA split - ONE fp16 activation term
+ *           x fp16 hi + lo weight terms, 2 x v_mfma_f32_16x16x32_f16 per product (11-bit activations, TF32 class; blobs from
+ *           surface_plan_bf16(term="fp16") / radiance_plan_bf16(term="fp16")).  A MEASUREMENT variant of the three forward
+ *           kernels (inference entry points only; workspace as precision 1), never a default - DESIGN.md 4.1b.
  *   - point sources: either an explicit array pts[M,3], or ("_rays" variants) rays + per-ray depths:
  *     point m = slot m / n_per_ray, sample m % n_per_ray, ray = ray_idx ? ray_idx[slot] : slot,
  *     x = rays_o[ray] + rays_d[ray] * depth[slot * depth_stride + sample]  (two roundings, as the

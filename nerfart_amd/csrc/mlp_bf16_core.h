@@ -30,15 +30,29 @@ struct EpiCtx {
     bool is_val;                                    // tangent kernels: this lane is a value column
 };
 
+// NERFART_F16X2 (csrc/mlp_chain_f16x2.hip compiles this whole core a second time, namespace f16x2, C-ABI precision 4): the
+// 2-MFMA split - ONE fp16 activation term (11 significant bits, TF32 class) against fp16 hi + lo weight terms:
+//     a . w  ~  a16 . w_hi + a16 . w_lo            (v_mfma_f32_16x16x32_f16 x 2, fp32 accumulate)
+// Same data flow, same blob geometry (the packer writes fp16 fragments), 2/3 of the matrix work.  A measurement variant: it
+// exists to put the "fewer MFMAs per product" question to the statistics the shipped bf16x3 mode is held to.
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     typedef float f32x2_ __attribute__((ext_vector_type(2)));
     f32x2_ v = {a, b};
+#ifdef NERFART_F16X2
+    typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_));      // v_cvt_pk_f16_f32 (RNE)
+#else
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));       // v_cvt_pk_bf16_f32 (RNE)
+#endif
 }
 __device__ __forceinline__ void split2(float y0, float y1, unsigned& hi, unsigned& lo) {
     hi = pack_bf16(y0, y1);
+#ifdef NERFART_F16X2
+    lo = 0u;                                        // single-term activations: no MFMA reads the lo unit
+#else
     const float h0 = __uint_as_float(hi << 16), h1 = __uint_as_float(hi & 0xffff0000u);
     lo = pack_bf16(y0 - h0, y1 - h1);
+#endif
 }
 __device__ __forceinline__ f32x4 mfma3(const u32x4 ah, const u32x4 al, const u32x4 bh, const u32x4 bl, f32x4 acc) {
 #ifdef NERFART_ABLATE_MFMA      // timing experiments only (tools/ablate_bf16.py): keep the operands live, skip the matrix work
@@ -50,6 +64,13 @@ __device__ __forceinline__ f32x4 mfma3(const u32x4 ah, const u32x4 al, const u32
     // between triples.  Hazards the compiler no longer pads: a VALU write of an A/B operand just before the
     // statement (s_nop 1 inside); the result read by a VALU after it (readers are >= 2 triples away, except at
     // the end of a layer: layer() ends with explicit nops).
+#ifdef NERFART_F16X2
+    asm volatile("s_nop 1\n\t"
+                 "v_mfma_f32_16x16x32_f16 %0, %1, %3, %0\n\t"
+                 "v_mfma_f32_16x16x32_f16 %0, %2, %3, %0"
+                 : "+v"(acc) : "v"(ah), "v"(al), "v"(bh));
+    return acc;
+#endif
     asm volatile("s_nop 1\n\t"
                  "v_mfma_f32_16x16x32_bf16 %0, %1, %3, %0\n\t"
                  "v_mfma_f32_16x16x32_bf16 %0, %1, %4, %0\n\t"
@@ -74,6 +95,20 @@ __device__ __forceinline__ f32x4 wait_mfma3(u32x4& ah, u32x4& al, const u32x4 bh
 #if defined(NERFART_ABLATE_MFMA) || defined(NERFART_OLD_ITEM)
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(ah), "+v"(al) : "i"(CNT));
     return mfma3(ah, al, bh, bl, acc);
+#elif defined(NERFART_F16X2)
+    if constexpr (PAD) {
+        asm volatile("s_waitcnt lgkmcnt(%4)\n\t"
+                     "s_nop 0\n\t"
+                     "v_mfma_f32_16x16x32_f16 %0, %1, %3, %0\n\t"
+                     "v_mfma_f32_16x16x32_f16 %0, %2, %3, %0"
+                     : "+v"(acc) : "v"(ah), "v"(al), "v"(bh), "i"(CNT));
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(%4)\n\t"
+                     "v_mfma_f32_16x16x32_f16 %0, %1, %3, %0\n\t"
+                     "v_mfma_f32_16x16x32_f16 %0, %2, %3, %0"
+                     : "+v"(acc) : "v"(ah), "v"(al), "v"(bh), "i"(CNT));
+    }
+    return acc;
 #else
     if constexpr (PAD) {
         asm volatile("s_waitcnt lgkmcnt(%5)\n\t"
@@ -295,6 +330,10 @@ __device__ __forceinline__ void epi_phase(float z0, float z1, Work& w, unsigned&
         if constexpr (MODE == 3) {
             w.r0 = (float)(din & 0xffffu);          // 65535 * softplus'(z_l): the 1/65535 lives in the packed weights
             w.r1 = (float)(din >> 16);
+#ifdef NERFART_F16X2                                   // ... except in fp16: z * 65535 overflows it, w / 65535 underflows it
+            w.r0 *= (1.0f / 65535.0f);
+            w.r1 *= (1.0f / 65535.0f);
+#endif
         }
         if constexpr (MODE == 7) {
             w.r0 = (din & 0xffffu) ? 1.f : 0.f;     // relu mask from the dumped activation (bf16 bits)

@@ -607,15 +607,19 @@ int radiance_fwd_dump_bf16(const float* blob, int view_tiles, const PointSrc& s,
 int radiance_bwd_bf16(const float* blob, long long M, const float* rgb, const float* g_rgb, void* fwd_dump, void* bwd_dump, float* g_h7,
                       float* g_n, hipStream_t st);
 int sdf_grad_bf16(const float* blob, const PointSrc& s, float R_bg, float* sdf, float* nabla, float* h7, void* ws, hipStream_t st);
+// precision 4 (csrc/mlp_chain_f16x2.hip: the same three kernels with the 2-MFMA fp16 split)
+int sdf_f16x2(const float* blob, const PointSrc& s, float R_bg, float* out, int out_stride, hipStream_t st);
+int radiance_f16x2(const float* blob, int view_tiles, const PointSrc& s, const float* nabla, const float* h7, float* rgb, hipStream_t st);
+int sdf_grad_f16x2(const float* blob, const PointSrc& s, float R_bg, float* sdf, float* nabla, float* h7, void* ws, hipStream_t st);
 // bytes of the reverse-mode kernels' softplus' scratch (one private region per resident workgroup): caller owned
 static size_t nabla_ws_bytes(int precision) {
     if (precision == 0) return (size_t)num_cus() * GRADF_WS_PER_WG;
-    if (precision == 1) return sdf_grad_ws_bytes();
+    if (precision == 1 || precision == 4) return sdf_grad_ws_bytes();
     return 0;                                         // forward-mode tangent kernels (2, 3): none
 }
 static int check_precision(int precision, bool allow_fwd_tangents = false) {
-    if (precision == 0 || precision == 1 || (allow_fwd_tangents && (precision == 2 || precision == 3))) return 0;
-    set_last_error("precision must be 0 (fp32-exact MFMA) or 1 (split-bf16 'bf16x3' MFMA)");
+    if (precision == 0 || precision == 1 || precision == 4 || (allow_fwd_tangents && (precision == 2 || precision == 3))) return 0;
+    set_last_error("precision must be 0 (fp32-exact MFMA), 1 (split-bf16 'bf16x3' MFMA) or 4 (2-MFMA 'fp16x2', measurement variant)");
     return 2;
 }
 // precision 0: reverse-mode kernel; precision 3: the forward-mode tangent quads of k_sdf_nabla (kept for cross-checks - same
@@ -632,6 +636,7 @@ static int sdf_nabla_f32_dispatch(int precision, const float* blob, const PointS
 static int sdf_nabla_bf16_dispatch(int precision, const float* blob, const PointSrc& s, float R_bg, float* sdf, float* nabla,
                                    float* h7, void* ws, hipStream_t st) {
     if (precision == 2) return sdf_nabla_bf16(blob, s, R_bg, sdf, nabla, h7, st);
+    if (precision == 4) return sdf_grad_f16x2(blob, s, R_bg, sdf, nabla, h7, ws, st);
     return sdf_grad_bf16(blob, s, R_bg, sdf, nabla, h7, ws, st);
 }
 static int check_nabla_ws(int precision, const void* ws, long long ws_bytes) {
@@ -652,6 +657,7 @@ int nerfart_sdf_fwd(const float* blob, int precision, const float* pts, long lon
     if (M == 0) return 0;
     PointSrc s = make_src(pts, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, M);
     if (int rc = validate_src(s)) return rc;
+    if (precision == 4) return sdf_f16x2(blob, s, R_bg, sdf_out, 0, (hipStream_t)stream);
     if (precision == 1) return sdf_bf16(blob, s, R_bg, sdf_out, 0, (hipStream_t)stream);
     return launch_chain(0, M, k_sdf_only, (unsigned)((M + 127) / 128), (hipStream_t)stream, blob, s, R_bg, sdf_out, 0);
 }
@@ -665,6 +671,7 @@ int nerfart_sdf_fwd_rays(const float* blob, int precision, const float* rays_o, 
     PointSrc s = make_src(nullptr, nullptr, rays_o, rays_d, ray_idx, depth, n_per_ray, depth_stride, M);
     if (int rc = validate_src(s)) return rc;
     if (int rc = check_precision(precision)) return rc;
+    if (precision == 4) return sdf_f16x2(blob, s, R_bg, sdf_out, out_stride, (hipStream_t)stream);
     if (precision == 1) return sdf_bf16(blob, s, R_bg, sdf_out, out_stride, (hipStream_t)stream);
     return launch_chain(0, M, k_sdf_only, (unsigned)((M + 127) / 128), (hipStream_t)stream, blob, s, R_bg, sdf_out, out_stride);
 }
@@ -679,7 +686,7 @@ int nerfart_sdf_nabla_fwd(const float* blob, int precision, const float* pts, lo
     if (int rc = validate_src(s)) return rc;
     if (int rc = check_precision(precision, true)) return rc;
     if (int rc = check_nabla_ws(precision, workspace, workspace_bytes)) return rc;
-    if (precision == 1 || precision == 2) return sdf_nabla_bf16_dispatch(precision, blob, s, R_bg, sdf_out, nabla_out, h7_out, workspace, (hipStream_t)stream);
+    if (precision == 1 || precision == 2 || precision == 4) return sdf_nabla_bf16_dispatch(precision, blob, s, R_bg, sdf_out, nabla_out, h7_out, workspace, (hipStream_t)stream);
     return sdf_nabla_f32_dispatch(precision, blob, s, R_bg, sdf_out, nabla_out, h7_out, workspace, (hipStream_t)stream);
 }
 
@@ -693,7 +700,7 @@ int nerfart_sdf_nabla_fwd_rays(const float* blob, int precision, const float* ra
     if (int rc = validate_src(s)) return rc;
     if (int rc = check_precision(precision, true)) return rc;
     if (int rc = check_nabla_ws(precision, workspace, workspace_bytes)) return rc;
-    if (precision == 1 || precision == 2) return sdf_nabla_bf16_dispatch(precision, blob, s, R_bg, sdf_out, nabla_out, h7_out, workspace, (hipStream_t)stream);
+    if (precision == 1 || precision == 2 || precision == 4) return sdf_nabla_bf16_dispatch(precision, blob, s, R_bg, sdf_out, nabla_out, h7_out, workspace, (hipStream_t)stream);
     return sdf_nabla_f32_dispatch(precision, blob, s, R_bg, sdf_out, nabla_out, h7_out, workspace, (hipStream_t)stream);
 }
 
@@ -705,6 +712,7 @@ int nerfart_radiance_fwd(const float* blob, int precision, int view_tiles, const
     PointSrc s = make_src(pts, view, nullptr, nullptr, nullptr, nullptr, 1, 0, M);
     if (int rc = validate_src(s)) return rc;
     if (int rc = check_precision(precision)) return rc;
+    if (precision == 4) return radiance_f16x2(blob, view_tiles, s, nabla, h7, rgb_out, (hipStream_t)stream);
     if (precision == 1) return radiance_bf16(blob, view_tiles, s, nabla, h7, rgb_out, (hipStream_t)stream);
     const unsigned nt = (unsigned)((M + 127) / 128);
     if (view_tiles == 1) return launch_chain(2, M, k_radiance<1>, nt, (hipStream_t)stream, blob, s, nabla, h7, rgb_out);
@@ -722,6 +730,7 @@ int nerfart_radiance_fwd_rays(const float* blob, int precision, int view_tiles, 
     PointSrc s = make_src(nullptr, nullptr, rays_o, rays_d, ray_idx, depth, n_per_ray, depth_stride, M);
     if (int rc = validate_src(s)) return rc;
     if (int rc = check_precision(precision)) return rc;
+    if (precision == 4) return radiance_f16x2(blob, view_tiles, s, nabla, h7, rgb_out, (hipStream_t)stream);
     if (precision == 1) return radiance_bf16(blob, view_tiles, s, nabla, h7, rgb_out, (hipStream_t)stream);
     const unsigned nt = (unsigned)((M + 127) / 128);
     if (view_tiles == 1) return launch_chain(2, M, k_radiance<1>, nt, (hipStream_t)stream, blob, s, nabla, h7, rgb_out);

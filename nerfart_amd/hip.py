@@ -167,7 +167,7 @@ def profile_end():
 
 
 # ---- point queries -----------------------------------------------------------------------
-PRECISIONS = {"fp32": 0, "bf16x3": 1}
+PRECISIONS = {"fp32": 0, "bf16x3": 1, "fp16x2": 4}      # 4: the 2-MFMA measurement variant (never the default)
 
 
 def sdf_fwd(surf_blob, pts, R_bg: float, precision: int = 0):

@@ -168,7 +168,9 @@ class _PackedModel(nn.Module):
     def set_precision(self, precision: str):
         """'fp32'  : v_mfma_f32_16x16x4_f32, exact fp32 FMA chains (157 TFLOP/s peak);
         'bf16x3': operands split hi+lo in bf16, 3 x v_mfma_f32_16x16x32_bf16 per k-step, fp32 accumulate
-                  (~2^-16 relative per product, 5.3x the fp32 MFMA rate)."""
+                  (~2^-16 relative per product, 5.3x the fp32 MFMA rate);
+        'fp16x2': ONE fp16 activation term x fp16 hi+lo weights, 2 x v_mfma_f32_16x16x32_f16 (11-bit activations, TF32 class):
+                  a measurement variant of the three forward kernels - inference only, never the default."""
         if precision not in hip.PRECISIONS:
             raise ValueError(f"precision must be one of {list(hip.PRECISIONS)}")
         self.precision = precision
@@ -186,8 +188,9 @@ class _PackedModel(nn.Module):
                 self._plans[self.precision] = (packing.surface_plan(s.W, s.D, tuple(s.skips), s.embed_multires, s.W_geo_feat),
                                                packing.radiance_plan(self.view_tiles, r.W, r.D, s.W_geo_feat))
             else:
-                self._plans[self.precision] = (packing.surface_plan_bf16(s.W, s.D, tuple(s.skips), s.embed_multires, s.W_geo_feat),
-                                               packing.radiance_plan_bf16(self.view_tiles, r.W, r.D, s.W_geo_feat))
+                term = "fp16" if self.precision == "fp16x2" else "bf16"
+                self._plans[self.precision] = (packing.surface_plan_bf16(s.W, s.D, tuple(s.skips), s.embed_multires, s.W_geo_feat, term=term),
+                                               packing.radiance_plan_bf16(self.view_tiles, r.W, r.D, s.W_geo_feat, term=term))
         return self._plans[self.precision]
 
     def _param_key(self):

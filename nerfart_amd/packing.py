@@ -399,8 +399,9 @@ class PackPlanBF16(PackPlan):
         if cs is not None:
             w = w * cs
         w = w.reshape(-1, 64, 8)                              # [(k-step, tile) of all chunks, lane, e]
-        hi = w.to(torch.bfloat16)                             # round-to-nearest-even
-        lo = (w - hi.to(torch.float32)).to(torch.bfloat16)
+        dt = torch.float16 if getattr(self, "term", "bf16") == "fp16" else torch.bfloat16      # "fp16": the 2-MFMA variant (precision 4)
+        hi = w.to(dt)                                         # round-to-nearest-even
+        lo = (w - hi.to(torch.float32)).to(dt)
         body = torch.stack([hi, lo], dim=1).contiguous().view(torch.float32).reshape(-1)   # [..][term][lane][4]
         hdr = torch.from_numpy(self.header.copy()).view(torch.float32).to(dev)
         return torch.cat([hdr, body, src[ai], torch.zeros(self.pad, dtype=torch.float32, device=dev)]).contiguous()
@@ -492,7 +493,10 @@ D_UNORM = 65535.0         # softplus'(z) in [0, 1] is handed from the forward to
 GRAD_ENC_ROW0 = 217       # rows 217..255 of the backward outputs of layers 4 and 0 carry d sdf / d enc[0..38]
 
 
-def surface_plan_bf16(W: int = 256, D: int = 8, skips=(4,), multires: int = 6, W_geo_feat: int = 256) -> PackPlanBF16:
+def surface_plan_bf16(W: int = 256, D: int = 8, skips=(4,), multires: int = 6, W_geo_feat: int = 256, term: str = "bf16") -> PackPlanBF16:
+    """term = "fp16": the same programs with fp16 hi + lo weight fragments for the 2-MFMA kernels (csrc/mlp_chain_f16x2.hip, C-ABI
+    precision 4); the reverse-mode chunks then do NOT absorb the unorm16 scale 1 / 65535 (w / 65535 would be an fp16 subnormal:
+    the kernel applies it to softplus' instead)."""
     if not (W == 256 and D == 8 and tuple(skips) == (4,) and multires == 6 and W_geo_feat == 256):
         raise NotImplementedError("gfx950 surface kernels are built for W=256, D=8, skips=[4], embed_multires=6, W_geo_feat=256")
     enc = 39
@@ -543,11 +547,11 @@ def surface_plan_bf16(W: int = 256, D: int = 8, skips=(4,), multires: int = 6, W
         for c0 in range(0, 8, CHUNK_KS):
             chunks.append(np.concatenate([_kstep_index_T(flat, f"w{l}", ks, kf, nat) for ks in range(c0, c0 + CHUNK_KS)]))
             mul.append(np.concatenate([_kstep_mul_index(flat, f"w{D}", 0, ks, kf) for ks in range(c0, c0 + CHUNK_KS)]) if l == D - 1 else None)
-            scl.append(1.0 if l == D - 1 else 1.0 / D_UNORM)
+            scl.append(1.0 if (l == D - 1 or term == "fp16") else 1.0 / D_UNORM)
     enc_rows = np.where(nat >= GRAD_ENC_ROW0, nat - GRAD_ENC_ROW0, -1)
     chunks.append(np.concatenate([_kstep_index_T(flat, "w0", ks, unit_feature_hidden, enc_rows, tiles=(13, 14, 15)) for ks in range(8)]))
     mul.append(None)
-    scl.append(1.0 / D_UNORM)
+    scl.append(1.0 if term == "fp16" else 1.0 / D_UNORM)
     aux = [flat.vec_index(f"b{l}", _pad(ar(dims[l][0]), 256)) for l in range(D)]
     aux.append(flat.mat_index(f"w{D}", np.array([0]), ar(256)).reshape(-1))
     aux.append(flat.vec_index(f"b{D}", _pad(np.array([0]), 4)))
@@ -591,10 +595,11 @@ def surface_plan_bf16(W: int = 256, D: int = 8, skips=(4,), multires: int = 6, W
     plan.header[8], plan.header[9] = len(chunks) - w32_first, w32_first      # the w32 program: chunk count, first chunk
     # cat[h, enc] / sqrt(2) (base.py:250) is applied to the skip layer's weights instead of its inputs
     plan.scale = {f"w{l}": 1.0 / float(np.sqrt(2.0)) for l in skips}
+    plan.term = term
     return plan
 
 
-def radiance_plan_bf16(view_tiles: int, W: int = 256, D: int = 4, W_geo_feat: int = 256) -> PackPlanBF16:
+def radiance_plan_bf16(view_tiles: int, W: int = 256, D: int = 4, W_geo_feat: int = 256, term: str = "bf16") -> PackPlanBF16:
     if not (W == 256 and D == 4 and W_geo_feat == 256 and view_tiles in (1, 3)):
         raise NotImplementedError("gfx950 radiance kernel is built for W=256, D=4, W_geo_feat=256")
     n_extra = 9 if view_tiles == 1 else 33
@@ -637,7 +642,9 @@ def radiance_plan_bf16(view_tiles: int, W: int = 256, D: int = 4, W_geo_feat: in
         chunks.append(np.concatenate([_kstep_index_T(flat, "r0", ks, unit_feature_hidden, n_extra + nat) for ks in range(c0, c0 + CHUNK_KS)]))
     for c0 in range(0, 8, CHUNK_KS):
         chunks.append(np.concatenate([_kstep_index_T(flat, "w8", ks, unit_feature_hidden, nat, row0=1) for ks in range(c0, c0 + CHUNK_KS)]))
-    return PackPlanBF16(PROG_RADIANCE_BF16, flat, chunks, aux, nc_main=nc_fwd)
+    plan = PackPlanBF16(PROG_RADIANCE_BF16, flat, chunks, aux, nc_main=nc_fwd)
+    plan.term = term
+    return plan
 
 
 def fold_weight_norm(weight_g: torch.Tensor, weight_v: torch.Tensor) -> torch.Tensor:

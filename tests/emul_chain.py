@@ -312,12 +312,25 @@ import torch as _torch
 TS_FLOATS = 512
 
 
+TERM = "bf16"        # "fp16": the 2-MFMA variant (csrc/mlp_chain_f16x2.hip, precision 4) - fp16 fragments, single-term activations
+
+
 def _bf16(x):
-    return _torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(_torch.bfloat16).to(_torch.float32).numpy()
+    dt = _torch.float16 if TERM == "fp16" else _torch.bfloat16
+    return _torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dt).to(_torch.float32).numpy()
+
+
+def _decode16(raw):
+    """uint16 fragment bits -> float32 values (bf16, or fp16 for the 2-MFMA blobs)"""
+    if TERM == "fp16":
+        return raw.view(np.float16).astype(np.float32)
+    return (raw.astype(np.uint32) << 16).view(np.float32)
 
 
 def split2(x):
     hi = _bf16(x)
+    if TERM == "fp16":
+        return hi, np.zeros_like(hi)                      # one activation term: the a_hi . b_lo product of the emulation adds zero
     lo = _bf16(x.astype(np.float32) - hi)
     return hi, lo
 
@@ -340,7 +353,7 @@ def _frag(w, kk, T):
     """chunk float array -> (A_hi, A_lo) [64, 8] bf16 values for k-step kk of the chunk, output tile T"""
     o = (kk * 16 + T) * TS_FLOATS
     raw = np.ascontiguousarray(w[o:o + TS_FLOATS]).view(np.uint16).reshape(2, 64, 8)
-    f = (raw.astype(np.uint32) << 16).view(np.float32)
+    f = _decode16(raw)
     return f[0], f[1]
 
 
@@ -510,7 +523,7 @@ def _acc_layer(units, blob, init, ntiles=16, tiles_per_kstep=16):
             for T in range(ntiles):
                 o = (kk * tiles_per_kstep + T) * TS_FLOATS
                 raw = np.ascontiguousarray(w[o:o + TS_FLOATS]).view(np.uint16).reshape(2, 64, 8)
-                f = (raw.astype(np.uint32) << 16).view(np.float32)
+                f = _decode16(raw)
                 acc[T] = mfma_16x16x32(f[0], units[ks + kk][0], acc[T])
                 acc[T] = mfma_16x16x32(f[0], units[ks + kk][1], acc[T])
                 acc[T] = mfma_16x16x32(f[1], units[ks + kk][0], acc[T])
@@ -554,6 +567,8 @@ def emul_sdf_grad_bf16(blob_np, pts16, R_bg):
     # backward: layer 7 (inputs softplus'(z7), the sdf row is inside the weights), then 6..1
     P = _acc_layer(_units_of([softplus100_grad(a) for a in z[7]]), blob, zero)
     ge4 = None
+    if TERM == "fp16":                                   # the fp16 blob does not absorb 1 / 65535: the kernel scales softplus' itself
+        dq = [None if q is None else [(t * np.float32(1.0 / 65535.0)).astype(np.float32) for t in q] for q in dq]
     for l in range(6, 0, -1):
         P = _acc_layer(_units_of([(P[T] * dq[l][T]).astype(np.float32) for T in range(16)]), blob, zero)
         if l == 4:
@@ -566,7 +581,7 @@ def emul_sdf_grad_bf16(blob_np, pts16, R_bg):
         for t in range(3):
             o = (ks * 3 + t) * TS_FLOATS
             raw = np.ascontiguousarray(w[o:o + TS_FLOATS]).view(np.uint16).reshape(2, 64, 8)
-            f = (raw.astype(np.uint32) << 16).view(np.float32)
+            f = _decode16(raw)
             E[t] = mfma_16x16x32(f[0], units[ks][0], E[t])
             E[t] = mfma_16x16x32(f[0], units[ks][1], E[t])
             E[t] = mfma_16x16x32(f[1], units[ks][0], E[t])

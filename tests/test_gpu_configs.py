@@ -132,23 +132,32 @@ def test_cfg5_960x540_frame_properties_and_oracle_subset():
     err = (rgb_s[0].cpu() - ref["rgb"]).abs().max(dim=-1).values
     print(f"  960x540 subset: identical rounds on {same.float().mean():.3f}; max rgb err (same rounds) {err[same].max():.2e}, (all) {err.max():.2e}")
     assert same.float().mean() >= 0.98                      # measured 1.000 (round 3), flipped rays 0
-    pixel_budget(rgb_s[0].cpu(), ref["rgb"], "960x540 subset vs oracle")
+    pixel_budget(rgb_s[0].cpu(), ref["rgb"], "960x540 subset vs oracle", stable=same & (ref["iter_usage"] >= 0))
     assert (depth_s[0].cpu() - ref["depth_volume"])[same].abs().max() < 1e-2
 
 
-def pixel_budget(got, ref, label, over_frac=2e-3, max_abs=5e-3, psnr_min=82.0):
-    """The north-star "pixel-for-pixel within 1e-3 PSNR-equivalent" as an EXPLICIT, sample-size independent budget: at most 0.2 % of the
-    rays (at least one) may sit past 1e-3 on a channel - rays whose error-bounded sampling (Algorithm 1: bisection branches, inverse-CDF
-    plateaus) took another branch, which happens under ANY change of rounding incl. fp32 on another machine -, none past 5e-3, and
-    the PSNR over the sample >= 82 dB.  Measured (profiles/r05b_parity_table.json, 2,048 rays): bf16x3 3 / 2 rays past 1e-3 on the two
-    views, max 2.4e-3, 83.9 / 88.4 dB; the EXACT-fp32 HIP mode on the same rays 3 / 0 rays, max 1.4e-3, 87.2 / 90.7 dB - every one of
-    those rays is a never-converged (iter_usage -1) ray on the CPU.  Returns the per-ray errors."""
+def pixel_budget(got, ref, label, stable=None, over_frac=2e-3, max_abs=5e-3, psnr_min=82.0):
+    """The north-star "pixel-for-pixel within 1e-3" as a sample-size independent statement of what CAN hold:
+
+    * HARD 1e-3 on every channel of every `stable` ray = rays whose error-bounded up-sampling converged on the CPU (iter_usage >= 0) in the
+      same number of rounds as on the GPU;
+    * the rest - rays that NEVER converge (iter_usage -1: they end on a bisected beta+) or flip a round - get a budget: at most 0.2 % of
+      all rays (at least one) past 1e-3, none past 5e-3, PSNR over the sample >= 82 dB.
+
+    Why a budget at all: the CPU oracle ITSELF moves such rays by more than 1e-3 when the SDF weights change by one fp32 ulp
+    (tools/oracle_sensitivity.py, profiles/r05_oracle_sensitivity_cfg{1,2}.json: 3 of 2,048 rays, max 2.1e-3, 86.2 dB at cfg 2; 22 of
+    4,096, max 8.0e-3, 74.6 dB at 32 spp - every one a never-converged ray, zero among the converged) - so does the reference on another
+    machine.  Measured here (profiles/r05b_parity_table.json, 2,048 rays): bf16x3 3 / 2 rays past 1e-3 on the two views, max 2.4e-3,
+    83.9 / 88.4 dB; the EXACT-fp32 HIP mode 3 / 0 rays, max 1.4e-3, 87.2 / 90.7 dB; all of them never-converged rays.  Returns the errors."""
     err = (got - ref).abs().max(dim=-1).values
     n = err.numel()
     over = int((err > 1e-3).sum())
     psnr = -10 * np.log10(max(float(((got - ref) ** 2).mean()), 1e-20))
     p999 = float(err.kthvalue(max(1, int(0.999 * n))).values)
-    print(f"  {label}: {n} rays, {over} past 1e-3 ({100.0 * over / n:.3f} %), max {float(err.max()):.2e}, p99.9 {p999:.2e}, PSNR {psnr:.1f} dB")
+    st = "" if stable is None else f"; stable rays {int(stable.sum())}, max on them {float(err[stable].max()):.2e}"
+    print(f"  {label}: {n} rays, {over} past 1e-3 ({100.0 * over / n:.3f} %), max {float(err.max()):.2e}, p99.9 {p999:.2e}, PSNR {psnr:.1f} dB{st}")
+    if stable is not None:
+        assert float(err[stable].max()) < 1e-3, (label, "a converged ray past the north-star bound", float(err[stable].max()))
     assert over <= max(1, int(np.ceil(over_frac * n))), (label, over, n)
     assert float(err.max()) <= max_abs, (label, float(err.max()))
     assert psnr >= psnr_min, (label, psnr)
@@ -159,8 +168,9 @@ def pixel_budget(got, ref, label, over_frac=2e-3, max_abs=5e-3, psnr_min=82.0):
 def test_cfg2_bf16x3_full_frame_vs_oracle(view):
     """The benchmarked configuration and precision against the oracle itself (not against the HIP fp32 frame): 2,048 rays strided over
     the 480 x 270 frame, on the default camera and on the view bench.py times and samples (orbit pose 1).  The bound is the explicit
-    budget of `pixel_budget` - the same statistic at any sample size, so the figures bench.py prints for its 1,792-ray sample cannot
-    contradict this test (round 3: a hard `max < 1e-3` held on 320 rays and failed on the bench's sample, 2 rays at 1.8e-3).  The
+    budget of `pixel_budget` - hard 1e-3 on the rays whose sampling converged, a count budget on the never-converged ones - the same
+    statistic at any sample size, so the figures bench.py prints for its own sample cannot contradict this test (round 3: a hard
+    `max < 1e-3` over ALL rays held on 320 rays and failed on the bench's 1,792-ray sample, 2 never-converged rays at 1.8e-3).  The
     exact-fp32 mode runs on the same rays: every ray the split-bf16 mode puts past 1e-3 is attributed (its fp32 error next to it)."""
     from nerfart_amd import scene, rend_util
     from oracle import render
@@ -183,7 +193,7 @@ def test_cfg2_bf16x3_full_frame_vs_oracle(view):
     errs = {}
     for precision, (got, dep, usage) in res.items():
         same = usage == ref["iter_usage"]
-        errs[precision] = pixel_budget(got, ref["rgb"], f"{precision} vs oracle ({view} view)")
+        errs[precision] = pixel_budget(got, ref["rgb"], f"{precision} vs oracle ({view} view)", stable=same & (ref["iter_usage"] >= 0))
         print(f"    identical up-sampling rounds on {float(same.float().mean()):.4f} of the rays; max depth error on those {float((dep - ref['depth_volume'])[same].abs().max()):.2e}")
         assert same.float().mean() >= 0.99
         assert (dep - ref["depth_volume"])[same].abs().max() < 2e-2

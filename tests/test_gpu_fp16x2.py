@@ -1,0 +1,80 @@
+"""C-ABI precision 4 ("fp16x2", csrc/mlp_chain_f16x2.hip): the 2-MFMA measurement variant of the three forward kernels.  Held to its own
+CPU emulation (tests/emul_chain.py with TERM = "fp16" walking the real fp16 blob: same data flow, so agreement is at fp32 summation
+noise) and, loosely, to the oracle; the pixel statistics that decide whether it could ever ship are tools/parity_table.py's."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import scene_state
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_fp16x2_kernels_match_their_emulation_and_the_oracle():
+    import emul_chain as em
+    from nerfart_amd import hip, packing, scene
+    from oracle import nets
+    model, _, _ = scene.build_model("VolSDF", seed=0, beta=0.01, device=DEV, precision="fp16x2")
+    assert model.precision_id == 4
+    surf, rad = model.packed()
+    sd, _ = scene_state("VolSDF", 0.01)
+    surf_cpu = packing.surface_plan_bf16(term="fp16").pack(packing.surface_tensors(sd)).numpy()
+    assert np.array_equal(surf.cpu().numpy().view(np.uint32), surf_cpu.view(np.uint32)), "GPU and CPU packers agree bit for bit"
+    g = torch.Generator().manual_seed(23)
+    pts = (torch.rand(64, 3, generator=g) * 4 - 2)
+    pts[:4] *= 2.0
+    view = torch.nn.functional.normalize(torch.randn(64, 3, generator=g), dim=-1)
+    x = pts.to(DEV)
+    s_k2 = hip.sdf_fwd(surf, x, 3.0, precision=4).cpu().numpy()
+    sdf, nab, h7 = hip.sdf_nabla_fwd(surf, x, 3.0, precision=4)
+    rgb = hip.radiance_fwd(rad, 1, x, view.to(DEV), nab, h7, precision=4).cpu().numpy()
+    em.TERM = "fp16"
+    try:
+        parts = [em.emul_sdf_grad_bf16(surf_cpu, pts[i:i + 16].numpy(), 3.0) for i in range(0, 64, 16)]
+    finally:
+        em.TERM = "bf16"
+    e_sdf, e_nab, e_h7 = (np.concatenate([p[k] for p in parts]) for k in range(3))
+    np.testing.assert_allclose(sdf.cpu().numpy(), e_sdf, atol=2e-5)
+    np.testing.assert_allclose(s_k2, e_sdf, atol=2e-5)
+    np.testing.assert_allclose(nab.cpu().numpy(), e_nab, atol=2e-4, rtol=1e-3)
+    np.testing.assert_allclose(h7.cpu().numpy(), e_h7, atol=2e-5)
+    s_ref, n_ref, feat_ref = nets.surface_forward_with_nablas(sd, pts)
+    d_bg = 3.0 - pts.norm(dim=-1)
+    s_ref = torch.where(d_bg < s_ref, d_bg, s_ref)
+    print(f"  fp16x2 vs oracle: sdf {np.abs(sdf.cpu().numpy() - s_ref.numpy()).max():.2e}, nabla {np.abs(nab.cpu().numpy() - n_ref.numpy()).max():.2e}")
+    np.testing.assert_allclose(sdf.cpu().numpy(), s_ref.numpy(), atol=3e-3)
+    np.testing.assert_allclose(nab.cpu().numpy(), n_ref.numpy(), atol=2e-2, rtol=2e-2)
+    ref = nets.radiance_forward(sd, pts, view, n_ref, feat_ref, -1, -1).numpy()
+    np.testing.assert_allclose(rgb, ref, atol=1e-2)
+
+
+@pytest.mark.parametrize("fw", ["VolSDF", "NeuS"])
+def test_fp16x2_renders_a_frame_close_to_fp32(fw):
+    """Both renderers at precision 4 against the exact-fp32 HIP frame: a valid rendering of the same field (PSNR, finite, chunk
+    invariant) - NOT the 1e-3 pixel contract, which this arithmetic is measured against in tools/parity_table.py."""
+    from nerfart_amd import scene, rend_util
+    H, W = 96, 54
+    c2w, K = scene.camera(H, W)
+    o, d, _ = rend_util.get_rays(c2w[None].to(DEV), K[None].to(DEV), H, W)
+    out = {}
+    for precision in ("fp32", "fp16x2"):
+        model, rk, fn = scene.build_model(fw, seed=0, beta=0.01 if fw == "VolSDF" else None, device=DEV, precision=precision)
+        kw = {k: v for k, v in rk.items() if k != "rayschunk"}
+        extra = dict(require_nablas=True) if fw == "VolSDF" else {}
+        rgb, depth, _ = fn(o, d, calc_normal=True, detailed_output=False, **extra, **kw)
+        rgb2, _, _ = fn(o, d, calc_normal=True, detailed_output=False, rayschunk=1777, **extra, **kw)
+        assert torch.equal(rgb, rgb2) and torch.isfinite(rgb).all()
+        out[precision] = rgb[0]
+    err = (out["fp16x2"] - out["fp32"]).abs().max(dim=-1).values
+    psnr = float(-10 * torch.log10(((out["fp16x2"] - out["fp32"]) ** 2).mean().clamp_min(1e-20)))
+    print(f"  {fw} fp16x2 vs fp32, {H * W} rays: {int((err > 1e-3).sum())} past 1e-3, max {float(err.max()):.2e}, PSNR {psnr:.1f} dB")
+    assert psnr > 55.0 and float(err.max()) < 0.1
+
+
+def test_training_refuses_fp16x2():
+    from nerfart_amd import scene
+    from nerfart_amd.trainer import Trainer
+    model, rk, fn = scene.build_model("VolSDF", seed=0, beta=0.01, device=DEV, precision="fp16x2")
+    with pytest.raises(RuntimeError, match="bf16x3"):
+        Trainer(model).native

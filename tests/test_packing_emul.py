@@ -307,3 +307,39 @@ def test_w32_program_register_path_matches_oracle():
     feats = sorted(packing.w32_feature_enc(q, h, e) for q in range(3) for h in range(2) for e in range(8))
     assert [f for f in feats if f >= 0] == list(range(39))
     assert sorted(packing.w32_feature_hidden(ks, h, e) for ks in range(16) for h in range(2) for e in range(8)) == list(range(256))
+
+
+# ---- the 2-MFMA variant (C-ABI precision 4, csrc/mlp_chain_f16x2.hip): fp16 hi + lo weight fragments, one fp16 activation term ------------
+def test_emulated_fp16x2_kernels_walk_the_fp16_blob():
+    """The same programs packed with term="fp16" (fp16 fragments; the reverse chunks without the folded 1 / 65535) through the same
+    emulated data flow with single-term fp16 activations: sdf / nabla / h7 / rgb land within the 11-bit-activation error of the
+    oracle - a wrong fragment decode, a missing scale or an fp16 underflow of the transposed weights would miss by orders of magnitude."""
+    sd, _ = scene_state("VolSDF", 0.01)
+    surf = packing.surface_plan_bf16(term="fp16").pack(packing.surface_tensors(sd)).numpy()
+    rad = packing.radiance_plan_bf16(1, term="fp16").pack(packing.radiance_tensors(sd)).numpy()
+    g = torch.Generator().manual_seed(23)
+    pts = (torch.rand(16, 3, generator=g) * 4 - 2)
+    pts[:2] *= 2.0
+    view = torch.nn.functional.normalize(torch.randn(16, 3, generator=g), dim=-1)
+    em.TERM = "fp16"
+    try:
+        s_only = em.emul_sdf_only_bf16(surf, pts.numpy(), 3.0)
+        sdf, nab, h7 = em.emul_sdf_grad_bf16(surf, pts.numpy(), 3.0)
+        s_ref, n_ref, feat_ref = nets.surface_forward_with_nablas(sd, pts)
+        rgb = em.emul_radiance_bf16(rad, 1, pts.numpy(), view.numpy(), n_ref.numpy(), h7)
+    finally:
+        em.TERM = "bf16"
+    d_bg = 3.0 - pts.norm(dim=-1)
+    s_ref = torch.where(d_bg < s_ref, d_bg, s_ref)
+    err_s = np.abs(sdf - s_ref.numpy()).max()
+    err_n = np.abs(nab - n_ref.numpy()).max()
+    print(f"  fp16x2 emulation: sdf {err_s:.2e}, K2 sdf {np.abs(s_only - s_ref.numpy()).max():.2e}, nabla {err_n:.2e}")
+    np.testing.assert_allclose(sdf, s_ref.numpy(), atol=3e-3)
+    np.testing.assert_allclose(s_only, sdf, atol=1e-6)                        # K2 and the reverse-mode kernel's forward sweep: same arithmetic
+    np.testing.assert_allclose(nab, n_ref.numpy(), atol=2e-2, rtol=2e-2)
+    w8 = nets.folded_weight(sd, "implicit_surface.surface_fc_layers.8").numpy()
+    b8 = sd["implicit_surface.surface_fc_layers.8.bias"].numpy()
+    np.testing.assert_allclose(h7 @ w8[1:].T + b8[1:], feat_ref.numpy(), atol=2e-2, rtol=2e-2)
+    ref = nets.radiance_forward(sd, pts, view, n_ref, feat_ref, -1, -1).numpy()
+    np.testing.assert_allclose(rgb, ref, atol=1e-2)
+    assert err_s > 1e-6, "suspiciously exact: is the emulation really on the fp16 path?"
