@@ -143,8 +143,13 @@ k_sdf_grad_bf16(const float* __restrict__ blob, PointSrc src, float R_bg, float*
 #pragma unroll
                 for (int pr = 0; pr < 4; ++pr) {
                     const int tile = 2 * u + (pr >> 1), r0 = 2 * (pr & 1);
+#ifdef NERFART_F16X2      // the fp16 blob does not absorb the unorm16 scale (mlp_bf16_core.h, MODE 3)
+                    const float y0 = B.t[tile][r0] * ((float)(d0[u][pr] & 0xffffu) * (1.0f / 65535.0f));
+                    const float y1 = B.t[tile][r0 + 1] * ((float)(d0[u][pr] >> 16) * (1.0f / 65535.0f));
+#else
                     const float y0 = B.t[tile][r0] * (float)(d0[u][pr] & 0xffffu);
                     const float y1 = B.t[tile][r0 + 1] * (float)(d0[u][pr] >> 16);
+#endif
                     unsigned hi, lo;
                     split2(y0, y1, hi, lo);
                     X[u].h[pr] = hi; X[u].l[pr] = lo;
