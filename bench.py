@@ -22,7 +22,13 @@ events recorded on the launching stream during the timed steps.  --precision bf1
 fp32 operands split into two bf16 terms, three v_mfma_f32_16x16x32_bf16 per product, fp32 accumulate (error
 ~2^-17, parity tests at 1e-3 like fp32); peak = 2,500 TFLOP/s dense bf16, of which a 3-MFMA product can reach
 1/3.  --precision fp32: k_sdf_only on v_mfma_f32_16x16x4_f32 (exact fp32 products), peak = 157.3 TFLOP/s.  `cpu_baseline` times the CPU oracle (a
-PyTorch port of the reference algorithm; kind "port") on a strided subset of the same frame's rays.
+PyTorch port of the reference algorithm; kind "port") on a strided subset of the same frame's rays, and doubles as a parity check of
+THIS run (the same rays through the HIP renderer at the benchmarked precision and at fp32-exact, converged and never-converged rays apart).
+
+`secondary` (N = 1; never the primary `value`): fp32_exact (5 frames), bf16x3_vs_fp32_pixels, fp16x2 (C-ABI precision 4, the 2-MFMA
+measurement variant, 3 frames + its pixel statistics), cfg5_frame_960x540 and cfg4_neus_480x270 (3 frames on 3 views each),
+cfg3_finetune_step (BASELINE configs[2]: 1 warm-up + 3 timed steps, stage split, peak memory, and the roofline of the dominant pass-2
+kernel k_wgrad<256> from the library's event records).
 """
 import argparse
 import json

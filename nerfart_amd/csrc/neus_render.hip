@@ -320,8 +320,14 @@ int nerfart_neus_render_fwd(const float* surf_blob, const float* rad_blob, int p
         NERFART_HIP(hipGetLastError());
     }
     if (d_all_out) NERFART_HIP(hipMemcpyAsync(d_all_out, w.d, sizeof(float) * (size_t)n_rays * P, hipMemcpyDeviceToDevice, stream));
-    // sdf + nablas at the P sample points (neus.py:320)
-    if (int rc = nerfart_sdf_nabla_fwd_rays(surf_blob, precision, rays_o, w.rays_dn, nullptr, w.d, n_rays, P, P, 0.f, sdf, nabla, nullptr, w.nabla_ws, (long long)w.nabla_ws_bytes, stream)) return rc;
+    // sdf + nablas at the P sample points (neus.py:320).  The nablas feed only normals_volume and the detailed output (:385-392):
+    // when neither is asked for, the sampler's own sdf row IS the result - the same network at the same sorted depths, evaluated by
+    // K2 during the up-sampling rounds (the reverse-mode kernel's forward sweep is K2's arithmetic) - and no launch is needed
+    if (normals || nabla_out) {
+        if (int rc = nerfart_sdf_nabla_fwd_rays(surf_blob, precision, rays_o, w.rays_dn, nullptr, w.d, n_rays, P, P, 0.f, sdf, nabla, nullptr, w.nabla_ws, (long long)w.nabla_ws_bytes, stream)) return rc;
+    } else {
+        NERFART_HIP(hipMemcpyAsync(sdf, w.s, sizeof(float) * (size_t)n_rays * P, hipMemcpyDeviceToDevice, stream));
+    }
     // radiance at the P-1 mid-points, with their own nablas (neus.py:324 -> forward_radiance :111-114)
     for (int c0 = 0; c0 < n_rays; c0 += k3_rays_chunk) {
         const int rk = (n_rays - c0 < k3_rays_chunk) ? n_rays - c0 : k3_rays_chunk;

@@ -256,6 +256,10 @@ def test_cfg4_neus_full_frame_properties_and_oracle_subset():
     assert rgb.shape == (1, H * W, 3) and torch.isfinite(rgb).all() and rgb.min() >= 0 and rgb.max() <= 1 + 1e-5
     rgb2, depth2, _ = render_fn(o, d, calc_normal=True, detailed_output=False, rayschunk=50021, **kw)
     assert torch.equal(rgb, rgb2) and torch.equal(depth, depth2), "results must not depend on ray chunking"
+    # without normals the renderer takes the samples' sdf from the sampler's own row instead of re-evaluating SDF + nabla there
+    # (neus.py:320, :385-392: the nablas feed only normals_volume / the detailed output): same pixels, bit for bit
+    rgb3, depth3, ex3 = render_fn(o, d, calc_normal=False, detailed_output=False, **kw)
+    assert torch.equal(rgb, rgb3) and torch.equal(depth, depth3) and "normals_volume" not in ex3
     sel = torch.arange(0, H * W, (H * W) // 64)[:64]
     rgb_s, depth_s, ex_s = render_fn(o[:, sel], d[:, sel], calc_normal=True, detailed_output=True, **kw)
     assert torch.equal(rgb_s, rgb[:, sel])
