@@ -335,7 +335,7 @@ def main():
         import glob
         # (only profiles of THIS workload: the train-step / CLIP profiles hold the same kernel names at other launch sizes)
         pm = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json"))
-                    if not any(t in os.path.basename(f) for t in ("_train_", "_clip_")))
+                    if not any(t in os.path.basename(f) for t in ("_train_", "_clip_", "_neus_")))
         if pm:
             try:
                 js = json.load(open(pm[-1]))
