@@ -33,6 +33,9 @@ struct EpiCtx {
 // NERFART_F16X2 (csrc/mlp_chain_f16x2.hip compiles this whole core a second time, namespace f16x2, C-ABI precision 4): the
 // 2-MFMA split - ONE fp16 activation term (11 significant bits, TF32 class) against fp16 hi + lo weight terms:
 //     a . w  ~  a16 . w_hi + a16 . w_lo            (v_mfma_f32_16x16x32_f16 x 2, fp32 accumulate)
+// on the k-steps whose input unit is built from the previous layer's accumulators; the READY-MADE input units (positional encodings of
+// layers 0 and 4, the radiance net's [x | v | n] and the h7 rows it reads from memory) keep a hi + lo pair and the three-term form - raw
+// coordinates and their sines are where 11 bits hurt most (2e-3 absolute at |x| = 8), and they are 4 of K2's 59 k-steps.
 // Same data flow, same blob geometry (the packer writes fp16 fragments), 2/3 of the matrix work.  A measurement variant: it
 // exists to put the "fewer MFMAs per product" question to the statistics the shipped bf16x3 mode is held to.
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
@@ -48,7 +51,12 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 __device__ __forceinline__ void split2(float y0, float y1, unsigned& hi, unsigned& lo) {
     hi = pack_bf16(y0, y1);
 #ifdef NERFART_F16X2
-    lo = 0u;                                        // single-term activations: no MFMA reads the lo unit
+    // the lo term is consumed only on the k-steps of READY-MADE input units (encodings, extras, h7 from memory: wait_mfma3<FULL>);
+    // for the units built from accumulators nothing reads it and the three instructions below are dead code
+    typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ hf = __builtin_convertvector(__builtin_bit_cast(f16x2_, hi), f32x2_);
+    lo = pack_bf16(y0 - hf[0], y1 - hf[1]);
 #else
     const float h0 = __uint_as_float(hi << 16), h1 = __uint_as_float(hi & 0xffff0000u);
     lo = pack_bf16(y0 - h0, y1 - h1);
@@ -90,13 +98,30 @@ __device__ __forceinline__ f32x4 mfma3(const u32x4 ah, const u32x4 al, const u32
 // item 15 of the previous k-step; PAD adds one state in front of item 0 anyway).  The fragments are plain inputs: named as
 // outputs, hipcc pads the next VALU that recycles their registers; that no compiler copy of them sits between the ds_read
 // statement and this one is what tools/audit_asm_loads.py (tests/test_asm_audit.py) checks in the ISA.
-template <int CNT, bool PAD>
+// FULL (NERFART_F16X2 only; ignored by the split-bf16 build, which always runs three terms): this k-step's B unit is a ready-made
+// input unit with a real lo term - a_hi b_hi + a_hi b_lo + a_lo b_hi in fp16; otherwise the 2-MFMA form a_hi b_hi + a_lo b_hi.
+template <int CNT, bool PAD, bool FULL = false>
 __device__ __forceinline__ f32x4 wait_mfma3(u32x4& ah, u32x4& al, const u32x4 bh, const u32x4 bl, f32x4 acc) {
 #if defined(NERFART_ABLATE_MFMA) || defined(NERFART_OLD_ITEM)
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(ah), "+v"(al) : "i"(CNT));
     return mfma3(ah, al, bh, bl, acc);
 #elif defined(NERFART_F16X2)
-    if constexpr (PAD) {
+    if constexpr (FULL) {
+        if constexpr (PAD) {
+            asm volatile("s_waitcnt lgkmcnt(%5)\n\t"
+                         "s_nop 0\n\t"
+                         "v_mfma_f32_16x16x32_f16 %0, %1, %3, %0\n\t"
+                         "v_mfma_f32_16x16x32_f16 %0, %1, %4, %0\n\t"
+                         "v_mfma_f32_16x16x32_f16 %0, %2, %3, %0"
+                         : "+v"(acc) : "v"(ah), "v"(al), "v"(bh), "v"(bl), "i"(CNT));
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(%5)\n\t"
+                         "v_mfma_f32_16x16x32_f16 %0, %1, %3, %0\n\t"
+                         "v_mfma_f32_16x16x32_f16 %0, %1, %4, %0\n\t"
+                         "v_mfma_f32_16x16x32_f16 %0, %2, %3, %0"
+                         : "+v"(acc) : "v"(ah), "v"(al), "v"(bh), "v"(bl), "i"(CNT));
+        }
+    } else if constexpr (PAD) {
         asm volatile("s_waitcnt lgkmcnt(%4)\n\t"
                      "s_nop 0\n\t"
                      "v_mfma_f32_16x16x32_f16 %0, %1, %3, %0\n\t"
@@ -558,7 +583,7 @@ struct Items {
                 mfma6(r.h[SP], r.l[SP], r.h[S], r.l[S], bh, bl, Q.t[T - 1], Q.t[T]);
             }
 #else
-            Q.t[T] = wait_mfma3<PENDING, T == 0>(r.h[S], r.l[S], bh, bl, Q.t[T]);
+            Q.t[T] = wait_mfma3<PENDING, T == 0, (ks >= L::NH)>(r.h[S], r.l[S], bh, bl, Q.t[T]);
 #endif
             constexpr int HU = L::hosted(ks);
             constexpr int HM = L::mode_of(HU);
