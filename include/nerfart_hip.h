@@ -111,8 +111,8 @@ int nerfart_radiance_bwd(const float* rad_blob, long long M, const float* rgb, c
  * the second quantity of the pair, per point; features in unit order; so dW_l is ONE GEMM over the stacked rows, read in
  * place.  (The softplus' slots 8..15 of f2_dump hold one value per point: rows 0..Mp-1 only, rows Mp.. are never written or read.)
  * At most 2^21 points per call.
- * The reductions are nerfart_wgrad_bf16 calls; the un-permutation and the weight_norm chain rule are host side (nerfart_amd/autodiff.py:
- * surface_weight_grads_raw / _finish). */
+ * The reductions are nerfart_wgrad_bf16 calls; the whole sequence - these two sweeps, the reductions, the un-permutation and the weight_norm chain
+ * rule - is behind nerfart_sdf_param_bwd / nerfart_*_render_bwd + nerfart_fold_weight_grads / nerfart_weight_norm_bwd (csrc/render_backward.hip). */
 long long nerfart_sdf_fwd2_dump_bytes(long long M);
 long long nerfart_sdf_bwd2_dump_bytes(long long M);
 int nerfart_sdf_fwd2(const float* surf_blob, const float* pts, const float* dir, long long M, void* f2_dump, void* stream);
