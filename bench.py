@@ -206,7 +206,16 @@ def main():
         pix2 = {"rays": int(e2.numel()), "rays_over_1e-3": int((e2 > 1e-3).sum()), "max_abs": round(float(e2.max()), 6),
                 "p999_abs": round(float(e2.flatten().kthvalue(int(0.999 * e2.numel())).values), 7),
                 "psnr_db": round(float(-10 * torch.log10(((b16_ - a32) ** 2).mean().clamp_min(1e-20))), 1)}
-        del a32, a16, e16, b16_, e2
+        # ... and the mixed variant: Algorithm 1 (the 512 (1 + rounds) no-gradient SDF queries per ray) on the 2-MFMA kernels, the 192 final
+        # samples - every number that reaches a pixel - in split-bf16 (nerfart_amd.hip.volsdf_render_mixed: the per-stage entry points)
+        mmx, _, fmx = scene.build_model("VolSDF", seed=0, beta=args.beta, device=dev, precision="bf16x3")
+        mmx.set_sampler_precision("fp16x2")
+        bmx, _, _ = fmx(o_, d_, require_nablas=True, calc_normal=True, detailed_output=False, **kw)
+        e3 = (bmx - a32).abs().max(dim=-1).values
+        pix3 = {"rays": int(e3.numel()), "rays_over_1e-3": int((e3 > 1e-3).sum()), "max_abs": round(float(e3.max()), 6),
+                "p999_abs": round(float(e3.flatten().kthvalue(int(0.999 * e3.numel())).values), 7),
+                "psnr_db": round(float(-10 * torch.log10(((bmx - a32) ** 2).mean().clamp_min(1e-20))), 1)}
+        del a32, a16, e16, b16_, e2, bmx, e3
         n32 = 5                                           # five timed frames (five views of the orbit), one warm-up above
         views32 = []
         for s_ in range(n32):
@@ -233,7 +242,17 @@ def main():
                                "what": "same workload at C-ABI precision 4: ONE fp16 activation term x fp16 hi + lo weights, 2 x v_mfma_f32_16x16x32_f16 per "
                                        "product (11-bit activations, TF32 class) - a measurement variant, NOT the headline precision; table vs the "
                                        "oracle: profiles/r05*_parity_table.json (tools/parity_table.py)"}
-        del m32, f32, m16, f16
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for oo_, dd_ in views32[:3]:
+            fmx(oo_, dd_, require_nablas=True, calc_normal=True, detailed_output=False, **kw)
+        torch.cuda.synchronize()
+        tmx = (time.perf_counter() - t1) / 3
+        secondary["bf16x3_with_fp16x2_sampler"] = {"value": round(H * W / tmx, 1), "unit": "rays/s", "ms_per_step": round(tmx * 1e3, 2), "steps": 3,
+                                                   "vs_fp32_pixels": pix3,
+                                                   "what": "Algorithm 1's SDF queries at C-ABI precision 4, the 192 final samples (sdf, nabla, radiance, compositing) in "
+                                                           "split-bf16: model.set_precision('bf16x3').set_sampler_precision('fp16x2') - a measurement variant"}
+        del m32, f32, m16, f16, mmx, fmx
         # the other single-GPU configurations of BASELINE.json: one warm-up frame, then N_SEC timed frames on N_SEC views of the orbit
         # (bench lines of their own: tools/bench_neus.py, tools/bench_train.py)
         N_SEC = 3

@@ -574,6 +574,50 @@ def volsdf_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, near, far,
     return out
 
 
+def volsdf_render_mixed(surf_blob, rad_blob, sampler_blob, sampler_precision: int, view_tiles, rays_o, rays_d, *, near, far, R_bg, alpha, beta, eps=0.1,
+                        n_samples=128, n_importance=64, max_upsample_steps=5, max_bisection_steps=10, white_bkgd=False, calc_normal=True,
+                        detailed=False, k3_rays_chunk=8192, precision=1, u_final=None):
+    """volsdf_render with the SAMPLER (Algorithm 1: 512 (1 + rounds) SDF queries per ray, no gradient, volsdf.py:479) on another blob /
+    precision than the 192 final samples: the fused renderer's own stage sequence on the per-stage entry points.  The final samples -
+    sdf, nabla, radiance, compositing, i.e. every number that reaches a pixel - run at `precision` on (surf_blob, rad_blob); only WHERE the
+    64 fine samples sit comes from the cheaper arithmetic.  Same return dict as volsdf_render."""
+    R = rays_o.shape[0]
+    dev = rays_o.device
+    P = n_samples + n_importance
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    dn = normalize_dirs(rays_d)
+    d_fine, beta_map, usage = volsdf_fine_sample(sampler_blob, rays_o, dn, near, far, R_bg, alpha, beta, eps, 4 * n_samples, 4 * n_samples, n_importance,
+                                                 max_upsample_steps, max_bisection_steps, precision=sampler_precision, u_final=u_final)
+    d_coarse = f(R, n_samples)
+    _check(lib.nerfart_linspace_depths(_dev(lin_table(n_samples, dev)), n_samples, None, None, float(near), float(far), R, _dev(d_coarse), n_samples,
+                                       _stream()), "nerfart_linspace_depths")
+    d_all = f(R, P)
+    _check(lib.nerfart_sort_concat(R, _dev(d_coarse), n_samples, n_samples, _dev(d_fine), n_importance, n_importance, _dev(d_all), P, _stream()),
+           "nerfart_sort_concat")
+    sdf, nab, rad = f(R, P), f(R, P, 3), f(R, P, 3)
+    ws, nb = nabla_workspace(precision, dev)
+    h7 = f(min(k3_rays_chunk, R) * P, 256)
+    for c0 in range(0, R, k3_rays_chunk):
+        rk = min(k3_rays_chunk, R - c0)
+        sl = slice(c0, c0 + rk)
+        _check(lib.nerfart_sdf_nabla_fwd_rays(_dev(surf_blob), int(precision), _dev(rays_o[sl]), _dev(dn[sl]), None, _dev(d_all[sl]), rk, P, P, float(R_bg),
+                                              _dev(sdf[sl]), _dev(nab[sl]), _dev(h7), _dev(ws, torch.uint8), nb, _stream()), "nerfart_sdf_nabla_fwd_rays")
+        _check(lib.nerfart_radiance_fwd_rays(_dev(rad_blob), int(precision), int(view_tiles), _dev(rays_o[sl]), _dev(dn[sl]), None, _dev(d_all[sl]), rk, P, P,
+                                             _dev(nab[sl]), _dev(h7), _dev(rad[sl]), _stream()), "nerfart_radiance_fwd_rays")
+    out = {"rgb": f(R, 3), "depth_volume": f(R), "mask_volume": f(R)}
+    if calc_normal:
+        out["normals_volume"] = f(R, 3)
+    det = {}
+    if detailed:
+        det = {"d_vals": d_all, "implicit_surface": sdf, "implicit_nablas": nab, "radiance": rad, "sigma": f(R, P), "p_i": f(R, P - 1),
+               "visibility_weights": f(R, P - 1), "beta_map": beta_map, "iter_usage": usage}
+    _check(lib.nerfart_volsdf_composite(R, P, _dev(d_all), _dev(sdf), _dev(rad), _dev(nab), float(alpha), float(beta), int(bool(white_bkgd)), _dev(out["rgb"]),
+                                        _dev(out["depth_volume"]), _dev(out["mask_volume"]), _dev(out.get("normals_volume")), _dev(det.get("sigma")),
+                                        _dev(det.get("p_i")), _dev(det.get("visibility_weights")), _stream()), "nerfart_volsdf_composite")
+    out.update(det)
+    return out
+
+
 def neus_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, obj_bounding_radius, s, n_samples=64, n_importance=64,
                 n_upsample_iters=4, white_bkgd=False, calc_normal=True, detailed=False, k3_rays_chunk=8192, precision=0,
                 u_new=None):

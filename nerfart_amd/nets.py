@@ -148,6 +148,8 @@ class _PackedModel(nn.Module):
         self._blobs = None
         self._blob_key = None
         self.precision = "fp32"
+        self.sampler_precision = None
+        self._sampler_blob = None
 
     def _bind_owner(self):
         import weakref
@@ -176,6 +178,35 @@ class _PackedModel(nn.Module):
         self.precision = precision
         self._blobs = None
         return self
+
+    def set_sampler_precision(self, precision):
+        """VolSDF only, a MEASUREMENT variant: run Algorithm 1's SDF queries (512 (1 + rounds) per ray, no gradient,
+        volsdf.py:479) at another precision than the 192 final samples - e.g. model.set_precision("bf16x3").set_sampler_precision("fp16x2"):
+        every number that reaches a pixel is computed in split-bf16, only WHERE the fine samples sit comes from the 2-MFMA kernels.
+        None: the sampler uses the model's precision (the fused renderer)."""
+        if precision is not None and precision not in hip.PRECISIONS:
+            raise ValueError(f"precision must be one of {list(hip.PRECISIONS)} or None")
+        self.sampler_precision = precision
+        self._sampler_blob = None
+        return self
+
+    def packed_sampler(self):
+        """(surface blob, precision id) for the sampler when it runs at its own precision; None otherwise."""
+        if self.sampler_precision is None or self.sampler_precision == self.precision:
+            return None
+        key = (self.sampler_precision,) + tuple((p.data_ptr(), p._version) for p in self.implicit_surface.parameters())
+        if self._sampler_blob is None or self._sampler_blob[0] != key:
+            s = self.implicit_surface
+            if self.sampler_precision == "fp32":
+                plan = packing.surface_plan(s.W, s.D, tuple(s.skips), s.embed_multires, s.W_geo_feat)
+            else:
+                plan = packing.surface_plan_bf16(s.W, s.D, tuple(s.skips), s.embed_multires, s.W_geo_feat,
+                                                 term="fp16" if self.sampler_precision == "fp16x2" else "bf16")
+            sd = {k: v.detach() for k, v in self.state_dict().items()}
+            with torch.no_grad():
+                blob = plan.pack(packing.surface_tensors(sd, D=s.D))
+            self._sampler_blob = (key, blob)
+        return self._sampler_blob[1], hip.PRECISIONS[self.sampler_precision]
 
     @property
     def precision_id(self) -> int:

@@ -41,6 +41,7 @@ def volume_render(rays_o, rays_d, model: VolSDF, near=0.0, far=6.0, obj_bounding
     rd = rays_d.reshape(-1, 3).float().contiguous()
     N = ro.shape[0]
     surf_blob, rad_blob = model.packed()
+    sampler = model.packed_sampler()                       # None unless model.set_sampler_precision(...) chose another arithmetic for Algorithm 1
     alpha, beta = model.forward_ab()
     alpha, beta = float(alpha.detach()), float(beta.detach())
     chunk = int(rayschunk) if rayschunk else DEFAULT_RAYSCHUNK
@@ -50,7 +51,10 @@ def volume_render(rays_o, rays_d, model: VolSDF, near=0.0, far=6.0, obj_bounding
         # perturb (volsdf.py:122, rend_util.py:306-307): the 64 final samples invert the opacity CDF at uniform random numbers
         # instead of linspace(0, 1, 64); drawn here from torch's generator of the device, a row per ray
         u_final = torch.rand(min(chunk, N - i), N_importance, device=ro.device) if perturb else None
-        parts.append(hip.volsdf_render(
+        render_chunk = hip.volsdf_render
+        if sampler is not None:                            # measurement variant: Algorithm 1 on a cheaper arithmetic, final samples at the model's
+            render_chunk = lambda sb, rb, vt, o_, d_, **kw_: hip.volsdf_render_mixed(sb, rb, sampler[0], sampler[1], vt, o_, d_, **kw_)
+        parts.append(render_chunk(
             surf_blob, rad_blob, model.view_tiles, ro[i:i + chunk], rd[i:i + chunk], near=near, far=far,
             R_bg=obj_bounding_radius, alpha=alpha, beta=beta, eps=epsilon, n_samples=N_samples,
             n_importance=N_importance, max_upsample_steps=max_upsample_steps,

@@ -86,3 +86,36 @@ def test_training_refuses_fp16x2():
     model, rk, fn = scene.build_model("VolSDF", seed=0, beta=0.01, device=DEV, precision="fp16x2")
     with pytest.raises(RuntimeError, match="bf16x3"):
         Trainer(model).native
+
+
+def test_staged_renderer_equals_the_fused_one_and_the_mixed_sampler_mode_renders():
+    """hip.volsdf_render_mixed (the per-stage entry points in the fused renderer's order) with the sampler on the SAME blob and
+    precision reproduces nerfart_volsdf_render_fwd bit for bit, every output; with the sampler at precision 4
+    (model.set_sampler_precision("fp16x2")) the final samples stay split-bf16: sdf / nabla / radiance at the chosen depths are
+    the bf16x3 kernels' own values, and the frame is close to the fused bf16x3 frame."""
+    from nerfart_amd import hip, scene, rend_util
+    model, rk, render_fn = scene.build_model("VolSDF", seed=0, beta=0.01, device=DEV, precision="bf16x3")
+    H, W = 48, 27
+    c2w, K = scene.camera(H, W)
+    o, d, _ = rend_util.get_rays(c2w[None].to(DEV), K[None].to(DEV), H, W)
+    surf, rad = model.packed()
+    alpha, beta = (float(t) for t in model.forward_ab())
+    kw = dict(near=0.0, far=6.0, R_bg=3.0, alpha=alpha, beta=beta, max_upsample_steps=6, detailed=True, precision=1)
+    fused = hip.volsdf_render(surf, rad, 1, o[0].contiguous(), d[0].contiguous(), **kw)
+    staged = hip.volsdf_render_mixed(surf, rad, surf, 1, 1, o[0].contiguous(), d[0].contiguous(), **kw)
+    assert set(fused) == set(staged)
+    for k in fused:
+        assert torch.equal(fused[k], staged[k]), k
+    rkk = {k: v for k, v in rk.items() if k != "rayschunk"}
+    rgb_f, _, _ = render_fn(o, d, require_nablas=True, calc_normal=True, detailed_output=False, **rkk)
+    model.set_sampler_precision("fp16x2")
+    rgb_m, depth_m, ex = render_fn(o, d, require_nablas=True, calc_normal=True, detailed_output=True, **rkk)
+    model.set_sampler_precision(None)
+    # the final samples are evaluated by the split-bf16 kernels at the depths the cheaper sampler chose
+    pts, _ = hip.ray_points(o[0].contiguous(), hip.normalize_dirs(d[0].contiguous()), ex["d_vals"][0].contiguous())
+    sdf, nab, _ = hip.sdf_nabla_fwd(surf, pts, 3.0, precision=1)
+    assert float((sdf.reshape(H * W, -1) - ex["implicit_surface"][0]).abs().max()) < 2e-5           # (precision 4 would be off by ~4e-4 here)
+    assert float((nab.reshape(H * W, -1, 3) - ex["implicit_nablas"][0]).abs().max()) < 1e-4
+    err = (rgb_m - rgb_f).abs().max(dim=-1).values
+    print(f"  bf16x3 with the fp16x2 sampler vs fused bf16x3, {H * W} rays: {int((err > 1e-3).sum())} past 1e-3, max {float(err.max()):.2e}")
+    assert float(err.max()) < 2e-2 and float((err > 1e-3).float().mean()) < 0.02

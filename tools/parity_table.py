@@ -32,12 +32,15 @@ def main():
     from oracle import render as orender
     dev = "cuda:0"
     H, W = 480, 270
-    precisions = [p for p in args.precisions.split(",") if p in hip.PRECISIONS]
+    MIXED = "bf16x3+fp16x2sampler"            # Algorithm 1 on the 2-MFMA kernels, the 192 final samples in split-bf16 (model.set_sampler_precision)
+    precisions = [p for p in args.precisions.split(",") if p in hip.PRECISIONS or p == MIXED]
     if "fp32" not in precisions:
         precisions = ["fp32"] + precisions
     angles = scene.spiral(90)
     out = {"frame": f"{H}x{W}, 128 + 64 spp, beta 0.01", "oracle_rays": args.rays, "csrc_sha256": hip.csrc_sha256(), "views": {}}
-    models = {p: scene.build_model("VolSDF", seed=0, beta=0.01, device=dev, precision=p) for p in precisions}
+    models = {p: scene.build_model("VolSDF", seed=0, beta=0.01, device=dev, precision="bf16x3" if p == MIXED else p) for p in precisions}
+    if MIXED in models:
+        models[MIXED][0].set_sampler_precision("fp16x2")
     sd = {k: v.detach().cpu() for k, v in models["fp32"][0].state_dict().items()}
     for view, ang in (("default", 0.0), ("bench_orbit_pose_1", angles[1])):
         c2w, K = scene.camera(H, W, angle=ang)
