@@ -171,7 +171,10 @@ def test_cfg2_bf16x3_full_frame_vs_oracle(view):
     budget of `pixel_budget` - hard 1e-3 on the rays whose sampling converged, a count budget on the never-converged ones - the same
     statistic at any sample size, so the figures bench.py prints for its own sample cannot contradict this test (round 3: a hard
     `max < 1e-3` over ALL rays held on 320 rays and failed on the bench's 1,792-ray sample, 2 never-converged rays at 1.8e-3).  The
-    exact-fp32 mode runs on the same rays: every ray the split-bf16 mode puts past 1e-3 is attributed (its fp32 error next to it)."""
+    exact-fp32 mode runs on the same rays: every ray the split-bf16 mode puts past 1e-3 is attributed (its fp32 error next to it).  So does
+    the mixed measurement variant (sampler at C-ABI precision 4, final samples split-bf16; +15 % frame rate): measured 4 / 1 rays past 1e-3,
+    all never-converged or flipped, 83.7 / 88.2 dB, 99.1 - 99.2 % identical rounds - inside the budget (the pure fp16x2 mode is not:
+    three CONVERGED rays at 1.0 - 1.2e-3; tests/test_gpu_fp16x2.py holds it to looser, own bounds)."""
     from nerfart_amd import scene, rend_util
     from oracle import render
     H, W = 480, 270
@@ -180,8 +183,11 @@ def test_cfg2_bf16x3_full_frame_vs_oracle(view):
     sel = torch.arange(0, H * W, (H * W) // n)[:n]
     sd, _ = scene_state("VolSDF", 0.01)
     res = {}
-    for precision in ("bf16x3", "fp32"):
-        model, rk, render_fn = scene.build_model("VolSDF", seed=0, beta=0.01, device=DEV, precision=precision)
+    MIXED = "bf16x3+fp16x2sampler"      # Algorithm 1 on the 2-MFMA kernels, the final samples in split-bf16: held to the SAME budget (it meets it)
+    for precision in ("bf16x3", "fp32", MIXED):
+        model, rk, render_fn = scene.build_model("VolSDF", seed=0, beta=0.01, device=DEV, precision="bf16x3" if precision == MIXED else precision)
+        if precision == MIXED:
+            model.set_sampler_precision("fp16x2")
         kw = {k: v for k, v in rk.items() if k != "rayschunk"}
         o, d, _ = rend_util.get_rays(c2w[None].to(DEV), K[None].to(DEV), H, W)
         rgb, depth, _ = render_fn(o, d, require_nablas=True, calc_normal=True, detailed_output=False, **kw)
