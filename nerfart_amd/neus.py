@@ -33,6 +33,8 @@ def volume_render(rays_o, rays_d, model: NeuS, obj_bounding_radius=1.0, batched=
     rd = rays_d.reshape(-1, 3).float().contiguous()
     N = ro.shape[0]
     surf_blob, rad_blob = model.packed()
+    if model.packed_sampler() is not None:
+        raise NotImplementedError("set_sampler_precision is a VolSDF measurement variant (Algorithm 1); NeuS's up-sampling runs at the model's precision")
     s = float(model.forward_s().detach())
     chunk = int(rayschunk) if rayschunk else DEFAULT_RAYSCHUNK
     parts = []
