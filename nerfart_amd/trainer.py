@@ -120,10 +120,13 @@ class Trainer(nn.Module):
         alpha, beta = m.forward_ab()
         ns, ni = rk.get("N_samples", 128), rk.get("N_importance", 64)
         near, far = rk.get("near", 0.0), rk.get("far", 6.0)
-        d_fine, _, _ = hip.volsdf_fine_sample(surf_blob, o, dn, near, far, rk.get("obj_bounding_radius", 3.0), float(alpha.detach()),
+        # model.set_sampler_precision(...): Algorithm 1 on its own blob / precision (it carries no gradient, volsdf.py:479; the per-sample
+        # state pass 2 differentiates is evaluated at the model's precision at whatever depths it returns)
+        samp_blob, samp_prec = m.packed_sampler() or (surf_blob, m.precision_id)
+        d_fine, _, _ = hip.volsdf_fine_sample(samp_blob, o, dn, near, far, rk.get("obj_bounding_radius", 3.0), float(alpha.detach()),
                                               float(beta.detach()), rk.get("epsilon", 0.1), 4 * ns, 4 * ns, ni,
                                               rk.get("max_upsample_steps", 5), rk.get("max_bisection_steps", 10),
-                                              precision=m.precision_id,
+                                              precision=samp_prec,
                                               u_final=torch.rand(o.shape[0], ni, device=o.device) if perturb else None)
         t = hip.lin_table(ns, o.device)
         d_coarse = (near * (1.0 - t) + far * t)[None, :].expand(o.shape[0], ns)

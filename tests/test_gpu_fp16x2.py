@@ -119,3 +119,27 @@ def test_staged_renderer_equals_the_fused_one_and_the_mixed_sampler_mode_renders
     err = (rgb_m - rgb_f).abs().max(dim=-1).values
     print(f"  bf16x3 with the fp16x2 sampler vs fused bf16x3, {H * W} rays: {int((err > 1e-3).sum())} past 1e-3, max {float(err.max()):.2e}")
     assert float(err.max()) < 2e-2 and float((err > 1e-3).float().mean()) < 0.02
+
+
+def test_finetune_step_with_the_fp16x2_sampler():
+    """Training with model.set_sampler_precision("fp16x2"): pass 1's sampler (no gradient, volsdf.py:479) runs on the 2-MFMA kernels, the
+    kept per-sample state and the whole pass 2 stay split-bf16; image and gradients stay close to the all-bf16x3 step (the samples move by
+    the sampler's arithmetic only)."""
+    from nerfart_amd import scene, rend_util
+    from nerfart_amd.trainer import Trainer
+    H, W = 24, 16
+    c2w, K = scene.camera(H, W)
+    o, d, _ = rend_util.get_rays(c2w[None].to(DEV), K[None].to(DEV), H, W)
+    target = torch.rand(1, H * W, 3, generator=torch.Generator().manual_seed(1)).to(DEV)
+    loss_fn = lambda pred, gt: ((pred - gt) ** 2).mean()
+    res = {}
+    for samp in (None, "fp16x2"):
+        model, rk, render_fn = scene.build_model("VolSDF", seed=0, beta=0.01, device=DEV, precision="bf16x3")
+        model.set_sampler_precision(samp)
+        model.zero_grad()
+        out = Trainer(model, pass2_rays=64).finetune_step(render_fn, o, d, target, H, loss_fn, **rk)
+        res[samp] = (out["rgb"], {n: p.grad.clone() for n, p in model.named_parameters()})
+    assert float((res[None][0] - res["fp16x2"][0]).abs().max()) < 2e-2
+    for n, g in res[None][1].items():
+        rel = float((res["fp16x2"][1][n] - g).norm() / (g.norm() + 1e-12))
+        assert rel < 0.1, (n, rel)
