@@ -302,6 +302,12 @@ def main():
             "mlp_kernel_ms_per_step": {k: round(v[0] / N_SEC, 2) for k, v in prof3.items()},
             "what": "configs[2]: volsdf_fangzhou_vangogh.yaml train step at 480x270 (render + CLIP directional / contrastive / PatchNCE + VGG "
                     "perceptual, backward, Adam), seeded random-weight CLIP ViT-B/32 + VGG16, perturb=False, split-bf16 kernels"}
+        # the same step with Algorithm 1 on the 2-MFMA kernels (model.set_sampler_precision: no gradient flows through the sampler, volsdf.py:479;
+        # the kept state and pass 2 stay split-bf16) - a measurement variant like secondary.bf16x3_with_fp16x2_sampler
+        ctx3["model"].set_sampler_precision("fp16x2")
+        m3b, loss3b, _, _ = bench_util.finetune_steps(ctx3, 2, warmup=1)
+        secondary["cfg3_finetune_step"]["with_fp16x2_sampler"] = {"value": round(sum(m3b), 4), "unit": "s/step", "steps": 2, "pass1_render_s": round(m3b[0], 4),
+                                                                  "pass2_render_bwd_s": round(m3b[2], 4), "loss": round(loss3b, 5)}
         del ctx3
         torch.cuda.empty_cache()
 

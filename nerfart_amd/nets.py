@@ -197,11 +197,14 @@ class _PackedModel(nn.Module):
         key = (self.sampler_precision,) + tuple((p.data_ptr(), p._version) for p in self.implicit_surface.parameters())
         if self._sampler_blob is None or self._sampler_blob[0] != key:
             s = self.implicit_surface
-            if self.sampler_precision == "fp32":
-                plan = packing.surface_plan(s.W, s.D, tuple(s.skips), s.embed_multires, s.W_geo_feat)
-            else:
-                plan = packing.surface_plan_bf16(s.W, s.D, tuple(s.skips), s.embed_multires, s.W_geo_feat,
-                                                 term="fp16" if self.sampler_precision == "fp16x2" else "bf16")
+            pkey = ("sampler", self.sampler_precision)
+            if pkey not in self._plans:                        # building a plan's index arrays takes ~0.1 s: once, not once per weight update
+                if self.sampler_precision == "fp32":
+                    self._plans[pkey] = packing.surface_plan(s.W, s.D, tuple(s.skips), s.embed_multires, s.W_geo_feat)
+                else:
+                    self._plans[pkey] = packing.surface_plan_bf16(s.W, s.D, tuple(s.skips), s.embed_multires, s.W_geo_feat,
+                                                                  term="fp16" if self.sampler_precision == "fp16x2" else "bf16")
+            plan = self._plans[pkey]
             sd = {k: v.detach() for k, v in self.state_dict().items()}
             with torch.no_grad():
                 blob = plan.pack(packing.surface_tensors(sd, D=s.D))
