@@ -207,7 +207,7 @@ def main():
                 "p999_abs": round(float(e2.flatten().kthvalue(int(0.999 * e2.numel())).values), 7),
                 "psnr_db": round(float(-10 * torch.log10(((b16_ - a32) ** 2).mean().clamp_min(1e-20))), 1)}
         # ... and the mixed variant: Algorithm 1 (the 512 (1 + rounds) no-gradient SDF queries per ray) on the 2-MFMA kernels, the 192 final
-        # samples - every number that reaches a pixel - in split-bf16 (nerfart_amd.hip.volsdf_render_mixed: the per-stage entry points)
+        # samples - every number that reaches a pixel - in split-bf16 (C entry point nerfart_volsdf_render_mixed_fwd)
         mmx, _, fmx = scene.build_model("VolSDF", seed=0, beta=args.beta, device=dev, precision="bf16x3")
         mmx.set_sampler_precision("fp16x2")
         bmx, _, _ = fmx(o_, d_, require_nablas=True, calc_normal=True, detailed_output=False, **kw)

@@ -193,6 +193,19 @@ int nerfart_volsdf_render_fwd(const float* surf_blob, const float* rad_blob, int
                               float* radiance_out, float* sigma_out, float* p_out, float* tau_out, float* beta_map_out,
                               float* iter_usage_out, void* workspace, long long workspace_bytes, void* stream);
 
+/* The same with Algorithm 1's SDF queries (the no-gradient sampling stage, volsdf.py:479: 512 (1 + rounds) queries per ray, 70 % of a frame) on
+ * their OWN blob and precision - e.g. precision 4 (the 2-MFMA kernels) for the sampler and precision 1 for the 192 final samples, whose sdf / nabla /
+ * radiance / compositing produce every number that reaches a pixel (+15 % frame rate inside the shipped mode's pixel budgets).  The
+ * workspace is nerfart_volsdf_render_workspace_bytes'.  nerfart_volsdf_render_fwd = this with (sampler_blob, sampler_precision) = (surf_blob, precision). */
+int nerfart_volsdf_render_mixed_fwd(const float* surf_blob, const float* rad_blob, int precision, const float* sampler_blob, int sampler_precision,
+                                    int view_tiles, const float* rays_o, const float* rays_d, int n_rays, float near_s, float far_s, float R_bg, float alpha,
+                                    float beta, float eps, int n_samples, int n_importance, int max_upsample_steps,
+                                    int max_bisection_steps, int white_bkgd, int k3_rays_chunk, const float* t_coarse_dev,
+                                    const float* t_init_dev, const float* u_up_dev, const float* u_final_dev, int u_final_per_ray,
+                                    float* rgb, float* depth, float* acc, float* normals, float* d_all_out, float* sdf_out, float* nabla_out,
+                                    float* radiance_out, float* sigma_out, float* p_out, float* tau_out, float* beta_map_out,
+                                    float* iter_usage_out, void* workspace, long long workspace_bytes, void* stream);
+
 /* ---- NeuS (models/frameworks/neus.py): up-sampling 'official_solution' :275-303, helpers :29-78,
  * volume_render :142-424; near_far_from_sphere utils/rend_util.py:168-186. */
 int nerfart_near_far_from_sphere(const float* rays_o, const float* rays_dn, int n_rays, float r, float* near,

@@ -544,7 +544,11 @@ long long nerfart_volsdf_render_workspace_bytes(int n_rays, int n_samples, int n
 // Renders n_rays rays (rays_d un-normalised, as get_rays returns them).  Outputs rgb [R,3], depth [R],
 // acc [R] always; every other output pointer may be null:  normals [R,3]; detailed per-sample
 // arrays d_all/sdf/sigma [R,P], nabla/radiance [R,P,3], p_i/tau [R,P-1]; beta_map/iter_usage [R].
-int nerfart_volsdf_render_fwd(const float* surf_blob, const float* rad_blob, int precision, int view_tiles, const float* rays_o,
+// sampler_blob / sampler_precision: the surface blob and precision Algorithm 1's SDF queries run on (the no-gradient sampling stage,
+// volsdf.py:479); the 192 final samples - sdf, nabla, radiance, compositing: every number that reaches a pixel - run on surf_blob /
+// rad_blob at `precision`.  nerfart_volsdf_render_fwd passes the same blob and precision for both.
+int nerfart_volsdf_render_mixed_fwd(const float* surf_blob, const float* rad_blob, int precision, const float* sampler_blob, int sampler_precision,
+                                    int view_tiles, const float* rays_o,
                               const float* rays_d, int n_rays, float near_s, float far_s, float R_bg, float alpha,
                               float beta, float eps, int n_samples, int n_importance, int max_upsample_steps,
                               int max_bisection_steps, int white_bkgd, int k3_rays_chunk, const float* t_coarse_dev,
@@ -554,6 +558,7 @@ int nerfart_volsdf_render_fwd(const float* surf_blob, const float* rad_blob, int
                               float* iter_usage_out, void* workspace, long long workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_rays <= 0) return 0;
+    if (!sampler_blob) { set_last_error("render: sampler_blob is NULL"); return 2; }
     if (n_samples < 2 || n_importance < 1 || k3_rays_chunk < 1) { set_last_error("render: bad sample counts"); return 2; }
     const int P = n_samples + n_importance;
     render_ws_t w;
@@ -567,7 +572,7 @@ int nerfart_volsdf_render_fwd(const float* surf_blob, const float* rad_blob, int
     float* iter_usage = iter_usage_out ? iter_usage_out : w.iter_usage;
 
     if (int rc = nerfart_normalize_dirs(rays_d, w.rays_dn, n_rays, stream)) return rc;
-    if (int rc = nerfart_volsdf_fine_sample(surf_blob, precision, rays_o, w.rays_dn, n_rays, nullptr, nullptr, near_s, far_s, R_bg,
+    if (int rc = nerfart_volsdf_fine_sample(sampler_blob, sampler_precision, rays_o, w.rays_dn, n_rays, nullptr, nullptr, near_s, far_s, R_bg,
                                             alpha, beta, eps, 4 * n_samples, 4 * n_samples, n_importance,
                                             max_upsample_steps, max_bisection_steps, t_init_dev, u_up_dev, u_final_dev,
                                             u_final_per_ray, w.d_fine, beta_map, iter_usage, w.sampler, (long long)w.sampler_bytes, stream)) return rc;
@@ -594,6 +599,21 @@ int nerfart_volsdf_render_fwd(const float* surf_blob, const float* rad_blob, int
     }
     return nerfart_volsdf_composite(n_rays, P, d_all, sdf, rad, nabla, alpha, beta, white_bkgd, rgb, depth, acc, normals,
                                     sigma_out, p_out, tau_out, stream);
+}
+
+int nerfart_volsdf_render_fwd(const float* surf_blob, const float* rad_blob, int precision, int view_tiles, const float* rays_o,
+                              const float* rays_d, int n_rays, float near_s, float far_s, float R_bg, float alpha,
+                              float beta, float eps, int n_samples, int n_importance, int max_upsample_steps,
+                              int max_bisection_steps, int white_bkgd, int k3_rays_chunk, const float* t_coarse_dev,
+                              const float* t_init_dev, const float* u_up_dev, const float* u_final_dev, int u_final_per_ray,
+                              float* rgb, float* depth, float* acc, float* normals, float* d_all_out, float* sdf_out, float* nabla_out,
+                              float* radiance_out, float* sigma_out, float* p_out, float* tau_out, float* beta_map_out,
+                              float* iter_usage_out, void* workspace, long long workspace_bytes, void* stream_) {
+    return nerfart_volsdf_render_mixed_fwd(surf_blob, rad_blob, precision, surf_blob, precision, view_tiles, rays_o, rays_d, n_rays, near_s, far_s, R_bg, alpha,
+                                           beta, eps, n_samples, n_importance, max_upsample_steps, max_bisection_steps, white_bkgd, k3_rays_chunk,
+                                           t_coarse_dev, t_init_dev, u_up_dev, u_final_dev, u_final_per_ray, rgb, depth, acc, normals, d_all_out, sdf_out,
+                                           nabla_out, radiance_out, sigma_out, p_out, tau_out, beta_map_out, iter_usage_out, workspace, workspace_bytes,
+                                           stream_);
 }
 
 }  // extern "C"

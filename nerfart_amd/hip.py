@@ -79,6 +79,7 @@ _SIGS = {
     "nerfart_radiance_bwd": (_i, [_p, _ll, _p, _p, _p, _p, _p, _p, _p]),
     "nerfart_volsdf_render_workspace_bytes": (_ll, [_i, _i, _i, _i, _i]),
     "nerfart_volsdf_render_fwd": (_i, [_p, _p, _i, _i, _p, _p, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i] + [_p] * 4 + [_i] + [_p] * 13 + [_p, _ll, _p]),
+    "nerfart_volsdf_render_mixed_fwd": (_i, [_p, _p, _i, _p, _i, _i, _p, _p, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i] + [_p] * 4 + [_i] + [_p] * 13 + [_p, _ll, _p]),
     "nerfart_near_far_from_sphere": (_i, [_p, _p, _i, _f, _p, _p, _p]),
     "nerfart_neus_upsample_step": (_i, [_i, _i, _i, _i, _f, _p, _p, _p, _i, _p, _p]),
     "nerfart_merge_sorted_pairs": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p]),
@@ -541,9 +542,10 @@ def weight_norm_bwd(dW, weight_v, weight_g):
 
 def volsdf_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, near, far, R_bg, alpha, beta, eps=0.1,
                   n_samples=128, n_importance=64, max_upsample_steps=5, max_bisection_steps=10, white_bkgd=False,
-                  calc_normal=True, detailed=False, k3_rays_chunk=8192, precision=0, u_final=None):
+                  calc_normal=True, detailed=False, k3_rays_chunk=8192, precision=0, u_final=None, sampler=None):
     """One chunk of rays through nerfart_volsdf_render_fwd.  Returns a dict of flat [R, ...] tensors.
-    u_final [R, n_importance]: uniform random numbers of the final samples (perturb=True); None: deterministic."""
+    u_final [R, n_importance]: uniform random numbers of the final samples (perturb=True); None: deterministic.
+    sampler = (surface blob, precision id): Algorithm 1 on its own blob / precision (nerfart_volsdf_render_mixed_fwd); None: the model's."""
     R = rays_o.shape[0]
     dev = rays_o.device
     P = n_samples + n_importance
@@ -560,8 +562,10 @@ def volsdf_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, near, far,
     nb = lib.nerfart_volsdf_render_workspace_bytes(R, n_samples, n_importance, max_upsample_steps, k3_rays_chunk)
     ws = _workspace(nb, dev)
     g = lambda k: _dev(det.get(k))
-    _check(lib.nerfart_volsdf_render_fwd(
-        _dev(surf_blob), _dev(rad_blob), int(precision), int(view_tiles), _dev(rays_o, name="rays_o"), _dev(rays_d, name="rays_d"), R,
+    samp_blob, samp_prec = sampler if sampler is not None else (surf_blob, precision)
+    _check(lib.nerfart_volsdf_render_mixed_fwd(
+        _dev(surf_blob), _dev(rad_blob), int(precision), _dev(samp_blob, name="sampler_blob"), int(samp_prec), int(view_tiles),
+        _dev(rays_o, name="rays_o"), _dev(rays_d, name="rays_d"), R,
         float(near), float(far), float(R_bg), float(alpha), float(beta), float(eps), n_samples, n_importance,
         max_upsample_steps, max_bisection_steps, int(bool(white_bkgd)), k3_rays_chunk,
         _dev(lin_table(n_samples, dev)), _dev(lin_table(4 * n_samples, dev)), _dev(lin_table(4 * n_samples + 2, dev)),
@@ -569,7 +573,7 @@ def volsdf_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, near, far,
         _dev(out["rgb"]), _dev(out["depth_volume"]), _dev(out["mask_volume"]), _dev(out.get("normals_volume")),
         g("d_vals"), g("implicit_surface"), g("implicit_nablas"), g("radiance"), g("sigma"), g("p_i"),
         g("visibility_weights"), g("beta_map"), g("iter_usage"), ws.data_ptr(), ws.numel(), _stream()),
-        "nerfart_volsdf_render_fwd")
+        "nerfart_volsdf_render_mixed_fwd")
     out.update(det)
     return out
 
@@ -577,8 +581,9 @@ def volsdf_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, near, far,
 def volsdf_render_mixed(surf_blob, rad_blob, sampler_blob, sampler_precision: int, view_tiles, rays_o, rays_d, *, near, far, R_bg, alpha, beta, eps=0.1,
                         n_samples=128, n_importance=64, max_upsample_steps=5, max_bisection_steps=10, white_bkgd=False, calc_normal=True,
                         detailed=False, k3_rays_chunk=8192, precision=1, u_final=None):
-    """volsdf_render with the SAMPLER (Algorithm 1: 512 (1 + rounds) SDF queries per ray, no gradient, volsdf.py:479) on another blob /
-    precision than the 192 final samples: the fused renderer's own stage sequence on the per-stage entry points.  The final samples -
+    """volsdf_render(..., sampler=(sampler_blob, sampler_precision)) restated on the PER-STAGE entry points, in the fused renderer's own order
+    (tests: the two must agree bit for bit, every output): the SAMPLER (Algorithm 1: 512 (1 + rounds) SDF queries per ray, no gradient,
+    volsdf.py:479) on another blob / precision than the 192 final samples.  The final samples -
     sdf, nabla, radiance, compositing, i.e. every number that reaches a pixel - run at `precision` on (surf_blob, rad_blob); only WHERE the
     64 fine samples sit comes from the cheaper arithmetic.  Same return dict as volsdf_render."""
     R = rays_o.shape[0]

@@ -51,15 +51,13 @@ def volume_render(rays_o, rays_d, model: VolSDF, near=0.0, far=6.0, obj_bounding
         # perturb (volsdf.py:122, rend_util.py:306-307): the 64 final samples invert the opacity CDF at uniform random numbers
         # instead of linspace(0, 1, 64); drawn here from torch's generator of the device, a row per ray
         u_final = torch.rand(min(chunk, N - i), N_importance, device=ro.device) if perturb else None
-        render_chunk = hip.volsdf_render
-        if sampler is not None:                            # measurement variant: Algorithm 1 on a cheaper arithmetic, final samples at the model's
-            render_chunk = lambda sb, rb, vt, o_, d_, **kw_: hip.volsdf_render_mixed(sb, rb, sampler[0], sampler[1], vt, o_, d_, **kw_)
-        parts.append(render_chunk(
+        # sampler: Algorithm 1 on its own blob / precision (model.set_sampler_precision; None = the model's): nerfart_volsdf_render_mixed_fwd
+        parts.append(hip.volsdf_render(
             surf_blob, rad_blob, model.view_tiles, ro[i:i + chunk], rd[i:i + chunk], near=near, far=far,
             R_bg=obj_bounding_radius, alpha=alpha, beta=beta, eps=epsilon, n_samples=N_samples,
             n_importance=N_importance, max_upsample_steps=max_upsample_steps,
             max_bisection_steps=max_bisection_steps, white_bkgd=white_bkgd, calc_normal=want_normal,
-            detailed=detailed_output, k3_rays_chunk=k3_rays_chunk, precision=model.precision_id, u_final=u_final))
+            detailed=detailed_output, k3_rays_chunk=k3_rays_chunk, precision=model.precision_id, u_final=u_final, sampler=sampler))
     ret = OrderedDict()
     order = ["rgb", "depth_volume", "mask_volume", "normals_volume", "implicit_surface", "implicit_nablas", "radiance",
              "alpha", "p_i", "visibility_weights", "d_vals", "sigma", "beta_map", "iter_usage"]

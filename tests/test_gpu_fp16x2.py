@@ -106,6 +106,15 @@ def test_staged_renderer_equals_the_fused_one_and_the_mixed_sampler_mode_renders
     assert set(fused) == set(staged)
     for k in fused:
         assert torch.equal(fused[k], staged[k]), k
+    # ... and with the sampler on the fp16 blob at precision 4: the C entry point nerfart_volsdf_render_mixed_fwd against the same stages one by one
+    model.set_sampler_precision("fp16x2")
+    samp = model.packed_sampler()
+    fused4 = hip.volsdf_render(surf, rad, 1, o[0].contiguous(), d[0].contiguous(), sampler=samp, **kw)
+    staged4 = hip.volsdf_render_mixed(surf, rad, samp[0], samp[1], 1, o[0].contiguous(), d[0].contiguous(), **kw)
+    for k in fused4:
+        assert torch.equal(fused4[k], staged4[k]), k
+    assert not torch.equal(fused4["d_vals"], fused["d_vals"])
+    model.set_sampler_precision(None)
     rkk = {k: v for k, v in rk.items() if k != "rayschunk"}
     rgb_f, _, _ = render_fn(o, d, require_nablas=True, calc_normal=True, detailed_output=False, **rkk)
     model.set_sampler_precision("fp16x2")
