@@ -57,8 +57,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--beta", type=float, default=0.01)
-    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="bf16x3",
-                    help="fp32: exact v_mfma_f32_16x16x4_f32; bf16x3: split-bf16 operands on v_mfma_f32_16x16x32_bf16")
+    ap.add_argument("--precision", choices=["fp32", "bf16x3", "fp16x2"], default="bf16x3",
+                    help="fp32: exact v_mfma_f32_16x16x4_f32; bf16x3 (the headline): split-bf16 operands on v_mfma_f32_16x16x32_bf16; fp16x2: the 2-MFMA "
+                         "measurement variant (C-ABI precision 4) as the primary of an EXPERIMENT line (tools/power_probe_precision.sh) - never the driver's")
     ap.add_argument("--shard", choices=["views", "tiles"], default="views",
                     help="N > 1: views = one view per rank per step (weak scaling, the primary line); tiles = one frame per step "
                          "sharded over the ranks in 2,048-ray tiles (strong scaling).  The other mode is reported as a secondary object.")
@@ -328,7 +329,7 @@ def main():
         achieved = flops_per_launch / avg_s / 1e12
         # bf16x3 issues 3 bf16 MFMAs per algorithmic product: priced against the dense bf16 MFMA peak
         peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
-        kname = "k_sdf_only" if args.precision == "fp32" else "k_sdf_only_bf16"
+        kname = "k_sdf_only" if args.precision == "fp32" else "k_sdf_only_bf16"      # (fp16x2: the same kernel name in namespace f16x2)
         roofline = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
                     "launches": int(launches), "avg_launch_ms": round(ms / launches, 4),
@@ -500,7 +501,8 @@ def main():
             "metric": "rays/sec at %dx%dx128spp VolSDF render" % (H, W),
             "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong" if primary_tiles else "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16x3 (f32 split into 2 bf16 terms, f32 accumulate)", "data": "synthetic",
+            "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (f32 split into 2 bf16 terms, f32 accumulate)",
+                                           "fp16x2": "fp16x2 (1 fp16 activation term x 2 fp16 weight terms, f32 accumulate) - EXPERIMENT, not the benchmark precision"}[args.precision], "data": "synthetic",
             "config": {"workload": ("configs[1]" if (H, W) == (480, 270) else "configs[4] frame size" if (H, W) == (960, 540) else "custom frame") +
                                    ": volsdf_fangzhou_nature.yaml dims, %dx%d rays/frame, 128 coarse + 64 fine " % (H, W) +
                                    "spp, pure renderer (no CLIP), synthetic random-weight scene beta=%g" % args.beta,
