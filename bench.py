@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py - rays/s of the VolSDF render hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]            (N > 1 without a launcher: re-runs itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" renders one 480 x 270 frame (129,600 rays, 128 coarse + 64 fine samples per ray, up to 6
@@ -51,6 +51,33 @@ PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0
 
 
+def launch_plan(n_gpus: int, env: dict, n_devices: int, argv: list, port: int = None):
+    """What `python bench.py --gpus N` has to do before anything else.  Returns one of
+      ("run", None)        this process is a rank (WORLD_SIZE set by a launcher) or N = 1: go on;
+      ("refuse", message)  the RCCL backend needs one visible device per rank and there are fewer (or WORLD_SIZE contradicts --gpus);
+      ("spawn", cmd)       N > 1 without a launcher: re-run THIS command line under torch.distributed.run, one process per GPU, rendezvous
+                           on 127.0.0.1 (the container hostname may not resolve); rank 0 of that job prints the one JSON line.
+    The driver may call `python3 bench.py --gpus 8` directly or through torch.distributed.run: both give the same job."""
+    backend = env.get("NERFART_BENCH_BACKEND", "nccl")
+    if "WORLD_SIZE" in env:
+        if int(env["WORLD_SIZE"]) != n_gpus:
+            return "refuse", f"--gpus {n_gpus} but the launcher set WORLD_SIZE={env['WORLD_SIZE']}"
+        if backend == "nccl" and n_gpus > 1 and n_devices < n_gpus:
+            return "refuse", f"--gpus {n_gpus} over RCCL needs {n_gpus} visible devices, this node shows {n_devices}"
+        return "run", None
+    if n_gpus <= 1:
+        return "run", None
+    if backend == "nccl" and n_devices < n_gpus:
+        return "refuse", (f"--gpus {n_gpus} over RCCL needs {n_gpus} visible devices, this node shows {n_devices} "
+                          "(NERFART_BENCH_BACKEND=gloo runs the N-rank path functionally on fewer devices; it is not a measurement)")
+    if port is None:
+        import socket
+        s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return "spawn", cmd
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,6 +99,15 @@ def main():
     global H, W
     H, W = (int(v) for v in args.frame.lower().split("x"))
 
+    what, arg = launch_plan(args.gpus, dict(os.environ), torch.cuda.device_count(), sys.argv[1:])
+    if what == "refuse":
+        print(f"bench.py: {arg}", file=sys.stderr, flush=True)
+        sys.exit(2)
+    if what == "spawn":
+        import subprocess
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(arg, env=env))
+
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -91,8 +127,18 @@ def main():
     else:
         dist = None
         torch.cuda.set_device(local)
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local)
+    # what the collective backend actually sees (goes into the JSON line: a curve point is only as good as its rank count)
+    ranks_seen = dist.get_world_size() if dist is not None else 1
+    my_dev = f"{torch.cuda.get_device_name(dev)} (cuda:{local})"
+    if dist is not None:
+        devices = [None] * ranks_seen
+        dist.all_gather_object(devices, my_dev)
+    else:
+        devices = [my_dev]
+    if ranks_seen != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the process group has {ranks_seen} ranks", file=sys.stderr, flush=True)
+        sys.exit(2)
 
     from nerfart_amd import scene, rend_util, hip, dist as nd
 
@@ -499,7 +545,9 @@ def main():
     if rank == 0:
         out = {
             "metric": "rays/sec at %dx%dx128spp VolSDF render" % (H, W),
-            "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "ranks_seen": ranks_seen,
+            "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else " (functional run, not a measurement)")) if dist is not None else None,
+            "devices": devices, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong" if primary_tiles else "weak",
             "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (f32 split into 2 bf16 terms, f32 accumulate)",
                                            "fp16x2": "fp16x2 (1 fp16 activation term x 2 fp16 weight terms, f32 accumulate) - EXPERIMENT, not the benchmark precision"}[args.precision], "data": "synthetic",

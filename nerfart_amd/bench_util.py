@@ -34,11 +34,17 @@ def finetune_setup(dev, H: int, W: int, beta: float = 0.01, with_vgg: bool = Tru
     return dict(model=model, rk=rk, render_fn=render_fn, o=o, d=d, style=style, target=target, trainer=tr, opt=opt, H=H, W=W)
 
 
-def finetune_steps(ctx, steps: int, warmup: int = 1, keep: bool = True, profile: bool = False):
+def finetune_steps(ctx, steps: int, warmup: int = 1, keep: bool = True, profile: bool = False, perturb: bool = False):
     """`warmup` untimed + `steps` timed fine-tune steps.  Returns (mean seconds of [pass 1, style, pass 2, adam], last loss, last
-    eikonal, launch-profile dict or None).  profile: nerfart_profile_begin / _end around the timed steps."""
+    eikonal, launch-profile dict or None).  profile: nerfart_profile_begin / _end around the timed steps.
+    perturb=True: the reference's default render_kwargs_train (volsdf.py:982) - pass 1 on the fused renderer with random final samples,
+    nothing kept; pass 2 runs the sampler AGAIN with fresh draws and re-evaluates the per-point state (Trainer.resamples)."""
     from . import hip
     tr, opt, o, d, rk, H, W = ctx["trainer"], ctx["opt"], ctx["o"], ctx["d"], ctx["rk"], ctx["H"], ctx["W"]
+    if perturb:
+        rk = dict(rk, perturb=True)
+    resample = tr.resamples(rk)
+    keep = keep and not resample
     to_img = lambda t: t.reshape(1, H, W, 3).permute(0, 3, 1, 2)
     times, loss, eik = [], None, None
     for it in range(warmup + steps):
@@ -49,6 +55,8 @@ def finetune_steps(ctx, steps: int, warmup: int = 1, keep: bool = True, profile:
         if keep:
             rgb, depths_all = tr.render_keep(o, d, **rk), None
             kept, tr._kept = tr._kept, None
+        elif resample:
+            rgb, depths_all, kept = tr.render_image(ctx["render_fn"], o, d, **rk), None, None
         else:
             rgb, depths_all = tr.render_image(ctx["render_fn"], o, d, want_depths=True, **rk)
             kept = None
@@ -67,3 +75,20 @@ def finetune_steps(ctx, steps: int, warmup: int = 1, keep: bool = True, profile:
     prof = hip.profile_end() if profile else None
     mean = [sum(x[i] for x in times) / len(times) for i in range(4)]
     return mean, float(loss.detach()), eik, prof
+
+
+def pass2_sampler_seconds(ctx, reps: int = 2, perturb: bool = True):
+    """Seconds the sampler ALONE takes over the frame in pass 2's batches (Trainer.pass1_groups launch groups per set of sampler
+    launches) - the part of a perturb=True step's pass 2 that a perturb=False step does not have."""
+    from . import hip
+    tr, o, d, rk = ctx["trainer"], ctx["o"].reshape(-1, 3), ctx["d"].reshape(-1, 3), dict(ctx["rk"], perturb=perturb)
+    P = rk.get("N_samples", 128) + rk.get("N_importance", 64)
+    big = tr._launch_rays(P) * tr.pass1_groups
+    ts = []
+    for _ in range(reps + 1):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        with torch.no_grad():
+            for i in range(0, o.shape[0], big):
+                tr._samples(o[i:i + big], hip.normalize_dirs(d[i:i + big].contiguous()), d[i:i + big], rk, 2, i)
+        torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    return sum(ts[1:]) / reps

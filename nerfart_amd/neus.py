@@ -22,7 +22,9 @@ def volume_render(rays_o, rays_d, model: NeuS, obj_bounding_radius=1.0, batched=
                   calc_normal=False, use_view_dirs=True, rayschunk=None, netchunk=1048576, white_bkgd=False,
                   near_bypass=None, far_bypass=None, detailed_output=True, show_progress=False, perturb=False,
                   fixed_s_recp=1 / 64., N_samples=64, N_importance=64, N_outside=0, upsample_algo="official_solution",
-                  N_nograd_samples=2048, N_upsample_iters=4, k3_rays_chunk=8192, **dummy_kwargs):
+                  N_nograd_samples=2048, N_upsample_iters=4, k3_rays_chunk=8192, uniforms=None, **dummy_kwargs):
+    """uniforms [N_rays, N_importance] (not a reference argument): with perturb=True, the uniform numbers of the up-sampling rounds
+    (round k reads columns k * N_importance / N_upsample_iters ...), a row per ray, instead of a fresh torch.rand."""
     if upsample_algo != "official_solution" or N_outside > 0 or near_bypass is not None or far_bypass is not None:
         raise NotImplementedError("NeuS render: only upsample_algo='official_solution', N_outside=0, no near/far "
                                   "bypass (the reference configs) are on the HIP path")
@@ -40,7 +42,10 @@ def volume_render(rays_o, rays_d, model: NeuS, obj_bounding_radius=1.0, batched=
     parts = []
     for i in range(0, N, chunk):
         # perturb (neus.py:296, rend_util.py:269-272): every up-sampling round inverts its CDF at uniform random numbers
-        u_new = torch.rand(min(chunk, N - i), N_importance, device=ro.device) if perturb else None
+        if perturb and uniforms is not None:
+            u_new = uniforms.reshape(N, N_importance)[i:i + chunk].to(device=ro.device, dtype=torch.float32).contiguous()
+        else:
+            u_new = torch.rand(min(chunk, N - i), N_importance, device=ro.device) if perturb else None
         parts.append(hip.neus_render(
             surf_blob, rad_blob, model.view_tiles, ro[i:i + chunk], rd[i:i + chunk],
             obj_bounding_radius=obj_bounding_radius, s=s, n_samples=N_samples, n_importance=N_importance,

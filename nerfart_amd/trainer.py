@@ -8,12 +8,18 @@
             rgb_patch.backward(d loss / d rgb[patch]); eikonal = w * MSE(|nabla|, 1) over the patch's nablas, backward.
     caller  optimizer.step()  (train.py:247); with N ranks: dist.allreduce_gradients first.
 
-Differences from the reference, all deliberate: native pass 2 evaluates the samples pass 1
-drew (their depths - and for VolSDF sdf / nablas / h7 - are kept in HBM; with perturb=False re-sampling would reproduce
-them, with perturb=True the reference draws NEW random samples in pass 2 for the gradient of a loss it evaluated on
-pass 1's: reusing them is the consistent estimator; `Trainer(native=False)` re-samples like the reference); several
-reference patches share one launch group (per-patch eikonal means kept); NeuS keeps `radiance_net` frozen exactly
-like neus.py:455-456.
+The two passes and `perturb` (volsdf.py:724-728, :759-766, :982; neus.py:520-576, :742): the reference calls its renderer with
+`render_kwargs_train` in BOTH passes, and `perturb` defaults to True there - pass 2 draws NEW uniform numbers for the 64 inverse-CDF
+samples of every ray and back-propagates d loss / d rgb (evaluated on pass 1's image) through THOSE samples.  This Trainer does the
+same: with perturb=True pass 1 keeps nothing, every group of pass 2 runs the sampler again with fresh draws and the ray-level
+backward re-evaluates the per-point state (`have_state = 0`).  With perturb=False re-sampling reproduces pass 1's samples exactly
+(same weights, deterministic sampler), so pass 1 keeps its depths - and for VolSDF sdf / nablas / h7 - in HBM and pass 2 reads them:
+the same numbers for one sampler and one forward evaluation less.  `Trainer(reuse_pass1_samples=True)` asks for that reuse under
+perturb=True as well (a deviation: the gradient is then taken at the samples the loss was evaluated on; INTEGRATION.md section F);
+`Trainer(resample_pass2=True / False)` forces either behaviour.
+
+Other differences from the reference, all deliberate: several reference patches share one launch group
+(per-patch eikonal means kept); NeuS keeps `radiance_net` frozen exactly like neus.py:455-456.
 """
 import warnings
 
@@ -31,7 +37,8 @@ _WARNED_AUTOGRAD = False
 
 class Trainer(nn.Module):
     def __init__(self, model, w_eikonal: float = 0.1, use_eikonal: bool = True, pass2_rays: int = 1200, native: bool = None,
-                 patches_per_launch: int = 4, freeze_radiance: bool = None, pass1_groups: int = 4):
+                 patches_per_launch: int = 4, freeze_radiance: bool = None, pass1_groups: int = 4, resample_pass2: bool = None,
+                 reuse_pass1_samples: bool = False):
         super().__init__()
         if not isinstance(model, (VolSDF, NeuS)):
             raise TypeError("Trainer expects a nerfart_amd VolSDF or NeuS model")
@@ -44,6 +51,15 @@ class Trainer(nn.Module):
         # the cross-check the native kernels are tested against, never chosen silently (it warns when it runs).
         self._native = native
         self._style_cfg = None
+        # pass 2 draws its own samples (the reference's semantics, volsdf.py:759-766): None = whenever render_kwargs['perturb'] is
+        # true (at perturb=False the sampler is deterministic and pass 1's samples ARE what pass 2 would draw: reused);
+        # reuse_pass1_samples=True: the explicit opt-in to reuse under perturb=True as well
+        if reuse_pass1_samples and resample_pass2:
+            raise ValueError("Trainer: reuse_pass1_samples=True contradicts resample_pass2=True")
+        self.resample_pass2, self.reuse_pass1_samples = resample_pass2, bool(reuse_pass1_samples)
+        # the uniform numbers of perturb=True: None = torch.rand on the device; a callable (pass_no, first_ray, n_rays, n, device) ->
+        # [n_rays, n] lets a test feed the draws the reference made (tests/golden/make_golden_finetune.py records them per pass)
+        self.uniform_source = None
         # native pass 2: this many of the reference's pass2_rays-ray patches share one set of kernel launches (the per-patch
         # eikonal means are kept); bounded by the kernels' 2^21 points per launch
         self.patches_per_launch = patches_per_launch
@@ -89,13 +105,32 @@ class Trainer(nn.Module):
             self.style_loss = criteria.build_style_loss(args, hw, device=next(self.model.parameters()).device)
         return getattr(self, "style_loss", None)
 
+    def resamples(self, render_kwargs) -> bool:
+        """Does pass 2 of a fine-tune step with these render kwargs run the sampler again (module docstring)?"""
+        if self.reuse_pass1_samples:
+            return False
+        if self.resample_pass2 is not None:
+            return bool(self.resample_pass2)
+        return bool(render_kwargs.get("perturb", False))
+
+    def _uniform(self, pass_no: int, first_ray: int, n_rays: int, n: int, device):
+        if self.uniform_source is not None:
+            u = self.uniform_source(pass_no, first_ray, n_rays, n, device)
+            if tuple(u.shape) != (n_rays, n):
+                raise ValueError(f"uniform_source returned {tuple(u.shape)}, expected {(n_rays, n)}")
+            return u.to(device=device, dtype=torch.float32).contiguous()
+        return torch.rand(n_rays, n, device=device)
+
     # ---- pass 1 ---------------------------------------------------------------------------------------
     @torch.no_grad()
     def render_image(self, render_fn, rays_o, rays_d, want_depths: bool = False, **render_kwargs):
-        """Pass 1.  want_depths: also return the sample depths [N, P] of every ray (with perturb=False and unchanged
-        weights pass 2 would re-derive exactly these - it can reuse them)."""
+        """Pass 1 on the fused renderer.  want_depths: also return the sample depths [N, P] of every ray (with perturb=False and
+        unchanged weights pass 2 would re-derive exactly these - it can reuse them)."""
         kw = dict(render_kwargs)
         kw.pop("rayschunk", None)
+        if kw.get("perturb", False) and self.uniform_source is not None:
+            n = rays_o.reshape(-1, 3).shape[0]
+            kw["uniforms"] = self._uniform(1, 0, n, kw.get("N_importance", 64), rays_o.device)
         rgb, depth, extras = render_fn(rays_o, rays_d, detailed_output=want_depths, require_nablas=True, calc_normal=True, **kw)
         if want_depths:
             d = extras["d_all" if self.is_neus else "d_vals"]
@@ -103,7 +138,7 @@ class Trainer(nn.Module):
         return rgb
 
     # ---- pass 2 ---------------------------------------------------------------------------------------
-    def _samples(self, o, dn, d_raw, rk):
+    def _samples(self, o, dn, d_raw, rk, pass_no: int = 2, first_ray: int = 0):
         """Sample depths of a patch (no grad): the HIP sampler.  perturb=True draws the uniform numbers of the inverse-CDF
         samples from torch's generator (a fresh draw per call, as the reference's two passes draw separately)."""
         m = self.model
@@ -115,7 +150,7 @@ class Trainer(nn.Module):
                                   s=float(m.forward_s().detach()), n_samples=rk.get("N_samples", 64),
                                   n_importance=ni, n_upsample_iters=rk.get("N_upsample_iters", 4),
                                   calc_normal=False, detailed=True, precision=m.precision_id,
-                                  u_new=torch.rand(o.shape[0], ni, device=o.device) if perturb else None)
+                                  u_new=self._uniform(pass_no, first_ray, o.shape[0], ni, o.device) if perturb else None)
             return out["d_all"]
         alpha, beta = m.forward_ab()
         ns, ni = rk.get("N_samples", 128), rk.get("N_importance", 64)
@@ -127,7 +162,7 @@ class Trainer(nn.Module):
                                               float(beta.detach()), rk.get("epsilon", 0.1), 4 * ns, 4 * ns, ni,
                                               rk.get("max_upsample_steps", 5), rk.get("max_bisection_steps", 10),
                                               precision=samp_prec,
-                                              u_final=torch.rand(o.shape[0], ni, device=o.device) if perturb else None)
+                                              u_final=self._uniform(pass_no, first_ray, o.shape[0], ni, o.device) if perturb else None)
         t = hip.lin_table(ns, o.device)
         d_coarse = (near * (1.0 - t) + far * t)[None, :].expand(o.shape[0], ns)
         return torch.sort(torch.cat([d_coarse, d_fine], dim=-1), dim=-1)[0]
@@ -162,7 +197,7 @@ class Trainer(nn.Module):
                                       s=s_val, n_samples=rk.get("N_samples", 64), n_importance=ni,
                                       n_upsample_iters=rk.get("N_upsample_iters", 4), white_bkgd=rk.get("white_bkgd", False),
                                       calc_normal=False, detailed=True, precision=m.precision_id,
-                                      u_new=torch.rand(oi.shape[0], ni, device=o.device) if rk.get("perturb", False) else None)
+                                      u_new=self._uniform(1, i, oi.shape[0], ni, o.device) if rk.get("perturb", False) else None)
                 kept.append((out["d_all"], out["implicit_surface"].reshape(-1), out["implicit_nablas"].reshape(-1, 3), None))
                 rgbs.append(out["rgb"])
             self._kept = kept
@@ -177,7 +212,7 @@ class Trainer(nn.Module):
         for i in range(0, o.shape[0], big):
             oi, di = o[i:i + big], d_raw[i:i + big]
             dn = hip.normalize_dirs(di)                                   # the kernel nerfart_volsdf_render_bwd normalises with: same points
-            depths = self._samples(oi, dn, di, rk).contiguous()           # one set of sampler launches for pass1_groups launch groups
+            depths = self._samples(oi, dn, di, rk, 1, i).contiguous()     # one set of sampler launches for pass1_groups launch groups
             for j in range(0, oi.shape[0], step):                         # pass 2's launch groups: their OWN tensors, freed group by group
                 dj = depths[j:j + step].contiguous()
                 Rj = dj.shape[0]
@@ -221,6 +256,7 @@ class Trainer(nn.Module):
             else:
                 step = self._launch_rays(P)
                 bounds = [(i, min(i + step, N)) for i in range(0, N, step)]
+            fresh, fresh_lo = None, 0                              # re-sampled depths of the current batch of launch groups
             for gi, (i0, i1) in enumerate(bounds):
                 o, d_raw, g = o_all[i0:i1], d_all_[i0:i1], g_all[i0:i1]
                 state = None
@@ -230,8 +266,14 @@ class Trainer(nn.Module):
                 elif depths_all is not None:
                     depths = depths_all[i0:i1].contiguous()
                 else:
-                    with torch.no_grad():
-                        depths = self._samples(o, hip.normalize_dirs(d_raw), d_raw, render_kwargs)
+                    # pass 2 draws its own samples (volsdf.py:759-766): ONE set of sampler launches per pass1_groups launch groups
+                    # (the sampler's rounds each cost a host read; its results do not depend on how rays are chunked)
+                    if fresh is None or i1 > fresh_lo + fresh.shape[0]:
+                        j1 = bounds[min(gi + self.pass1_groups, len(bounds)) - 1][1]
+                        with torch.no_grad():
+                            fresh = self._samples(o_all[i0:j1], hip.normalize_dirs(d_all_[i0:j1]), d_all_[i0:j1], render_kwargs, 2, i0)
+                        fresh_lo = i0
+                    depths = fresh[i0 - fresh_lo:i1 - fresh_lo].contiguous()
                 if self.is_neus:
                     eik = autodiff.neus_backward_samples_native(self.model, o, d_raw, depths, g, self.w_eikonal, self.use_eikonal, white,
                                                                 s_val=s_val, accum=accum, eik_group_rays=self.pass2_rays, state=state)
@@ -247,7 +289,7 @@ class Trainer(nn.Module):
             o, d_raw = o_all[i:i + self.pass2_rays], d_all_[i:i + self.pass2_rays]
             dn = F.normalize(d_raw, dim=-1)
             with torch.no_grad():
-                depths = self._samples(o, dn, d_raw, render_kwargs) if depths_all is None else depths_all[i:i + self.pass2_rays].contiguous()
+                depths = self._samples(o, dn, d_raw, render_kwargs, 2, i) if depths_all is None else depths_all[i:i + self.pass2_rays].contiguous()
             fn = autodiff.neus_render_samples if self.is_neus else autodiff.volsdf_render_samples
             out = fn(self.model, o, dn, depths, white_bkgd=white)
             if self.use_eikonal:
@@ -457,7 +499,8 @@ class Trainer(nn.Module):
         summation order."""
         sharded = nd.world_size() > 1
         tile = self.pass2_rays if tile is None else tile
-        keep = self.native                                # pass 1 keeps its per-point state for pass 2 (render_keep)
+        resample = self.resamples(render_kwargs)           # pass 2 draws its own samples (the reference under perturb=True)
+        keep = self.native and not resample                # pass 1 keeps its per-point state for pass 2 (render_keep)
         self._kept = None
         if sharded:
             kw = {k: v for k, v in render_kwargs.items() if k != "rayschunk"}
@@ -466,12 +509,17 @@ class Trainer(nn.Module):
                     r = self.render_keep(ro, rd, **kw_)
                     return r, None, {"rgb": r[None]}
             else:
-                fn = render_fn
+                def fn(ro, rd, **kw_):
+                    kw_ = {k: v for k, v in kw_.items() if k not in ("detailed_output", "require_nablas", "calc_normal")}
+                    r = self.render_image(render_fn, ro, rd, **kw_)
+                    return r, None, {"rgb": r.reshape(1, -1, 3)}
             rgb = nd.render_sharded(fn, rays_o.reshape(1, -1, 3), rays_d.reshape(1, -1, 3), keys=("rgb",), tile=tile,
                                     detailed_output=False, require_nablas=True, calc_normal=True, **kw)["rgb"]
             depths_all = None
         elif keep:
             rgb, depths_all = self.render_keep(rays_o, rays_d, **render_kwargs), None
+        elif resample:
+            rgb, depths_all = self.render_image(render_fn, rays_o, rays_d, **render_kwargs), None
         else:
             rgb, depths_all = self.render_image(render_fn, rays_o, rays_d, want_depths=True, **render_kwargs)
         rgb = rgb.detach().reshape(1, -1, 3).requires_grad_(True)

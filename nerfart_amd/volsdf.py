@@ -28,8 +28,10 @@ def volume_render(rays_o, rays_d, model: VolSDF, near=0.0, far=6.0, obj_bounding
                   batched_info=None, require_nablas=False, calc_normal=True, use_view_dirs=True, rayschunk=None,
                   netchunk=1048576, white_bkgd=False, use_nerfplusplus=False, detailed_output=True,
                   show_progress=False, perturb=False, N_samples=128, N_importance=64, N_outside=32,
-                  max_upsample_steps=5, max_bisection_steps=10, epsilon=0.1, k3_rays_chunk=8192, **dummy_kwargs):
-    """rays_o / rays_d: [(B,) N_rays, 3], rays_d un-normalised.  See module docstring."""
+                  max_upsample_steps=5, max_bisection_steps=10, epsilon=0.1, k3_rays_chunk=8192, uniforms=None, **dummy_kwargs):
+    """rays_o / rays_d: [(B,) N_rays, 3], rays_d un-normalised.  See module docstring.
+    uniforms [N_rays, N_importance] (not a reference argument): with perturb=True, the uniform numbers of the final inverse-CDF
+    samples, a row per ray, instead of a fresh torch.rand - how a test feeds the draws the reference made."""
     if use_nerfplusplus:
         raise NotImplementedError("outside_scene: nerf++ is outside the hot-path scope (SURVEY.md 2, row 19)")
     if not use_view_dirs:
@@ -50,7 +52,10 @@ def volume_render(rays_o, rays_d, model: VolSDF, near=0.0, far=6.0, obj_bounding
     for i in range(0, N, chunk):
         # perturb (volsdf.py:122, rend_util.py:306-307): the 64 final samples invert the opacity CDF at uniform random numbers
         # instead of linspace(0, 1, 64); drawn here from torch's generator of the device, a row per ray
-        u_final = torch.rand(min(chunk, N - i), N_importance, device=ro.device) if perturb else None
+        if perturb and uniforms is not None:
+            u_final = uniforms.reshape(N, N_importance)[i:i + chunk].to(device=ro.device, dtype=torch.float32).contiguous()
+        else:
+            u_final = torch.rand(min(chunk, N - i), N_importance, device=ro.device) if perturb else None
         # sampler: Algorithm 1 on its own blob / precision (model.set_sampler_precision; None = the model's): nerfart_volsdf_render_mixed_fwd
         parts.append(hip.volsdf_render(
             surf_blob, rad_blob, model.view_tiles, ro[i:i + chunk], rd[i:i + chunk], near=near, far=far,

@@ -9,6 +9,10 @@ checkpoints are not available offline; the style heads are pinned separately, te
 everything else is the reference's: pass 1, d loss / d rgb, pass 2 with rgb.backward(gradient) and the eikonal backward,
 the NeuS radiance net frozen by `fix_module`-style requires_grad (neus.py:455-456).  Stored: the style loss, the image of
 pass 1, and the gradient norm + leading 32 entries of every parameter that received one.
+
+Keys `FP_*`: the same call at perturb=True, the reference's default (volsdf.py:982, neus.py:742) - pass 2 then draws NEW samples for
+the gradient of a loss evaluated on pass 1's.  torch.rand is recorded while the reference runs; stored per pass: the uniform numbers
+as one [R, 64] table, the rendered rgb (and iter_usage), then the loss and the gradients as above.
 """
 import os
 import sys
@@ -81,6 +85,63 @@ def main():
             out[tag + "gradnorm_" + name] = p.grad.norm()
             out[tag + "gradhead_" + name] = p.grad.reshape(-1)[:32].clone()
         print(fw, "style loss", float(ret["losses"]), "parameters with gradients:", n)
+
+        # ---- the same call at the reference's DEFAULT perturb=True (volsdf.py:982, neus.py:742): both passes call the renderer with
+        # render_kwargs_train, so pass 2 draws NEW uniform numbers and back-propagates pass 1's d loss / d rgb through its own samples.
+        # torch.rand is recorded per renderer call and re-assembled into one [R, 64] table per pass (the form the C ABI takes).
+        from make_golden_perturb import RandRecorder
+        rk["perturb"] = True
+        R = H * W
+        calls = []
+        inner = trainer.renderer
+        orig_forward = inner.forward
+
+        def recording_forward(*a, **k):
+            n0 = len(rr.draws)
+            res = orig_forward(*a, **k)
+            calls.append((n0, len(rr.draws), res[0].detach().clone(), res[2]))
+            return res
+        inner.forward = recording_forward
+        torch.Tensor.to = lambda self, *a, **k: self if (a and isinstance(a[0], str) and a[0].startswith("cuda")) else orig_to(self, *a, **k)
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        try:
+            with RandRecorder() as rr, np.errstate(all="ignore"):
+                torch.manual_seed(5)
+                ret = trainer.forward(cfg, torch.tensor([0]), model_input, ground_truth, rk, 0, optimizer=opt)
+        finally:
+            torch.Tensor.to, torch.Tensor.cuda = orig_to, orig_cuda
+            del inner.forward
+        assert len(calls) == 2, len(calls)                      # pass 1 (one 64-ray chunk) and pass 2 (one 64-ray patch)
+        tag = f"FP_{fw}_"
+        for pno, (n0, n1, rgb_call, ex) in enumerate(calls, start=1):
+            draws = rr.draws[n0:n1]
+            if fw == "VolSDF":                                  # one draw per converged subset, rounds ascending, the never-converged rest last
+                usage = ex["iter_usage"][0].detach()
+                order = [k for k in sorted(set(usage.tolist()) - {-1.0})] + ([-1.0] if (usage == -1).any() else [])
+                assert len(order) == len(draws), (order, [tuple(x.shape) for x in draws])
+                u = torch.zeros(R, 64)
+                for k, dr in zip(order, draws):
+                    mk = usage == k
+                    assert int(mk.sum()) == dr.reshape(-1, 64).shape[0]
+                    u[mk] = dr.reshape(-1, 64)
+                out[tag + f"iter_usage_pass{pno}"] = usage
+            else:                                               # NeuS: one [R, 16] draw per up-sampling round
+                assert len(draws) == 4 and all(x.reshape(-1, 16).shape[0] == R for x in draws), [tuple(x.shape) for x in draws]
+                u = torch.cat([x.reshape(R, 16) for x in draws], dim=-1)
+            out[tag + f"u_pass{pno}"] = u
+            out[tag + f"rgb_pass{pno}"] = rgb_call[0]
+        assert not torch.equal(out[tag + "u_pass1"], out[tag + "u_pass2"])
+        out[tag + "render_kwargs"] = np.array(json.dumps({k: v for k, v in rk.items() if isinstance(v, (int, float, bool, str))}))
+        out[tag + "loss"] = ret["losses"].detach()
+        n = 0
+        for name, p in model.named_parameters():
+            if p.grad is None:
+                continue
+            n += 1
+            out[tag + "gradnorm_" + name] = p.grad.norm()
+            out[tag + "gradhead_" + name] = p.grad.reshape(-1)[:32].clone()
+        print(fw, "perturb=True: style loss", float(ret["losses"]), "parameters with gradients:", n,
+              "max |rgb pass 1 - rgb pass 2|", float((calls[0][2] - calls[1][2]).abs().max()))
     np.savez_compressed(os.path.join(HERE, "finetune_golden.npz"), **mg.t2n(out))
     print("wrote finetune_golden.npz")
 

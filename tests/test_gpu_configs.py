@@ -113,10 +113,15 @@ def _frame_checks(render_fn, rk, H, W, precision_name):
     return o, d, kw, rgb, depth, ex
 
 
-def test_cfg5_960x540_frame_properties_and_oracle_subset():
+SAMPLERS = [None, "fp16x2"]          # Algorithm 1 at the model's precision / on the 2-MFMA kernels (the mixed mode): both held to every bound here
+
+
+@pytest.mark.parametrize("sampler", SAMPLERS)
+def test_cfg5_960x540_frame_properties_and_oracle_subset(sampler):
     from nerfart_amd import scene
     from oracle import render
     model, rk, render_fn = scene.build_model("VolSDF", seed=0, beta=0.01, device=DEV, precision="bf16x3")
+    model.set_sampler_precision(sampler)
     H, W = 960, 540
     o, d, kw, rgb, depth, ex = _frame_checks(render_fn, rk, H, W, "bf16x3")
     sel = torch.arange(0, H * W, (H * W) // 64)[:64]
@@ -154,6 +159,8 @@ def pixel_budget(got, ref, label, stable=None, over_frac=2e-3, max_abs=5e-3, psn
     over = int((err > 1e-3).sum())
     psnr = -10 * np.log10(max(float(((got - ref) ** 2).mean()), 1e-20))
     p999 = float(err.kthvalue(max(1, int(0.999 * n))).values)
+    if stable is not None and not bool(stable.any()):
+        raise AssertionError((label, "no ray converged in the same rounds on both sides: nothing to hold to the hard bound"))
     st = "" if stable is None else f"; stable rays {int(stable.sum())}, max on them {float(err[stable].max()):.2e}"
     print(f"  {label}: {n} rays, {over} past 1e-3 ({100.0 * over / n:.3f} %), max {float(err.max()):.2e}, p99.9 {p999:.2e}, PSNR {psnr:.1f} dB{st}")
     if stable is not None:
@@ -206,6 +213,41 @@ def test_cfg2_bf16x3_full_frame_vs_oracle(view):
     for i in (errs["bf16x3"] > 1e-3).nonzero().flatten().tolist():
         print(f"    ray {int(sel[i])}: bf16x3 {float(errs['bf16x3'][i]):.2e}, fp32 {float(errs['fp32'][i]):.2e}; rounds oracle / bf16x3 / fp32 = "
               f"{float(ref['iter_usage'][i]):.0f} / {float(res['bf16x3'][2][i]):.0f} / {float(res['fp32'][2][i]):.0f}")
+
+
+@pytest.mark.parametrize("sampler", SAMPLERS)
+def test_cfg1_64x64_32spp_in_full_vs_oracle(sampler):
+    """BASELINE configs[0] IN FULL against the oracle: all 4,096 rays of the 64 x 64 frame at 32 coarse + 64 fine samples per ray.
+
+    32 spp starts Algorithm 1 from 128 initial samples: ~10 % of this frame's rays NEVER converge (iter_usage -1: they end on a bisected
+    beta+), and those are the rays any change of rounding moves - the CPU oracle moves 22 of them past 1e-3 (max 8.0e-3, 74.6 dB) when its
+    own SDF weights change by one fp32 ulp (profiles/r05_oracle_sensitivity_cfg1.json), zero among the converged.  So:
+      * HARD 1e-3 on every ray whose sampling converged on the CPU in the same number of rounds as on the GPU (the north-star statement
+        where it can hold), and those rays are >= 85 % of the frame;
+      * the rest: at most 1.5 % of the frame past 1e-3 (measured 0.8 % = 33 rays; the oracle against itself 22), none past 2e-2 (measured
+        9.8e-3), PSNR over the whole frame >= 70 dB (measured 73.7)."""
+    from nerfart_amd import scene, rend_util
+    from oracle import render
+    model, rk, render_fn = scene.build_model("VolSDF", seed=0, beta=0.01, device=DEV, precision="bf16x3")
+    model.set_sampler_precision(sampler)
+    H = W = 64
+    c2w, K = scene.camera(H, W)
+    o, d, _ = rend_util.get_rays(c2w[None].to(DEV), K[None].to(DEV), H, W)
+    kw = dict({k: v for k, v in rk.items() if k != "rayschunk"}, N_samples=32)
+    rgb, depth, ex = render_fn(o, d, require_nablas=True, calc_normal=True, detailed_output=True, **kw)
+    sd, _ = scene_state("VolSDF", 0.01)
+    with torch.no_grad():
+        ref = render.volsdf_render(sd, o[0].cpu(), d[0].cpu(), near=0.0, far=6.0, obj_bounding_radius=3.0, N_samples=32, N_importance=64,
+                                   max_upsample_steps=kw["max_upsample_steps"], chunk=4096)
+    usage = ex["iter_usage"][0].cpu()
+    same = usage == ref["iter_usage"]
+    stable = same & (ref["iter_usage"] >= 0)
+    print(f"  cfg 1 in full, sampler {sampler or 'bf16x3'}: never-converged rays (oracle) {int((ref['iter_usage'] < 0).sum())}, identical rounds on "
+          f"{float(same.float().mean()):.4f}, converged in the same rounds {int(stable.sum())} of {H * W}")
+    assert float(stable.float().mean()) >= 0.85
+    pixel_budget(rgb[0].cpu(), ref["rgb"], f"cfg 1 (64x64, 32 spp) vs oracle, sampler {sampler or 'bf16x3'}", stable=stable, over_frac=1.5e-2, max_abs=2e-2,
+                 psnr_min=70.0)
+    assert (depth[0].cpu() - ref["depth_volume"])[stable].abs().max() < 2e-2
 
 
 def _shard_worker(rank, world, port, out_dir):

@@ -137,3 +137,35 @@ def test_sharded_render_and_finetune_step_over_rccl(tmp_path):
     assert not errs, errs[0]
     assert done, "the RCCL workers did not finish within 10 minutes"
     assert len([f for f in os.listdir(tmp_path) if f.startswith("ok")]) == world
+
+
+def test_bench_gpus_2_without_a_launcher_prints_one_parsable_line():
+    """`python bench.py --gpus 2 --steps 1` exactly as the driver's N = 1 command is shaped, no torchrun around it: bench.py spawns the two
+    ranks itself (tests/test_bench_launcher.py: the decision), rank 0 prints ONE JSON line that says how many ranks the backend saw.
+    gloo on one GPU = a functional run of the N-rank code path (RCCL refuses two ranks on one device), not a measurement."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NERFART_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-secondary"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    js = json.loads(lines[0])
+    assert js["n_gpus"] == 2 and js["ranks_seen"] == 2 and js["backend"].startswith("gloo") and len(js["devices"]) == 2
+    assert js["steps"] == 1 and js["value"] > 0 and js["scaling"] == "weak"
+    assert js["config"]["rays_per_step_per_gpu"] == 480 * 270
+
+
+def test_bench_refuses_more_rccl_ranks_than_devices():
+    """`python bench.py --gpus N` over RCCL with fewer than N visible devices: rc 2 and a message - not an assertion trace, not a hang."""
+    import subprocess
+    import sys
+    n = torch.cuda.device_count() + 1
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NERFART_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and f"needs {n} visible devices" in r.stderr and "Traceback" not in r.stderr, (r.returncode, r.stderr[-1000:])

@@ -598,3 +598,82 @@ def test_finetune_branch_matches_the_reference_trainer(fw):
         assert rel < HEAD_TOL or float(head.norm()) < 1e-3 * gold_n, (name, rel)
     print(f"  fine-tune branch {fw}: worst gradient-norm error {worst_n:.2e}, worst leading-entries error {worst_h:.2e} (vs the reference Trainer)")
     assert n == (43 if fw == "VolSDF" else 28)
+
+
+def _grad_errors(model, z, tag):
+    """(number of parameters with a golden gradient, worst norm error, worst leading-entries error) of model.grad vs the goldens `tag`*."""
+    n, worst_n, worst_h = 0, 0.0, 0.0
+    for name, p in model.named_parameters():
+        key = tag + "gradnorm_" + name
+        if key not in z.files:
+            assert p.grad is None, name
+            continue
+        n += 1
+        gold_n = float(z[key])
+        head = torch.from_numpy(z[tag + "gradhead_" + name]).to(DEV)
+        got = p.grad.reshape(-1)[: head.numel()]
+        worst_n = max(worst_n, abs(float(p.grad.norm()) - gold_n) / (gold_n + 1e-12))
+        if float(head.norm()) >= 1e-3 * gold_n:
+            worst_h = max(worst_h, float((got - head).norm() / (head.norm() + 1e-12)))
+    return n, worst_n, worst_h
+
+
+@pytest.mark.parametrize("fw", ["VolSDF", "NeuS"])
+def test_finetune_branch_perturb_true_matches_the_reference_trainer(fw):
+    """The fine-tune branch at the reference's DEFAULT perturb=True (volsdf.py:982, neus.py:742; no shipped YAML overrides it): both passes
+    call the renderer with render_kwargs_train (volsdf.py:724-728, :759-766), so pass 2 draws NEW uniform numbers and back-propagates pass
+    1's d loss / d rgb through ITS OWN samples.  tests/golden/make_golden_finetune.py recorded the reference's torch.rand draws of both
+    passes (keys FP_*); fed through Trainer.uniform_source, the native step (pass 1 on the fused renderer, pass 2 = sampler again +
+    nerfart_*_render_bwd with have_state = 0) must reproduce the reference's pass-1 image, loss and gradients at the tolerances of the
+    perturb=False test - and the explicit opt-in `reuse_pass1_samples=True` must NOT (VolSDF: the two estimators differ by ~2 % in the
+    gradient norms, 4x the tolerance)."""
+    import json
+    import os
+    from conftest import state_checksum
+    from nerfart_amd import scene
+    from nerfart_amd.config import ConfigDict
+    from nerfart_amd.trainer import Trainer
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "finetune_golden.npz"))
+    tag = f"FP_{fw}_"
+    rk = json.loads(str(z[tag + "render_kwargs"]))
+    assert rk["perturb"] is True
+    args = ConfigDict({"training": ConfigDict({"is_finetune": True}), "finetune": ConfigDict({"w_eikonal": 0.1, "use_eikonal": True})})
+    model_input = {"intrinsics": torch.from_numpy(z["F_K"])[None], "c2w": torch.from_numpy(z["F_c2w"])[None]}
+    ground_truth = {"rgb": torch.from_numpy(z["F_target"])[None]}
+    tables = {1: torch.from_numpy(z[tag + "u_pass1"]), 2: torch.from_numpy(z[tag + "u_pass2"])}
+    results = {}
+    for mode in ("reference", "reuse"):
+        model, _, render_fn = scene.build_model(fw, seed=0, beta=0.01 if fw == "VolSDF" else None, device=DEV, precision="bf16x3")
+        assert state_checksum({k: v.detach().cpu() for k, v in model.state_dict().items()}) == str(z[f"F_{fw}_state_sha256"])
+        tr = Trainer(model, reuse_pass1_samples=(mode == "reuse"))
+        assert tr.resamples(rk) == (mode == "reference") and not tr.resamples(dict(rk, perturb=False))
+        asked = []
+
+        def source(pass_no, first, count, n, device, _asked=asked):
+            _asked.append((pass_no, first, count))
+            return tables[pass_no][first:first + count, :n].to(device)
+        tr.uniform_source = source
+        tr.render_fn = render_fn
+        seen = {}
+
+        def mse(pred, gt, _seen=seen):
+            _seen["rgb"] = pred.detach().permute(0, 2, 3, 1).reshape(-1, 3).cpu()
+            return ((pred - gt) ** 2).mean()
+        tr.style_loss = mse
+        opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=0.0)
+        ret = tr(args, torch.tensor([0]), model_input, ground_truth, rk, 0, optimizer=opt)
+        n, worst_n, worst_h = _grad_errors(model, z, tag)
+        results[mode] = (worst_n, worst_h)
+        print(f"  fine-tune branch {fw}, perturb=True, {mode}: draws asked {asked}; worst gradient-norm error {worst_n:.2e}, worst "
+              f"leading-entries error {worst_h:.2e}; pass-1 image max error {float((seen['rgb'] - torch.from_numpy(z[tag + 'rgb_pass1'])).abs().max()):.2e}")
+        assert n == (43 if fw == "VolSDF" else 28)
+        # pass 1's image and the loss: the same draws -> the reference's pass-1 samples (both modes)
+        np.testing.assert_allclose(seen["rgb"].numpy(), z[tag + "rgb_pass1"], atol=1e-3)
+        np.testing.assert_allclose(float(ret["losses"]), float(z[tag + "loss"]), rtol=2e-3)
+        if mode == "reference":
+            assert [a[0] for a in asked] == [1, 2], asked              # one draw per pass: pass 2 sampled again
+            assert worst_n <= NORM_TOL and worst_h < HEAD_TOL, (worst_n, worst_h)
+        else:
+            assert [a[0] for a in asked] == [1], asked                 # pass 2 reused pass 1's samples
+    if fw == "VolSDF":
+        assert results["reuse"][0] > 2 * NORM_TOL, ("re-using pass 1's samples is a different estimator under perturb=True", results)
