@@ -206,7 +206,7 @@ int nerfart_volsdf_render_mixed_fwd(const float* surf_blob, const float* rad_blo
                                     float* radiance_out, float* sigma_out, float* p_out, float* tau_out, float* beta_map_out,
                                     float* iter_usage_out, void* workspace, long long workspace_bytes, void* stream);
 
-/* ---- NeuS (models/frameworks/neus.py): up-sampling 'official_solution' :275-303, helpers :29-78,
+/* ---- NeuS (models/frameworks/neus.py): up-sampling 'official_solution' :275-303 ('direct_use' / 'direct_more' :242-269 below), helpers :29-78,
  * volume_render :142-424; near_far_from_sphere utils/rend_util.py:168-186. */
 int nerfart_near_far_from_sphere(const float* rays_o, const float* rays_dn, int n_rays, float r, float* near,
                                  float* far, void* stream);
@@ -229,6 +229,26 @@ int nerfart_neus_render_fwd(const float* surf_blob, const float* rad_blob, int p
 /* u_new_per_ray != 0 (perturb=True: sample_pdf(det=False), rend_util.py:269-272): u_new_dev is [n_rays, n_importance], the
  * caller's uniform random numbers - up-sampling round i uses columns [i * n_new, (i + 1) * n_new); 0: the shared
  * linspace(0, 1, n_new) table (u_new_dev [n_new] or NULL). */
+
+/* ABI 3: the other two up-sampling algorithms of neus.py (:242-269; `model.upsample_algo` in the YAML, :735) behind the same renderer.
+ *   upsample_algo 0 'official_solution' (= nerfart_neus_render_fwd), 1 'direct_use' (:242-255: all n_importance fine samples at once from the
+ *   coarse samples' own visibility weights sdf_to_w(sdf, 1 / fixed_s_recp), :47-63), 2 'direct_more' (:259-269: the same from n_nograd_samples
+ *   evenly spaced no-gradient samples).  For 1 and 2 n_upsample_iters is ignored and the uniform numbers are ONE table of n_importance values
+ *   (u_new_per_ray == 0: u_new_dev [n_importance] = linspace(0, 1, n_importance), or NULL) or [n_rays, n_importance].
+ *   t_nograd_dev: linspace(0, 1, n_nograd_samples) on the device or NULL (built inside: one stream synchronisation).
+ *   nerfart_neus_direct_upsample_step: one inversion (n bins with row stride cap -> n_new sorted samples per ray), the stage entry. */
+int nerfart_neus_direct_upsample_step(int n_rays, int n, int cap, int n_new, float inv_s, const float* d, const float* sdf,
+                                      const float* u_new, int u_new_stride, float* d_new, void* stream);
+long long nerfart_neus_render_algo_workspace_bytes(int n_rays, int n_samples, int n_importance, int k3_rays_chunk, int upsample_algo,
+                                                   int n_nograd_samples);
+int nerfart_neus_render_algo_fwd(const float* surf_blob, const float* rad_blob, int precision, int view_tiles, const float* rays_o,
+                                 const float* rays_d, int n_rays, float obj_bounding_radius, float s, int n_samples,
+                                 int n_importance, int n_upsample_iters, int upsample_algo, int n_nograd_samples, float fixed_s_recp,
+                                 int white_bkgd, int k3_rays_chunk,
+                                 const float* t_coarse_dev, const float* t_nograd_dev, const float* u_new_dev, int u_new_per_ray, float* rgb,
+                                 float* depth, float* acc, float* normals, float* d_all_out, float* sdf_out,
+                                 float* nabla_out, float* radiance_out, float* cdf_out, float* alpha_out, float* w_out,
+                                 float* d_mid_out, void* workspace, long long workspace_bytes, void* stream);
 
 /* ---- B4: CLIP ViT-B/32 image encoder (third-party `clip`: `model.encode_image(img)` of `clip.load("ViT-B/32", device="cuda")`,
  * reference call sites criteria/clip_loss.py:204-216, contrastive_loss.py:110-114, patchnce_loss.py:124-128) and its

@@ -1,4 +1,4 @@
-// neus_render.hip - NeuS sampler ('official_solution' up-sampling), compositor and render
+// neus_render.hip - NeuS sampler ('official_solution' / 'direct_use' / 'direct_more' up-sampling), compositor and render
 // orchestrator (reference models/frameworks/neus.py: cdf_Phi_s/sdf_to_alpha/alpha_to_w :29-78,
 // volume_render :142-424 with the up-sampling loop :275-303; utils/rend_util.py
 // near_far_from_sphere :168-186, sample_pdf :256-293).
@@ -29,6 +29,9 @@ __global__ void k_midpoints(const float* __restrict__ d, int P, int n_rays, floa
 
 // One up-sampling round (neus.py:279-296): slope-limited SDF estimate at the interval ends,
 // sigmoid CDF with fixed inv_s, alpha -> visibility weights, n_new inverse-CDF samples.
+// DIRECT ('direct_use' / 'direct_more', neus.py:242-269): the weights are sdf_to_w(sdf, s) of the bins themselves (:36-63): the
+// opacity of consecutive sigmoid CDFs, clamped at 0, no slope estimate.
+template <bool DIRECT>
 __global__ void __launch_bounds__(64)
 k_neus_upsample(int n, int cap, int n_new, float inv_s, const float* __restrict__ dA, const float* __restrict__ sA,
                 const float* __restrict__ u_new, int u_new_stride, float* __restrict__ d_new) {
@@ -42,16 +45,22 @@ k_neus_upsample(int n, int cap, int n_new, float inv_s, const float* __restrict_
     // alpha per interval -> w[k] (temporarily), local product of (1 - alpha + 1e-10)
     float lp = 1.f;
     for (int k = k0; k < k1; ++k) {
-        const float ps = s[k], ns = s[k + 1], pz = d[k], nz = d[k + 1];
-        const float mid = (ps + ns) * 0.5f;
-        const float dot = (ns - ps) / (nz - pz + 1e-5f);
-        float pdot = 0.f;
-        if (k > 0) pdot = (s[k] - s[k - 1]) / (d[k] - d[k - 1] + 1e-5f);
-        const float dv = fminf(fmaxf(fminf(pdot, dot), -10.f), 0.f);
-        const float dist = nz - pz;
-        const float pe = mid - dv * dist * 0.5f, ne = mid + dv * dist * 0.5f;
-        const float pc = sigmoidf_(pe * inv_s), nc = sigmoidf_(ne * inv_s);
-        const float a = (pc - nc + 1e-5f) / (pc + 1e-5f);
+        float a;
+        if (DIRECT) {
+            const float pc = sigmoidf_(s[k] * inv_s), nc = sigmoidf_(s[k + 1] * inv_s);
+            a = fmaxf((pc - nc) / (pc + 1e-10f), 0.f);
+        } else {
+            const float ps = s[k], ns = s[k + 1], pz = d[k], nz = d[k + 1];
+            const float mid = (ps + ns) * 0.5f;
+            const float dot = (ns - ps) / (nz - pz + 1e-5f);
+            float pdot = 0.f;
+            if (k > 0) pdot = (s[k] - s[k - 1]) / (d[k] - d[k - 1] + 1e-5f);
+            const float dv = fminf(fmaxf(fminf(pdot, dot), -10.f), 0.f);
+            const float dist = nz - pz;
+            const float pe = mid - dv * dist * 0.5f, ne = mid + dv * dist * 0.5f;
+            const float pc = sigmoidf_(pe * inv_s), nc = sigmoidf_(ne * inv_s);
+            a = (pc - nc + 1e-5f) / (pc + 1e-5f);
+        }
         w[k] = a;
         lp *= (1.f - a + 1e-10f);
     }
@@ -190,16 +199,29 @@ int nerfart_near_far_from_sphere(const float* rays_o, const float* rays_dn, int 
     return 0;
 }
 
-int nerfart_neus_upsample_step(int n_rays, int n, int cap, int n_new, float inv_s, const float* d, const float* sdf,
-                               const float* u_new, int u_new_stride, float* d_new, void* stream) {
+static int upsample_step(bool direct, int n_rays, int n, int cap, int n_new, float inv_s, const float* d, const float* sdf,
+                         const float* u_new, int u_new_stride, float* d_new, void* stream) {
     if (n_rays <= 0) return 0;
+    if (n < 2 || n_new < 1) { set_last_error("neus upsample: needs n >= 2 bins and n_new >= 1"); return 2; }
     if (n_new > 64 && (n_new & (n_new - 1))) { set_last_error("neus upsample: n_new must be <= 64 or a power of two"); return 2; }
     const int npad = n_new < 64 ? 64 : n_new;
     const size_t lds = ((size_t)4 * n + npad) * sizeof(float);
-    if (int rc = set_lds_n((const void*)k_neus_upsample, lds)) return rc;
-    hipLaunchKernelGGL(k_neus_upsample, dim3(n_rays), dim3(64), lds, (hipStream_t)stream, n, cap, n_new, inv_s, d, sdf, u_new, u_new_stride, d_new);
+    const void* fn = direct ? (const void*)k_neus_upsample<true> : (const void*)k_neus_upsample<false>;
+    if (int rc = set_lds_n(fn, lds)) return rc;
+    if (direct) hipLaunchKernelGGL(k_neus_upsample<true>, dim3(n_rays), dim3(64), lds, (hipStream_t)stream, n, cap, n_new, inv_s, d, sdf, u_new, u_new_stride, d_new);
+    else hipLaunchKernelGGL(k_neus_upsample<false>, dim3(n_rays), dim3(64), lds, (hipStream_t)stream, n, cap, n_new, inv_s, d, sdf, u_new, u_new_stride, d_new);
     NERFART_HIP(hipGetLastError());
     return 0;
+}
+
+int nerfart_neus_upsample_step(int n_rays, int n, int cap, int n_new, float inv_s, const float* d, const float* sdf,
+                               const float* u_new, int u_new_stride, float* d_new, void* stream) {
+    return upsample_step(false, n_rays, n, cap, n_new, inv_s, d, sdf, u_new, u_new_stride, d_new, stream);
+}
+
+int nerfart_neus_direct_upsample_step(int n_rays, int n, int cap, int n_new, float inv_s, const float* d, const float* sdf,
+                                      const float* u_new, int u_new_stride, float* d_new, void* stream) {
+    return upsample_step(true, n_rays, n, cap, n_new, inv_s, d, sdf, u_new, u_new_stride, d_new, stream);
 }
 
 int nerfart_merge_sorted_pairs(int n_rays, int n, int cap, int n_new, float* d, float* sdf, const float* d_new,
@@ -227,11 +249,12 @@ int nerfart_neus_composite(int n_rays, int P, const float* d_all, const float* s
 
 typedef struct {
     float *rays_dn, *near, *far, *t_coarse, *u_new, *d, *s, *d_new, *s_new, *d_mid, *sdf, *nabla, *nabla_mid, *sdf_mid, *rad, *h7;
+    float *t_more, *d_more, *s_more;   // 'direct_more': the N_nograd_samples table, depths and sdf of the no-gradient samples
     char* nabla_ws;           // softplus' scratch of the reverse-mode grad(SDF) kernel
     size_t nabla_ws_bytes;
 } neus_ws_t;
 
-static size_t carve_neus(char* base, int R, int n_samples, int n_imp, int k3_rays, neus_ws_t* w) {
+static size_t carve_neus(char* base, int R, int n_samples, int n_imp, int k3_rays, neus_ws_t* w, int n_more = 0) {
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += align_up_n(bytes); return base ? base + r : (char*)nullptr; };
     const int P = n_samples + n_imp;
@@ -257,6 +280,10 @@ static size_t carve_neus(char* base, int R, int n_samples, int n_imp, int k3_ray
     const size_t nb = (size_t)(nb0 > nb1 ? nb0 : nb1);
     char* np = take(nb);
     if (w) { w->nabla_ws = np; w->nabla_ws_bytes = nb; }
+    // (appended: the layout of everything above does not depend on the up-sampling algorithm)
+    p = (float*)take((size_t)n_more * 4); if (w) w->t_more = p;
+    p = (float*)take((size_t)R * n_more * 4); if (w) w->d_more = p;
+    p = (float*)take((size_t)R * n_more * 4); if (w) w->s_more = p;
     return o;
 }
 
@@ -264,25 +291,41 @@ long long nerfart_neus_render_workspace_bytes(int n_rays, int n_samples, int n_i
     return (long long)carve_neus(nullptr, n_rays, n_samples, n_importance, k3_rays_chunk, nullptr);
 }
 
-// NeuS volume_render for one chunk of rays (upsample_algo = 'official_solution', N_outside = 0).
+long long nerfart_neus_render_algo_workspace_bytes(int n_rays, int n_samples, int n_importance, int k3_rays_chunk, int upsample_algo,
+                                                   int n_nograd_samples) {
+    return (long long)carve_neus(nullptr, n_rays, n_samples, n_importance, k3_rays_chunk, nullptr, upsample_algo == 2 ? n_nograd_samples : 0);
+}
+
+// NeuS volume_render for one chunk of rays (N_outside = 0).  upsample_algo: 0 'official_solution' (neus.py:275-303: n_upsample_iters
+// rounds of n_importance / n_upsample_iters slope-estimated samples at s = 64 * 2^i), 1 'direct_use' (:242-255: all n_importance samples at
+// once from the coarse samples' own visibility weights at s = 1 / fixed_s_recp), 2 'direct_more' (:259-269: the same from n_nograd_samples
+// evenly spaced no-gradient samples).  u_new_dev: the uniform numbers - a shared table of n_new = n_importance / n_upsample_iters (algo 0)
+// or n_importance (algo 1, 2) values when u_new_per_ray == 0, else [n_rays, n_importance].  t_coarse_dev / t_nograd_dev: torch.linspace(0, 1,
+// n_samples / n_nograd_samples) on the device (nerfart_linspace) or NULL (built here, one stream synchronisation).
 // s = exp(ln_s * speed_factor).  Outputs as nerfart_volsdf_render_fwd; detailed outputs: d_all/sdf/cdf [R,P],
 // nabla [R,P,3], radiance/alpha/w/d_mid on the P-1 mid-points.
-int nerfart_neus_render_fwd(const float* surf_blob, const float* rad_blob, int precision, int view_tiles, const float* rays_o,
-                            const float* rays_d, int n_rays, float obj_bounding_radius, float s, int n_samples,
-                            int n_importance, int n_upsample_iters, int white_bkgd, int k3_rays_chunk,
-                            const float* t_coarse_dev, const float* u_new_dev, int u_new_per_ray, float* rgb,
-                            float* depth, float* acc, float* normals, float* d_all_out, float* sdf_out,
-                            float* nabla_out, float* radiance_out, float* cdf_out, float* alpha_out, float* w_out,
-                            float* d_mid_out, void* workspace, long long workspace_bytes, void* stream_) {
+int nerfart_neus_render_algo_fwd(const float* surf_blob, const float* rad_blob, int precision, int view_tiles, const float* rays_o,
+                                 const float* rays_d, int n_rays, float obj_bounding_radius, float s, int n_samples,
+                                 int n_importance, int n_upsample_iters, int upsample_algo, int n_nograd_samples, float fixed_s_recp,
+                                 int white_bkgd, int k3_rays_chunk,
+                                 const float* t_coarse_dev, const float* t_nograd_dev, const float* u_new_dev, int u_new_per_ray, float* rgb,
+                                 float* depth, float* acc, float* normals, float* d_all_out, float* sdf_out,
+                                 float* nabla_out, float* radiance_out, float* cdf_out, float* alpha_out, float* w_out,
+                                 float* d_mid_out, void* workspace, long long workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_rays <= 0) return 0;
+    if (upsample_algo < 0 || upsample_algo > 2) { set_last_error("neus render: upsample_algo must be 0 (official_solution), 1 (direct_use) or 2 (direct_more)"); return 2; }
+    if (upsample_algo != 0) n_upsample_iters = 1;                 // all n_importance samples in one inversion
     if (n_samples < 2 || n_upsample_iters < 1 || n_importance % n_upsample_iters || k3_rays_chunk < 1) {
         set_last_error("neus render: bad sample counts"); return 2;
     }
+    if (upsample_algo == 2 && n_nograd_samples < 2) { set_last_error("neus render: direct_more needs n_nograd_samples >= 2"); return 2; }
+    if (upsample_algo != 0 && !(fixed_s_recp > 0.f)) { set_last_error("neus render: fixed_s_recp must be positive"); return 2; }
     const int P = n_samples + n_importance, n_new = n_importance / n_upsample_iters;
+    const int n_more = upsample_algo == 2 ? n_nograd_samples : 0;
     if (u_new_per_ray && !u_new_dev) { set_last_error("neus render: u_new_per_ray needs u_new_dev [n_rays, n_importance]"); return 2; }
     neus_ws_t w;
-    const size_t need = carve_neus((char*)workspace, n_rays, n_samples, n_importance, k3_rays_chunk, &w);
+    const size_t need = carve_neus((char*)workspace, n_rays, n_samples, n_importance, k3_rays_chunk, &w, n_more);
     if (!workspace || (size_t)workspace_bytes < need) { set_last_error("neus render: workspace too small"); return 2; }
     float* sdf = sdf_out ? sdf_out : w.sdf;
     float* nabla = nabla_out ? nabla_out : w.nabla;
@@ -306,10 +349,36 @@ int nerfart_neus_render_fwd(const float* surf_blob, const float* rad_blob, int p
     if (int rc = nerfart_linspace_depths(w.t_coarse, n_samples, w.near, w.far, 0.f, 0.f, n_rays, w.d, P, stream)) return rc;
     if (int rc = nerfart_sdf_fwd_rays(surf_blob, precision, rays_o, w.rays_dn, nullptr, w.d, n_rays, n_samples, P, 0.f, w.s, P, stream)) return rc;
     int n = n_samples;
-    for (int i = 0; i < n_upsample_iters; ++i) {
-        if (int rc = nerfart_neus_upsample_step(n_rays, n, P, n_new, 64.f * (float)(1 << i), w.d, w.s,
-                                                u_new_per_ray ? w.u_new + (size_t)i * n_new : w.u_new, u_new_per_ray ? n_importance : 0,
-                                                w.d_new, stream)) return rc;
+    if (upsample_algo == 0) {
+        for (int i = 0; i < n_upsample_iters; ++i) {
+            if (int rc = nerfart_neus_upsample_step(n_rays, n, P, n_new, 64.f * (float)(1 << i), w.d, w.s,
+                                                    u_new_per_ray ? w.u_new + (size_t)i * n_new : w.u_new, u_new_per_ray ? n_importance : 0,
+                                                    w.d_new, stream)) return rc;
+            if (int rc = nerfart_sdf_fwd_rays(surf_blob, precision, rays_o, w.rays_dn, nullptr, w.d_new, n_rays, n_new, n_new, 0.f, w.s_new, n_new, stream)) return rc;
+            if (int rc = nerfart_merge_sorted_pairs(n_rays, n, P, n_new, w.d, w.s, w.d_new, w.s_new, stream)) return rc;
+            n += n_new;
+        }
+    } else {
+        const float* bins_d = w.d; const float* bins_s = w.s; int n_bins = n_samples, bins_cap = P;
+        if (upsample_algo == 2) {                                 // neus.py:260-263: N_nograd_samples evenly spaced samples, sdf without gradient
+            if (t_nograd_dev) {
+                w.t_more = const_cast<float*>(t_nograd_dev);
+            } else {
+                float* h = (float*)malloc(sizeof(float) * (size_t)n_more);
+                if (!h) { set_last_error("out of host memory"); return 3; }
+                nerfart_linspace(0.f, 1.f, n_more, h);
+                hipError_t e1 = hipMemcpyAsync(w.t_more, h, sizeof(float) * n_more, hipMemcpyHostToDevice, stream);
+                hipError_t e2 = hipStreamSynchronize(stream);
+                free(h);
+                NERFART_HIP(e1); NERFART_HIP(e2);
+            }
+            if (int rc = nerfart_linspace_depths(w.t_more, n_more, w.near, w.far, 0.f, 0.f, n_rays, w.d_more, n_more, stream)) return rc;
+            if (int rc = nerfart_sdf_fwd_rays(surf_blob, precision, rays_o, w.rays_dn, nullptr, w.d_more, n_rays, n_more, n_more, 0.f, w.s_more, n_more, stream)) return rc;
+            bins_d = w.d_more; bins_s = w.s_more; n_bins = n_more; bins_cap = n_more;
+        }
+        if (int rc = nerfart_neus_direct_upsample_step(n_rays, n_bins, bins_cap, n_new, 1.f / fixed_s_recp, bins_d, bins_s, w.u_new,
+                                                       u_new_per_ray ? n_importance : 0, w.d_new, stream)) return rc;
+        // d_all = sort(cat(d_coarse, d_fine)) (:254-255, :268-269); the fine samples' sdf rides along so that w.s stays the sdf row of w.d
         if (int rc = nerfart_sdf_fwd_rays(surf_blob, precision, rays_o, w.rays_dn, nullptr, w.d_new, n_rays, n_new, n_new, 0.f, w.s_new, n_new, stream)) return rc;
         if (int rc = nerfart_merge_sorted_pairs(n_rays, n, P, n_new, w.d, w.s, w.d_new, w.s_new, stream)) return rc;
         n += n_new;
@@ -323,7 +392,9 @@ int nerfart_neus_render_fwd(const float* surf_blob, const float* rad_blob, int p
     // sdf + nablas at the P sample points (neus.py:320).  The nablas feed only normals_volume and the detailed output (:385-392):
     // when neither is asked for, the sampler's own sdf row IS the result - the same network at the same sorted depths, evaluated by
     // K2 during the up-sampling rounds (the reverse-mode kernel's forward sweep is K2's arithmetic) - and no launch is needed
-    if (normals || nabla_out) {
+    // (only at precision 1, where the two kernels' forward sweeps are the same code and tests hold the pixels bit-identical; elsewhere the
+    // samples' sdf always comes from the SDF + nabla kernel, so pixels never depend on calc_normal)
+    if (normals || nabla_out || precision != 1) {
         if (int rc = nerfart_sdf_nabla_fwd_rays(surf_blob, precision, rays_o, w.rays_dn, nullptr, w.d, n_rays, P, P, 0.f, sdf, nabla, nullptr, w.nabla_ws, (long long)w.nabla_ws_bytes, stream)) return rc;
     } else {
         NERFART_HIP(hipMemcpyAsync(sdf, w.s, sizeof(float) * (size_t)n_rays * P, hipMemcpyDeviceToDevice, stream));
@@ -339,6 +410,20 @@ int nerfart_neus_render_fwd(const float* surf_blob, const float* rad_blob, int p
     }
     return nerfart_neus_composite(n_rays, P, w.d, sdf, rad, nabla, s, white_bkgd, rgb, depth, acc, normals, cdf_out,
                                   alpha_out, w_out, d_mid_out, stream);
+}
+
+// upsample_algo = 'official_solution' (what the four shipped configs use): the entry point of ABI versions 1 - 2.
+int nerfart_neus_render_fwd(const float* surf_blob, const float* rad_blob, int precision, int view_tiles, const float* rays_o,
+                            const float* rays_d, int n_rays, float obj_bounding_radius, float s, int n_samples,
+                            int n_importance, int n_upsample_iters, int white_bkgd, int k3_rays_chunk,
+                            const float* t_coarse_dev, const float* u_new_dev, int u_new_per_ray, float* rgb,
+                            float* depth, float* acc, float* normals, float* d_all_out, float* sdf_out,
+                            float* nabla_out, float* radiance_out, float* cdf_out, float* alpha_out, float* w_out,
+                            float* d_mid_out, void* workspace, long long workspace_bytes, void* stream_) {
+    return nerfart_neus_render_algo_fwd(surf_blob, rad_blob, precision, view_tiles, rays_o, rays_d, n_rays, obj_bounding_radius, s, n_samples,
+                                        n_importance, n_upsample_iters, 0, 0, 1.f / 64.f, white_bkgd, k3_rays_chunk, t_coarse_dev, nullptr, u_new_dev,
+                                        u_new_per_ray, rgb, depth, acc, normals, d_all_out, sdf_out, nabla_out, radiance_out, cdf_out, alpha_out,
+                                        w_out, d_mid_out, workspace, workspace_bytes, stream_);
 }
 
 }  // extern "C"

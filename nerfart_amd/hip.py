@@ -86,6 +86,9 @@ _SIGS = {
     "nerfart_neus_composite": (_i, [_i, _i, _p, _p, _p, _p, _f, _i] + [_p] * 9),
     "nerfart_neus_render_workspace_bytes": (_ll, [_i, _i, _i, _i]),
     "nerfart_neus_render_fwd": (_i, [_p, _p, _i, _i, _p, _p, _i, _f, _f, _i, _i, _i, _i, _i] + [_p] * 2 + [_i] + [_p] * 12 + [_p, _ll, _p]),
+    "nerfart_neus_direct_upsample_step": (_i, [_i, _i, _i, _i, _f, _p, _p, _p, _i, _p, _p]),
+    "nerfart_neus_render_algo_workspace_bytes": (_ll, [_i, _i, _i, _i, _i, _i]),
+    "nerfart_neus_render_algo_fwd": (_i, [_p, _p, _i, _i, _p, _p, _i, _f, _f, _i, _i, _i, _i, _i, _f, _i, _i] + [_p] * 3 + [_i] + [_p] * 12 + [_p, _ll, _p]),
     "nerfart_clip_vitb32_blob_layout": (_ll, [_p]),
     "nerfart_clip_vitb32_workspace_bytes": (_ll, [_i, _i]),
     "nerfart_clip_vitb32_image_fwd": (_i, [_p, _ll, _p, _i, _p, _i, _p, _ll, _p]),
@@ -623,14 +626,21 @@ def volsdf_render_mixed(surf_blob, rad_blob, sampler_blob, sampler_precision: in
     return out
 
 
+NEUS_UPSAMPLE_ALGOS = {"official_solution": 0, "direct_use": 1, "direct_more": 2}      # neus.py:242-303
+
+
 def neus_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, obj_bounding_radius, s, n_samples=64, n_importance=64,
                 n_upsample_iters=4, white_bkgd=False, calc_normal=True, detailed=False, k3_rays_chunk=8192, precision=0,
-                u_new=None):
-    """One chunk of rays through nerfart_neus_render_fwd.  u_new [R, n_importance]: uniform random numbers of the
-    up-sampling rounds (perturb=True; round i takes columns i * n_new ..); None: deterministic."""
+                u_new=None, upsample_algo="official_solution", n_nograd_samples=2048, fixed_s_recp=1 / 64.):
+    """One chunk of rays through nerfart_neus_render_algo_fwd.  u_new [R, n_importance]: uniform random numbers of the
+    up-sampling (perturb=True; 'official_solution': round i takes columns i * n_new ..; 'direct_use' / 'direct_more': one inversion
+    of all n_importance); None: deterministic."""
     R = rays_o.shape[0]
     dev = rays_o.device
     P = n_samples + n_importance
+    if upsample_algo not in NEUS_UPSAMPLE_ALGOS:
+        raise ValueError(f"upsample_algo must be one of {list(NEUS_UPSAMPLE_ALGOS)}")
+    algo = NEUS_UPSAMPLE_ALGOS[upsample_algo]
     if u_new is not None and tuple(u_new.shape) != (R, n_importance):
         raise ValueError(f"u_new must be [{R}, {n_importance}]")
     f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
@@ -641,15 +651,18 @@ def neus_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, obj_bounding
     if detailed:
         det = {"d_all": f(R, P), "implicit_surface": f(R, P), "implicit_nablas": f(R, P, 3), "radiance": f(R, P - 1, 3),
                "cdf": f(R, P), "alpha": f(R, P - 1), "visibility_weights": f(R, P - 1), "d_final": f(R, P - 1)}
-    nb = lib.nerfart_neus_render_workspace_bytes(R, n_samples, n_importance, k3_rays_chunk)
+    nb = lib.nerfart_neus_render_algo_workspace_bytes(R, n_samples, n_importance, k3_rays_chunk, algo, int(n_nograd_samples))
     ws = _workspace(nb, dev)
     g = lambda k: _dev(det.get(k))
-    _check(lib.nerfart_neus_render_fwd(
+    n_new = n_importance // n_upsample_iters if algo == 0 else n_importance
+    _check(lib.nerfart_neus_render_algo_fwd(
         _dev(surf_blob), _dev(rad_blob), int(precision), int(view_tiles), _dev(rays_o, name="rays_o"), _dev(rays_d, name="rays_d"), R,
-        float(obj_bounding_radius), float(s), n_samples, n_importance, n_upsample_iters, int(bool(white_bkgd)), k3_rays_chunk,
-        _dev(lin_table(n_samples, dev)), _dev(lin_table(n_importance // n_upsample_iters, dev) if u_new is None else u_new, name="u_new"),
+        float(obj_bounding_radius), float(s), n_samples, n_importance, n_upsample_iters, algo, int(n_nograd_samples), float(fixed_s_recp),
+        int(bool(white_bkgd)), k3_rays_chunk,
+        _dev(lin_table(n_samples, dev)), _dev(lin_table(int(n_nograd_samples), dev) if algo == 2 else None),
+        _dev(lin_table(n_new, dev) if u_new is None else u_new, name="u_new"),
         int(u_new is not None), _dev(out["rgb"]), _dev(out["depth_volume"]), _dev(out["mask_volume"]), _dev(out.get("normals_volume")),
         g("d_all"), g("implicit_surface"), g("implicit_nablas"), g("radiance"), g("cdf"), g("alpha"),
-        g("visibility_weights"), g("d_final"), ws.data_ptr(), ws.numel(), _stream()), "nerfart_neus_render_fwd")
+        g("visibility_weights"), g("d_final"), ws.data_ptr(), ws.numel(), _stream()), "nerfart_neus_render_algo_fwd")
     out.update(det)
     return out

@@ -1,8 +1,8 @@
 """NeuS renderer with the reference's boundary (models/frameworks/neus.py:142-432), on the HIP library.
 
 ``volume_render(rays_o, rays_d, model, **kw) -> (rgb, depth, extras)``; ``extras`` carries the reference's
-keys (:384-407).  upsample_algo must be 'official_solution' (the only one the configs use) and
-N_outside = 0 (configs: ``outside_scene`` absent, ``with_mask: True``).
+keys (:384-407).  upsample_algo: 'official_solution' (the one the shipped configs use, :275-303), 'direct_use' (:242-255), 'direct_more'
+(:259-269); N_outside = 0 (configs: ``outside_scene`` absent, ``with_mask: True``).
 """
 from __future__ import annotations
 
@@ -25,9 +25,10 @@ def volume_render(rays_o, rays_d, model: NeuS, obj_bounding_radius=1.0, batched=
                   N_nograd_samples=2048, N_upsample_iters=4, k3_rays_chunk=8192, uniforms=None, **dummy_kwargs):
     """uniforms [N_rays, N_importance] (not a reference argument): with perturb=True, the uniform numbers of the up-sampling rounds
     (round k reads columns k * N_importance / N_upsample_iters ...), a row per ray, instead of a fresh torch.rand."""
-    if upsample_algo != "official_solution" or N_outside > 0 or near_bypass is not None or far_bypass is not None:
-        raise NotImplementedError("NeuS render: only upsample_algo='official_solution', N_outside=0, no near/far "
-                                  "bypass (the reference configs) are on the HIP path")
+    if upsample_algo not in hip.NEUS_UPSAMPLE_ALGOS:
+        raise NotImplementedError(f"upsample_algo {upsample_algo!r} (neus.py:303: the reference raises too)")
+    if N_outside > 0 or near_bypass is not None or far_bypass is not None:
+        raise NotImplementedError("NeuS render: N_outside=0, no near/far bypass (the reference configs) are on the HIP path")
     if not use_view_dirs:
         raise NotImplementedError("use_view_dirs=False is not used by any reference config")
     lead = rays_o.shape[:-1]
@@ -50,7 +51,8 @@ def volume_render(rays_o, rays_d, model: NeuS, obj_bounding_radius=1.0, batched=
             surf_blob, rad_blob, model.view_tiles, ro[i:i + chunk], rd[i:i + chunk],
             obj_bounding_radius=obj_bounding_radius, s=s, n_samples=N_samples, n_importance=N_importance,
             n_upsample_iters=N_upsample_iters, white_bkgd=white_bkgd, calc_normal=calc_normal,
-            detailed=detailed_output, k3_rays_chunk=k3_rays_chunk, precision=model.precision_id, u_new=u_new))
+            detailed=detailed_output, k3_rays_chunk=k3_rays_chunk, precision=model.precision_id, u_new=u_new,
+            upsample_algo=upsample_algo, n_nograd_samples=N_nograd_samples, fixed_s_recp=fixed_s_recp))
     ret = OrderedDict()
     for k in ["rgb", "depth_volume", "mask_volume", "normals_volume", "implicit_nablas", "implicit_surface", "radiance",
               "alpha", "cdf", "visibility_weights", "d_final", "d_all"]:      # d_all: the P sample depths (an extra key)
@@ -92,6 +94,9 @@ def get_model(args, render_target=None):
         "D": r.setdefault("D", 4), "W": r.setdefault("W", 256), "skips": r.setdefault("skips", []),
     }
     model = NeuS(**model_config)
+    # the arithmetic of the kernels (not a reference key; `model.precision` in the YAML or --model:precision overrides it): 'mixed' = the
+    # shipped mode (nets._PackedModel.set_precision) - a model from get_model renders AND trains without a further call
+    model.set_precision(m.get("precision", "mixed"))
     render_kwargs_train = {
         "upsample_algo": m.setdefault("upsample_algo", "official_solution"),
         "N_nograd_samples": m.setdefault("N_nograd_samples", 2048),

@@ -58,7 +58,8 @@ def perturb_state(sd: dict, beta: float | None = 0.01, speed_factor: float = 10.
 
 
 def build_model(framework: str = "VolSDF", seed: int = 0, beta: float | None = 0.01, device=None, precision: str = "fp32"):
-    """(model, render_kwargs_test, render_fn) with the synthetic scene's weights."""
+    """(model, render_kwargs_test, render_fn) with the synthetic scene's weights.  precision: 'fp32' (the default HERE: what the exact-parity
+    tests ask for), 'bf16x3', 'mixed' (the product's default, frameworks.get_model), 'fp16x2' - nets._PackedModel.set_precision."""
     from .frameworks import get_model
     cfg = synthetic_config(framework)
     torch.manual_seed(seed)

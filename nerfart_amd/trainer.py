@@ -149,7 +149,7 @@ class Trainer(nn.Module):
             out = hip.neus_render(surf_blob, rad_blob, m.view_tiles, o, d_raw, obj_bounding_radius=rk.get("obj_bounding_radius", 1.0),
                                   s=float(m.forward_s().detach()), n_samples=rk.get("N_samples", 64),
                                   n_importance=ni, n_upsample_iters=rk.get("N_upsample_iters", 4),
-                                  calc_normal=False, detailed=True, precision=m.precision_id,
+                                  calc_normal=False, detailed=True, precision=m.precision_id, **self._neus_algo(rk),
                                   u_new=self._uniform(pass_no, first_ray, o.shape[0], ni, o.device) if perturb else None)
             return out["d_all"]
         alpha, beta = m.forward_ab()
@@ -166,6 +166,12 @@ class Trainer(nn.Module):
         t = hip.lin_table(ns, o.device)
         d_coarse = (near * (1.0 - t) + far * t)[None, :].expand(o.shape[0], ns)
         return torch.sort(torch.cat([d_coarse, d_fine], dim=-1), dim=-1)[0]
+
+    @staticmethod
+    def _neus_algo(rk) -> dict:
+        """The up-sampling algorithm of the NeuS render kwargs (neus.py:733-736) in hip.neus_render's terms."""
+        return dict(upsample_algo=rk.get("upsample_algo", "official_solution"), n_nograd_samples=rk.get("N_nograd_samples", 2048),
+                    fixed_s_recp=rk.get("fixed_s_recp", 1 / 64.))
 
     def _launch_rays(self, P: int) -> int:
         k = max(1, min(self.patches_per_launch, (1 << 21) // max(self.pass2_rays * P, 1)))
@@ -196,7 +202,7 @@ class Trainer(nn.Module):
                 out = hip.neus_render(surf_blob, rad_blob, m.view_tiles, oi, di, obj_bounding_radius=rk.get("obj_bounding_radius", 1.0),
                                       s=s_val, n_samples=rk.get("N_samples", 64), n_importance=ni,
                                       n_upsample_iters=rk.get("N_upsample_iters", 4), white_bkgd=rk.get("white_bkgd", False),
-                                      calc_normal=False, detailed=True, precision=m.precision_id,
+                                      calc_normal=False, detailed=True, precision=m.precision_id, **self._neus_algo(rk),
                                       u_new=self._uniform(1, i, oi.shape[0], ni, o.device) if rk.get("perturb", False) else None)
                 kept.append((out["d_all"], out["implicit_surface"].reshape(-1), out["implicit_nablas"].reshape(-1, 3), None))
                 rgbs.append(out["rgb"])

@@ -121,6 +121,9 @@ def get_model(args, render_target=None):
         "D": r.setdefault("D", 4), "W": r.setdefault("W", 256), "skips": r.setdefault("skips", []),
     }
     model = VolSDF(**model_config)
+    # the arithmetic of the kernels (not a reference key; `model.precision` in the YAML or --model:precision overrides it): 'mixed' = the
+    # shipped mode (nets._PackedModel.set_precision) - a model from get_model renders AND trains without a further call
+    model.set_precision(m.get("precision", "mixed"))
     render_kwargs_train = {
         "near": args.data.near, "far": args.data.far, "batched": True,
         "perturb": m.setdefault("perturb", True), "white_bkgd": m.setdefault("white_bkgd", False),

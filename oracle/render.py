@@ -191,10 +191,36 @@ def neus_upsample(sdf_fn, d, o, v, N_importance=64, N_upsample_iters=4, u_new=No
     return d, s
 
 
-# a18  NeuS volume_render  (neus.py:142-424), upsample_algo='official_solution', N_outside=0
+def sdf_to_w(sdf, s):
+    """neus.py:47-63: visibility weights of the sigmoid-CDF opacity at a fixed s."""
+    _, a = sdf_to_alpha(sdf, s)
+    return alpha_to_w(a)
+
+
+def neus_direct_upsample(sdf_fn, d_coarse, near, far, o, v, algo, N_importance=64, N_nograd_samples=2048, fixed_s_recp=1 / 64., u_new=None):
+    """'direct_use' (neus.py:242-255: the N_importance fine samples invert the CDF of the COARSE samples' visibility weights at
+    s = 1 / fixed_s_recp) and 'direct_more' (:259-269: the same over N_nograd_samples evenly spaced no-gradient samples); both draw
+    all N_importance samples at once and sort them in with the coarse ones.  u_new [R, N_importance]: the uniform numbers of perturb=True."""
+    def query(dv):
+        pts = o[:, None, :] + dv[:, :, None] * v[:, None, :]
+        return sdf_fn(pts.reshape(-1, 3)).reshape(dv.shape)
+    if algo == "direct_use":
+        bins = d_coarse
+    elif algo == "direct_more":
+        t = torch.linspace(0, 1, N_nograd_samples).float()
+        bins = near * (1 - t) + far * t
+    else:
+        raise ValueError(algo)
+    w = sdf_to_w(query(bins), 1.0 / fixed_s_recp)
+    d_fine = sample_pdf(bins, w, N_importance, det=u_new is None, u=u_new)
+    return torch.sort(torch.cat([d_coarse, d_fine], dim=-1), dim=-1)[0]
+
+
+# a18  NeuS volume_render  (neus.py:142-424), N_outside=0; upsample_algo 'official_solution' (:275-303), 'direct_use' (:242-255), 'direct_more' (:259-269)
 def neus_render(sd, rays_o, rays_d, obj_bounding_radius=1.0, N_samples=64, N_importance=64,
                 N_upsample_iters=4, white_bkgd=False, speed_factor=10.0, multires=6, skips=(4,),
-                rad_multires=-1, rad_multires_view=4, calc_normal=True, chunk=1024, u_new=None):
+                rad_multires=-1, rad_multires_view=4, calc_normal=True, chunk=1024, u_new=None,
+                upsample_algo="official_solution", N_nograd_samples=2048, fixed_s_recp=1 / 64.):
     rays_o = rays_o.reshape(-1, 3).float()
     rays_d = F.normalize(rays_d.reshape(-1, 3).float(), dim=-1)
     outs = []
@@ -204,9 +230,13 @@ def neus_render(sd, rays_o, rays_d, obj_bounding_radius=1.0, N_samples=64, N_imp
         near, far = near_far_from_sphere(o, v, r=obj_bounding_radius)
         t = torch.linspace(0, 1, N_samples).float()
         d_coarse = near * (1 - t) + far * t
+        sdf_fn = lambda x: nets.surface_forward(sd, x, multires, skips)[0]
+        u_c = None if u_new is None else u_new[c0:c0 + chunk]
         with torch.no_grad():
-            d_all, _ = neus_upsample(lambda x: nets.surface_forward(sd, x, multires, skips)[0], d_coarse, o, v,
-                                     N_importance, N_upsample_iters, None if u_new is None else u_new[c0:c0 + chunk])
+            if upsample_algo == "official_solution":
+                d_all, _ = neus_upsample(sdf_fn, d_coarse, o, v, N_importance, N_upsample_iters, u_c)
+            else:
+                d_all = neus_direct_upsample(sdf_fn, d_coarse, near, far, o, v, upsample_algo, N_importance, N_nograd_samples, fixed_s_recp, u_c)
         pts = o[:, None, :] + v[:, None, :] * d_all[:, :, None]
         d_mid = 0.5 * (d_all[..., 1:] + d_all[..., :-1])
         pts_mid = o[:, None, :] + v[:, None, :] * d_mid[:, :, None]

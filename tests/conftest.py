@@ -68,3 +68,10 @@ def neus_state(golden):
 
 def tt(a):
     return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="session")
+def neus_algos_golden():
+    """NeuS upsample_algo = direct_use / direct_more vectors (tests/golden/make_golden_neus_algos.py)."""
+    z = np.load(os.path.join(os.path.dirname(GOLDEN), "neus_algos_golden.npz"), allow_pickle=False)
+    return {k: z[k] for k in z.files}

@@ -425,6 +425,39 @@ def test_neus_perturb_matches_reference_golden(perturb_golden):
     close("depth", out["depth_volume"], pg["P4_depth_volume"], 5e-3)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("algo", ["direct_use", "direct_more"])
+def test_neus_direct_upsampling_matches_reference_golden(neus_algos_golden, algo, precision):
+    """G10b: NeuS `upsample_algo` = 'direct_use' / 'direct_more' (neus.py:242-269, YAML-reachable through model.upsample_algo :735) through
+    render_fn against the reference's outputs, at G10's tolerances - every extras key at perturb=False; rgb / depth / d_final at
+    perturb=True with the reference's recorded uniform numbers (`uniforms=`); calc_normal=False takes the sampler's own sdf row."""
+    from nerfart_amd import scene, rend_util
+    ag = neus_algos_golden
+    model, rk, render_fn = scene.build_model("NeuS", seed=0, beta=None, device=DEV, precision=precision)
+    H, W = int(ag["A_H"]), int(ag["A_W"])
+    o, d, _ = rend_util.get_rays(tt(ag["A_c2w"])[None].to(DEV), tt(ag["A_K"])[None].to(DEV), H, W)
+    kw = dict(rk, upsample_algo=algo)
+    rgb, depth, ex = render_fn(o, d, calc_normal=True, detailed_output=True, **kw)
+    tag = f"A_{algo}_"
+    loose = 1.0 if precision == "fp32" else 3.0           # split-bf16: ~2^-16 relative per product instead of fp32 round-off
+    tol = {"rgb": 1e-4, "depth_volume": 3e-4, "mask_volume": 1e-4, "normals_volume": 3e-4, "implicit_nablas": 5e-4,
+           "implicit_surface": 3e-5, "radiance": 1e-4, "alpha": 3e-4, "cdf": 3e-4, "visibility_weights": 3e-4, "d_final": 3e-4}
+    assert [k for k in ex.keys() if k != "d_all"] == ["rgb", "depth_volume", "mask_volume", "normals_volume", "implicit_nablas", "implicit_surface",
+                                                       "radiance", "alpha", "cdf", "visibility_weights", "d_final"]
+    for k, t in tol.items():
+        close(f"{algo} {k}", ex[k][0], ag[tag + k], loose * t, 3e-4, frac=0.99)
+    close("rgb (all rays, 1e-3)", ex["rgb"][0], ag[tag + "rgb"], 1e-3)
+    close("depth (all rays, 5e-3)", ex["depth_volume"][0], ag[tag + "depth_volume"], 5e-3)
+    rgb2, depth2, ex2 = render_fn(o, d, calc_normal=False, detailed_output=False, **kw)
+    assert torch.equal(rgb2, rgb) and torch.equal(depth2, depth), "pixels must not depend on calc_normal"
+    rgb_p, depth_p, ex_p = render_fn(o, d, calc_normal=True, detailed_output=True, perturb=True, uniforms=tt(ag[tag + "perturb_u"]).to(DEV),
+                                     **{k: v for k, v in kw.items() if k != "perturb"})
+    close("perturb d_final", ex_p["d_final"][0], ag[tag + "perturb_d_final"], 3e-4, 3e-4, frac=0.99)
+    close("perturb rgb", rgb_p[0], ag[tag + "perturb_rgb"], 1e-3)
+    close("perturb depth", depth_p[0], ag[tag + "perturb_depth_volume"], 5e-3)
+    close("perturb mask", ex_p["mask_volume"][0], ag[tag + "perturb_mask_volume"], 1e-3)
+
+
 def test_render_fn_perturb_draws_fresh_samples():
     """render_fn(perturb=True) (the reference's training default, volsdf.py:982): two calls draw different final samples,
     the coarse samples stay, and the image stays close to the deterministic render (it is the same quadrature rule)."""

@@ -11,6 +11,7 @@ pytestmark = pytest.mark.gpu
 # gradients of the native pass 2 against the reference Trainer's own autograd (goldens): relative error of every parameter's gradient
 # norm / of its leading 32 entries
 NORM_TOL, HEAD_TOL = 5e-3, 1e-2          # round 2: 2e-2 / 5e-2; measured (profiles/r03g_train_err.log): <= 4.7e-3 / 9.4e-3
+P_NORM_TOL, P_HEAD_TOL = 7e-3, 1.2e-2    # the perturb=True goldens (random u on both sides): measured 5.4e-3 / 9.5e-3 (see the test)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
@@ -672,7 +673,12 @@ def test_finetune_branch_perturb_true_matches_the_reference_trainer(fw):
         np.testing.assert_allclose(float(ret["losses"]), float(z[tag + "loss"]), rtol=2e-3)
         if mode == "reference":
             assert [a[0] for a in asked] == [1, 2], asked              # one draw per pass: pass 2 sampled again
-            assert worst_n <= NORM_TOL and worst_h < HEAD_TOL, (worst_n, worst_h)
+            # measured (gpurun r06a): VolSDF 5.4e-3 / 9.5e-3, NeuS 1.1e-3 / 2.0e-3 - against 2.8e-3 / 4.8e-3 and 3.1e-4 / 2.7e-3 at perturb=False.
+            # The backward is the same code (have_state = 0 re-evaluates the kept state with the same kernel, bit for bit:
+            # test_pass1_state_reuse_matches_recompute); what grows is the INPUT's distance from the reference's: inverse-CDF samples at random u
+            # sit anywhere on the opacity CDF's plateaux, where a 1e-6 sdf difference moves a sample by up to a bin (pass-1 image 5.2e-4 from
+            # the reference's here, 1e-4 with linspace u), and d loss / d rgb = 2 (rgb - target) / N inherits it pixel by pixel
+            assert worst_n <= P_NORM_TOL and worst_h < P_HEAD_TOL, (worst_n, worst_h)
         else:
             assert [a[0] for a in asked] == [1], asked                 # pass 2 reused pass 1's samples
     if fw == "VolSDF":

@@ -208,3 +208,23 @@ def test_P4_neus_perturb(perturb_golden, neus_state):
                                  u_new=tt(pg["P4_u_new"]))
     for k in ("rgb", "depth_volume", "d_final", "implicit_surface"):
         close(out[k], pg["P4_" + k], 3e-5, 2e-4)
+
+
+@pytest.mark.parametrize("algo", ["direct_use", "direct_more"])
+def test_G10b_neus_direct_upsampling(neus_algos_golden, neus_state, algo):
+    """neus.py:242-269: the two up-sampling algorithms besides 'official_solution' (YAML-reachable, neus.py:735) - every extras key at
+    perturb=False, and rgb / depth / d_final at perturb=True with the reference's recorded draw."""
+    ag = neus_algos_golden
+    sd, rk = neus_state
+    assert state_checksum(sd) == str(ag["A_state_sha256"])
+    o, d = render.get_rays(tt(ag["A_c2w"]), tt(ag["A_K"]), int(ag["A_H"]), int(ag["A_W"]))
+    with torch.no_grad():
+        out = render.neus_render(sd, o, d, obj_bounding_radius=rk["obj_bounding_radius"], upsample_algo=algo)
+    tag = f"A_{algo}_"
+    for k in ("rgb", "depth_volume", "mask_volume", "normals_volume", "implicit_nablas", "implicit_surface", "radiance", "alpha", "cdf",
+              "visibility_weights", "d_final"):
+        close(out[k], ag[tag + k], 3e-5, 2e-4)
+    with torch.no_grad():
+        out = render.neus_render(sd, o, d, obj_bounding_radius=rk["obj_bounding_radius"], upsample_algo=algo, u_new=tt(ag[tag + "perturb_u"]))
+    for k in ("rgb", "depth_volume", "d_final", "mask_volume"):
+        close(out[k], ag[tag + "perturb_" + k], 3e-5, 2e-4)
