@@ -16,19 +16,25 @@ With N > 1 the same run ALSO times the strong-scaling mode (`"strong"` in the JS
 primary line): ONE frame per step cut into 2,048-ray tiles dealt round-robin over the ranks (nerfart_amd.dist.render_sharded,
 how a single 960 x 540 frame of cfg 5 is sharded) + one all_gather, value = rays of that one frame / max-over-ranks time.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (fused encode + SDF MLP): achieved =
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (fused encode + SDF MLP, k_sdf_only): achieved =
 algorithmic flops per launch (F_sdf = 1,049,088 per point) / average launch duration from HIP
-events recorded on the launching stream during the timed steps.  --precision bf16x3 (default): k_sdf_only_bf16,
-fp32 operands split into two bf16 terms, three v_mfma_f32_16x16x32_bf16 per product, fp32 accumulate (error
-~2^-17, parity tests at 1e-3 like fp32); peak = 2,500 TFLOP/s dense bf16, of which a 3-MFMA product can reach
-1/3.  --precision fp32: k_sdf_only on v_mfma_f32_16x16x4_f32 (exact fp32 products), peak = 157.3 TFLOP/s.  `cpu_baseline` times the CPU oracle (a
-PyTorch port of the reference algorithm; kind "port") on a strided subset of the same frame's rays, and doubles as a parity check of
-THIS run (the same rays through the HIP renderer at the benchmarked precision and at fp32-exact, converged and never-converged rays apart).
+events recorded on the launching stream during the timed steps; peak = 2,500 TFLOP/s (dense bf16 = dense fp16 MFMA).
+--precision mixed (default; the mode get_model ships since round 5): every value that reaches a pixel - sdf, nabla, radiance and
+compositing of the 192 final samples - in split-bf16 (fp32 operands split into two bf16 terms, three v_mfma_f32_16x16x32_bf16 per product,
+fp32 accumulate, error ~2^-17); VolSDF's Algorithm-1 sampler (512 (1 + rounds) no-gradient SDF queries per ray, volsdf.py:479) on the 2-MFMA
+kernels (ONE fp16 activation term x fp16 hi + lo weights, v_mfma_f32_16x16x32_f16).  Admitted as the headline by VERDICT r4 "next 2" after it
+passed every reference-golden assertion the pure split-bf16 mode passes (tests/test_gpu_bf16x3.py, tests/test_gpu_configs.py, both parametrised
+over the sampler; profiles/r06*_mixed_mode_battery.log).  --precision bf16x3: split-bf16 everywhere, the headline of rounds 2-4, now
+`secondary.bf16x3` with its own k_sdf_only roofline.  --precision fp32: k_sdf_only on v_mfma_f32_16x16x4_f32 (exact fp32 products), peak =
+157.3 TFLOP/s.  `cpu_baseline` times the CPU oracle (a PyTorch port of the reference algorithm; kind "port") on a strided subset of the same
+frame's rays, and doubles as a parity check of THIS run (the same rays through the HIP renderer at the benchmarked precision and at fp32-exact,
+converged and never-converged rays apart).
 
-`secondary` (N = 1; never the primary `value`): fp32_exact (5 frames), bf16x3_vs_fp32_pixels, fp16x2 (C-ABI precision 4, the 2-MFMA
-measurement variant, 3 frames + its pixel statistics), cfg5_frame_960x540 and cfg4_neus_480x270 (3 frames on 3 views each),
-cfg3_finetune_step (BASELINE configs[2]: 1 warm-up + 3 timed steps, stage split, peak memory, and the roofline of the dominant pass-2
-kernel k_wgrad<256> from the library's event records).
+`secondary` (N = 1; never the primary `value`): fp32_exact (5 frames), <precision>_vs_fp32_pixels, bf16x3 (pure; 3 frames + pixel statistics +
+roofline), fp16x2 (C-ABI precision 4 everywhere, a measurement variant), cfg5_frame_960x540 and cfg4_neus_480x270 (3 frames on 3 views each),
+cfg3_finetune_step (BASELINE configs[2]: 1 warm-up + 3 timed steps at perturb=False, stage split, peak memory, the roofline of the dominant
+pass-2 kernel k_wgrad<256> from the library's event records; `perturb_true`: the same step with the reference's default render_kwargs_train,
+where pass 2 runs the sampler again).
 """
 import argparse
 import json
@@ -84,9 +90,11 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--beta", type=float, default=0.01)
-    ap.add_argument("--precision", choices=["fp32", "bf16x3", "fp16x2"], default="bf16x3",
-                    help="fp32: exact v_mfma_f32_16x16x4_f32; bf16x3 (the headline): split-bf16 operands on v_mfma_f32_16x16x32_bf16; fp16x2: the 2-MFMA "
-                         "measurement variant (C-ABI precision 4) as the primary of an EXPERIMENT line (tools/power_probe_precision.sh) - never the driver's")
+    ap.add_argument("--precision", choices=["mixed", "fp32", "bf16x3", "fp16x2"], default="mixed",
+                    help="mixed (the headline since round 5 = get_model's default): every value that reaches a pixel in split-bf16 (3 MFMAs per product), "
+                         "VolSDF's Algorithm-1 sampler on the 2-MFMA fp16 kernels; bf16x3: split-bf16 everywhere (the headline of rounds 2-4, kept as "
+                         "`secondary.bf16x3`); fp32: exact v_mfma_f32_16x16x4_f32; fp16x2: the 2-MFMA form EVERYWHERE (C-ABI precision 4) as the primary "
+                         "of an EXPERIMENT line (tools/power_probe_precision.sh) - never the driver's")
     ap.add_argument("--shard", choices=["views", "tiles"], default="views",
                     help="N > 1: views = one view per rank per step (weak scaling, the primary line); tiles = one frame per step "
                          "sharded over the ranks in 2,048-ray tiles (strong scaling).  The other mode is reported as a secondary object.")
@@ -232,7 +240,9 @@ def main():
         dist.all_reduce(t5, op=dist.ReduceOp.MAX)
         secondary["strong_tiles_960x540"] = {"value": round(H5 * W5 / float(t5), 1), "unit": "rays/s", "ms_per_step": round(float(t5) * 1e3, 2), "steps": 1,
                                              "scaling": "strong", "what": "ONE 960x540 frame (cfg 5), 2,048-ray tiles round-robin over the ranks + one all_gather"}
-    if world == 1 and not args.no_secondary and args.precision == "bf16x3":
+    headline_split = args.precision in ("mixed", "bf16x3")
+    other = "bf16x3" if args.precision == "mixed" else "mixed"          # the split-bf16 mode that is NOT the headline: a secondary of its own
+    if world == 1 and not args.no_secondary and headline_split:
         m32, _, f32 = scene.build_model("VolSDF", seed=0, beta=args.beta, device=dev, precision="fp32")
         m32.packed()
         o_, d_ = rays[0]
@@ -253,10 +263,10 @@ def main():
         pix2 = {"rays": int(e2.numel()), "rays_over_1e-3": int((e2 > 1e-3).sum()), "max_abs": round(float(e2.max()), 6),
                 "p999_abs": round(float(e2.flatten().kthvalue(int(0.999 * e2.numel())).values), 7),
                 "psnr_db": round(float(-10 * torch.log10(((b16_ - a32) ** 2).mean().clamp_min(1e-20))), 1)}
-        # ... and the mixed variant: Algorithm 1 (the 512 (1 + rounds) no-gradient SDF queries per ray) on the 2-MFMA kernels, the 192 final
-        # samples - every number that reaches a pixel - in split-bf16 (C entry point nerfart_volsdf_render_mixed_fwd)
-        mmx, _, fmx = scene.build_model("VolSDF", seed=0, beta=args.beta, device=dev, precision="bf16x3")
-        mmx.set_sampler_precision("fp16x2")
+        # ... and the other split-bf16 mode (headline mixed: pure bf16x3, the headline of rounds 2-4, so the series stays comparable; headline
+        # bf16x3: the mixed mode = Algorithm 1's 512 (1 + rounds) no-gradient SDF queries per ray on the 2-MFMA kernels, the 192 final
+        # samples - every number that reaches a pixel - in split-bf16, C entry point nerfart_volsdf_render_mixed_fwd)
+        mmx, _, fmx = scene.build_model("VolSDF", seed=0, beta=args.beta, device=dev, precision=other)
         bmx, _, _ = fmx(o_, d_, require_nablas=True, calc_normal=True, detailed_output=False, **kw)
         e3 = (bmx - a32).abs().max(dim=-1).values
         pix3 = {"rays": int(e3.numel()), "rays_over_1e-3": int((e3 > 1e-3).sum()), "max_abs": round(float(e3.max()), 6),
@@ -277,7 +287,7 @@ def main():
         secondary["fp32_exact"] = {"value": round(H * W / t32, 1), "unit": "rays/s", "ms_per_step": round(t32 * 1e3, 2), "steps": n32,
                                    "what": "same workload with --precision fp32 (v_mfma_f32_16x16x4_f32, exact fp32 products; reverse-mode grad(SDF) kernel)",
                                    "vs_ref_3090": round(H * W / t32 / 6480.0, 2)}
-        secondary["bf16x3_vs_fp32_pixels"] = pix
+        secondary[f"{args.precision}_vs_fp32_pixels"] = pix
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for oo_, dd_ in views32[:3]:
@@ -290,15 +300,26 @@ def main():
                                        "product (11-bit activations, TF32 class) - a measurement variant, NOT the headline precision; table vs the "
                                        "oracle: profiles/r05*_parity_table.json (tools/parity_table.py)"}
         torch.cuda.synchronize()
+        hip.profile_begin()
         t1 = time.perf_counter()
         for oo_, dd_ in views32[:3]:
             fmx(oo_, dd_, require_nablas=True, calc_normal=True, detailed_output=False, **kw)
         torch.cuda.synchronize()
         tmx = (time.perf_counter() - t1) / 3
-        secondary["bf16x3_with_fp16x2_sampler"] = {"value": round(H * W / tmx, 1), "unit": "rays/s", "ms_per_step": round(tmx * 1e3, 2), "steps": 3,
-                                                   "vs_fp32_pixels": pix3,
-                                                   "what": "Algorithm 1's SDF queries at C-ABI precision 4, the 192 final samples (sdf, nabla, radiance, compositing) in "
-                                                           "split-bf16: model.set_precision('bf16x3').set_sampler_precision('fp16x2') - a measurement variant"}
+        pmx = hip.profile_end()
+        k_ms, k_n, k_pts = pmx["k_sdf_only"]
+        secondary["bf16x3" if other == "bf16x3" else "bf16x3_with_fp16x2_sampler"] = {
+            "value": round(H * W / tmx, 1), "unit": "rays/s", "ms_per_step": round(tmx * 1e3, 2), "steps": 3, "vs_fp32_pixels": pix3,
+            # the dominant kernel of THAT mode, priced like `roofline` (algorithmic flops / launch time / 2,500 TFLOP/s)
+            "roofline_k_sdf_only": None if not k_n else {
+                "kernel": "k_sdf_only_bf16" if other == "bf16x3" else "f16x2::k_sdf_only_bf16", "mfma_per_product": 3 if other == "bf16x3" else 2,
+                "achieved": round(k_pts / k_n * F_SDF / (k_ms / k_n * 1e-3) / 1e12, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(k_pts / k_n * F_SDF / (k_ms / k_n * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4), "avg_launch_ms": round(k_ms / k_n, 4),
+                "launches": int(k_n)},
+            "what": ("split-bf16 EVERYWHERE (model.set_precision('bf16x3')): the headline precision of rounds 2-4 (BENCH_r02..r04), kept so that the "
+                     "series stays comparable" if other == "bf16x3" else
+                     "Algorithm 1's SDF queries at C-ABI precision 4, the 192 final samples (sdf, nabla, radiance, compositing) in "
+                     "split-bf16: model.set_precision('mixed')")}
         del m32, f32, m16, f16, mmx, fmx
         # the other single-GPU configurations of BASELINE.json: one warm-up frame, then N_SEC timed frames on N_SEC views of the orbit
         # (bench lines of their own: tools/bench_neus.py, tools/bench_train.py)
@@ -334,7 +355,7 @@ def main():
         from nerfart_amd import bench_util
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()
-        ctx3 = bench_util.finetune_setup(dev, H, W, beta=args.beta, angle=angles[2])
+        ctx3 = bench_util.finetune_setup(dev, H, W, beta=args.beta, angle=angles[2], precision=args.precision)
         m3, loss3, eik3, prof3 = bench_util.finetune_steps(ctx3, N_SEC, warmup=1, profile=True)
         wg_ms, wg_n, wg_bytes = prof3["k_wgrad256"]
         secondary["cfg3_finetune_step"] = {
@@ -348,13 +369,26 @@ def main():
                 "what": "weight-gradient reductions over the point-major bf16 dumps: both operands read once (DESIGN.md 4.3)"},
             "mlp_kernel_ms_per_step": {k: round(v[0] / N_SEC, 2) for k, v in prof3.items()},
             "what": "configs[2]: volsdf_fangzhou_vangogh.yaml train step at 480x270 (render + CLIP directional / contrastive / PatchNCE + VGG "
-                    "perceptual, backward, Adam), seeded random-weight CLIP ViT-B/32 + VGG16, perturb=False, split-bf16 kernels"}
-        # the same step with Algorithm 1 on the 2-MFMA kernels (model.set_sampler_precision: no gradient flows through the sampler, volsdf.py:479;
-        # the kept state and pass 2 stay split-bf16) - a measurement variant like secondary.bf16x3_with_fp16x2_sampler
-        ctx3["model"].set_sampler_precision("fp16x2")
+                    "perceptual, backward, Adam), seeded random-weight CLIP ViT-B/32 + VGG16, perturb=False (pass 2 reads pass 1's kept samples: at "
+                    "perturb=False re-sampling reproduces them), precision %s; `perturb_true` = the same step with render_kwargs_train as the reference "
+                    "builds them" % args.precision}
+        # THE REFERENCE'S DEFAULT render_kwargs_train: perturb=True (volsdf.py:982; no shipped YAML overrides it).  Both passes call the renderer
+        # (volsdf.py:724-728, :759-766): pass 1 on the fused renderer with random final samples, nothing kept; pass 2 runs Algorithm 1 AGAIN with
+        # fresh draws and nerfart_volsdf_render_bwd re-evaluates the per-point state (have_state = 0).  tests: FP_* goldens of the reference Trainer.
+        m3p, loss3p, eik3p, _ = bench_util.finetune_steps(ctx3, 2, warmup=1, perturb=True)
+        secondary["cfg3_finetune_step"]["perturb_true"] = {
+            "value": round(sum(m3p), 4), "unit": "s/step", "higher_is_better": False, "steps": 2, "rays_per_s": round(H * W / sum(m3p), 1),
+            "pass1_render_s": round(m3p[0], 4), "style_losses_fwd_bwd_s": round(m3p[1], 4), "pass2_render_bwd_s": round(m3p[2], 4), "adam_s": round(m3p[3], 4),
+            "pass2_sampler_alone_s": round(bench_util.pass2_sampler_seconds(ctx3), 4), "loss": round(loss3p, 5), "eikonal": round(float(eik3p), 7),
+            "what": "render_kwargs_train['perturb'] = True, the reference's default: pass 2 = second Algorithm 1 (pass2_sampler_alone_s, timed on "
+                    "its own over the same ray batches) + forward re-evaluation + backward; Trainer(reuse_pass1_samples=True) is the opt-in that "
+                    "avoids it (INTEGRATION.md section F)"}
+        # the same (perturb=False) step in the OTHER split-bf16 mode (no gradient flows through the sampler, volsdf.py:479; the kept state and
+        # pass 2 are split-bf16 in both)
+        ctx3["model"].set_precision(other)
         m3b, loss3b, _, _ = bench_util.finetune_steps(ctx3, 2, warmup=1)
-        secondary["cfg3_finetune_step"]["with_fp16x2_sampler"] = {"value": round(sum(m3b), 4), "unit": "s/step", "steps": 2, "pass1_render_s": round(m3b[0], 4),
-                                                                  "pass2_render_bwd_s": round(m3b[2], 4), "loss": round(loss3b, 5)}
+        secondary["cfg3_finetune_step"]["with_bf16x3_sampler" if other == "bf16x3" else "with_fp16x2_sampler"] = {
+            "value": round(sum(m3b), 4), "unit": "s/step", "steps": 2, "pass1_render_s": round(m3b[0], 4), "pass2_render_bwd_s": round(m3b[2], 4), "loss": round(loss3b, 5)}
         del ctx3
         torch.cuda.empty_cache()
 
@@ -375,12 +409,21 @@ def main():
         achieved = flops_per_launch / avg_s / 1e12
         # bf16x3 issues 3 bf16 MFMAs per algorithmic product: priced against the dense bf16 MFMA peak
         peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
-        kname = "k_sdf_only" if args.precision == "fp32" else "k_sdf_only_bf16"      # (fp16x2: the same kernel name in namespace f16x2)
+        # (mixed: every k_sdf_only launch of a frame is Algorithm 1's - the 2-MFMA kernel, namespace f16x2; the final samples run k_sdf_grad_bf16)
+        kname = {"fp32": "k_sdf_only", "bf16x3": "k_sdf_only_bf16"}.get(args.precision, "f16x2::k_sdf_only_bf16")
         roofline = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
                     "launches": int(launches), "avg_launch_ms": round(ms / launches, 4),
                     "points_per_launch": int(points / launches),
                     "flops_per_point": F_SDF}
+        if args.precision in ("mixed", "fp16x2"):
+            # ONE fp16 activation term x fp16 hi + lo weight terms: 2 x v_mfma_f32_16x16x32_f16 per product (the dense fp16 peak = the bf16 one)
+            roofline["mfma_per_product"] = 2
+            roofline["mfma_executed_frac"] = round(2 * 2.0 * MFMA_MAC_SDF * (points / launches) / avg_s / 1e12 / peak, 4)
+            roofline["ceiling_frac"] = {"matrix_pipe_only": round(0.91 / 2, 4), "source": "profiles/r02s_ubench_coissue.txt (MFMA-only rate 0.91 of peak)"}
+            roofline["note"] = ("the sampler's kernel: Algorithm 1's 512 (1 + rounds) SDF queries per ray, 69 % of a bf16x3 frame; frac = ALGORITHMIC flops "
+                                "(F_sdf per point) / launch time / 2,500 TFLOP/s, comparable across modes; the sustained rate is set by the package "
+                                "power cap (joules per product: profiles/r05n power probes), which is why 2 MFMAs per product buy time")
         if args.precision == "bf16x3":
             # what the matrix pipe executes: MFMA_MAC_SDF multiply-adds per point, each as `mfma_per_product` bf16 MFMAs
             # (hi.hi + hi.lo + lo.hi), as a fraction of the dense bf16 peak
@@ -478,7 +521,7 @@ def main():
                   "max_abs_depth_same_rounds": float(f"{float((g_depth[0].cpu() - ref['depth_volume'])[same].abs().max()):.3e}")}
         # the exact-fp32 mode against the oracle on the SAME rays: says whether a ray past 1e-3 is the split-bf16 arithmetic or
         # Algorithm 1's own discontinuities (a ray that flips under any change of rounding; tools/fp32_outlier.py)
-        if args.precision == "bf16x3" and not args.no_secondary:
+        if headline_split and not args.no_secondary:
             m32, _, f32 = scene.build_model("VolSDF", seed=0, beta=args.beta, device=dev, precision="fp32")
             with torch.no_grad():
                 r32, d32, x32 = f32(o[:, sel], d[:, sel], require_nablas=True, calc_normal=True, detailed_output=True, **kw)
@@ -490,9 +533,9 @@ def main():
                 "rays_over_1e-3": int((e32 > 1e-3).sum()), "max_abs_rgb_all": float(f"{float(e32.max()):.3e}"),
                 "max_abs_rgb_same_rounds": float(f"{float(e32[same32].max()):.3e}"),
                 "psnr_db": round(float(-10 * torch.log10(((r32[0].cpu() - ref["rgb"]) ** 2).mean().clamp_min(1e-20))), 1),
-                "bf16x3_rays_over_1e-3": [{"ray": int(sel[i]), "bf16x3_err": float(f"{float(e_pix[i]):.3e}"), "fp32_err": float(f"{float(e32[i]):.3e}"),
-                                           "rounds_oracle_bf16x3_fp32": [float(ref["iter_usage"][i]), float(g_ex["iter_usage"][0, i]), float(x32["iter_usage"][0, i])]}
-                                          for i in over16[:16]]}
+                f"{args.precision}_rays_over_1e-3": [{"ray": int(sel[i]), f"{args.precision}_err": float(f"{float(e_pix[i]):.3e}"), "fp32_err": float(f"{float(e32[i]):.3e}"),
+                                                      f"rounds_oracle_{args.precision}_fp32": [float(ref["iter_usage"][i]), float(g_ex["iter_usage"][0, i]), float(x32["iter_usage"][0, i])]}
+                                                     for i in over16[:16]]}
             del m32, f32, r32, d32, x32
         del g_rgb, g_depth, g_ex
         cpu = {"value": round(n_cpu / tc, 1), "unit": "rays/s", "cores": int(cores), "kind": "port", "cpu_model": cpu_model,
@@ -531,7 +574,7 @@ def main():
                     "max_abs_rgb_converged": float(f"{float(e_[conv_].max()) if conv_.any() else 0.0:.3e}"),
                     "psnr_db": round(float(-10 * torch.log10(((rgb_[0].cpu() - ref1["rgb"]) ** 2).mean().clamp_min(1e-20))), 1)}
         par1 = {"never_converged_rays_oracle": int((ref1["iter_usage"] < 0).sum()), args.precision: parity1(rgb1, ex1["iter_usage"])}
-        if args.precision == "bf16x3" and not args.no_secondary:
+        if headline_split and not args.no_secondary:
             m32, _, f32 = scene.build_model("VolSDF", seed=0, beta=args.beta, device=dev, precision="fp32")
             with torch.no_grad():
                 r32, _, x32 = f32(o1, d1, require_nablas=True, calc_normal=True, detailed_output=True, **kw1)
@@ -550,6 +593,8 @@ def main():
             "devices": devices, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong" if primary_tiles else "weak",
             "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (f32 split into 2 bf16 terms, f32 accumulate)",
+                                           "mixed": "pixels bf16x3 (sdf, nabla, radiance, compositing of the 192 final samples: f32 split into 2 bf16 terms, 3 MFMAs per "
+                                                    "product, f32 accumulate), Algorithm-1 sampler fp16x2 (fp16 act x fp16 hi+lo weights, 2 MFMAs per product, f32 accumulate)",
                                            "fp16x2": "fp16x2 (1 fp16 activation term x 2 fp16 weight terms, f32 accumulate) - EXPERIMENT, not the benchmark precision"}[args.precision], "data": "synthetic",
             "config": {"workload": ("configs[1]" if (H, W) == (480, 270) else "configs[4] frame size" if (H, W) == (960, 540) else "custom frame") +
                                    ": volsdf_fangzhou_nature.yaml dims, %dx%d rays/frame, 128 coarse + 64 fine " % (H, W) +

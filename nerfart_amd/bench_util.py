@@ -13,10 +13,10 @@ import torch
 
 
 def finetune_setup(dev, H: int, W: int, beta: float = 0.01, with_vgg: bool = True, pass2_rays: int = 1200, patches_per_launch: int = 4,
-                   angle: float = 0.0):
+                   angle: float = 0.0, precision: str = "mixed"):
     from . import scene, rend_util, criteria, clip_vit, vgg
     from .trainer import Trainer
-    model, rk, render_fn = scene.build_model("VolSDF", seed=0, beta=beta, device=dev, precision="bf16x3")
+    model, rk, render_fn = scene.build_model("VolSDF", seed=0, beta=beta, device=dev, precision=precision)
     c2w, K = scene.camera(H, W, angle=angle)
     o, d, _ = rend_util.get_rays(c2w[None].to(dev), K[None].to(dev), H, W)
     feats = criteria.ClipFeatures(model=clip_vit.build_clip(dev, seed=0), device=dev, synthetic=True)
