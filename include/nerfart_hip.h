@@ -39,7 +39,9 @@
 extern "C" {
 #endif
 
-/* 2 (round 4).  History: 1 -> 2: nerfart_sdf_nabla_fwd[_rays] take a caller-owned workspace; the CLIP blob stores every matrix once; the
+/* 3 (round 5).  History: 2 -> 3, additions only (every version-2 entry point keeps its signature): the weight-blob packers
+ * (nerfart_pack_surface_blob / nerfart_pack_radiance_blob + size queries; header word 10 of a split blob now names its fragment encoding),
+ * nerfart_neus_render_algo_fwd / nerfart_neus_direct_upsample_step (upsample_algo 'direct_use' / 'direct_more').  1 -> 2: nerfart_sdf_nabla_fwd[_rays] take a caller-owned workspace; the CLIP blob stores every matrix once; the
  * VGG blob is fp32; the CLIP / VGG entry points take blob_bytes and reject blobs of another layout; new: the ray-level backward
  * (nerfart_*_render_bwd, nerfart_sdf_param_bwd, nerfart_fold_weight_grads, nerfart_weight_norm_bwd). */
 int nerfart_abi_version(void);
@@ -425,6 +427,33 @@ long long nerfart_folded_grads_layout(int multires, int multires_view, long long
 int nerfart_fold_weight_grads(const float* raw, int multires, int multires_view, float* folded, void* stream);
 int nerfart_weight_norm_bwd(const float* dW, const float* weight_v, const float* weight_g, int out_features, int in_features, float* g_weight_v,
                             float* g_weight_g, int accumulate, void* stream);
+
+/* ---- B5: checkpoint -> blobs (reference render.py:266-267 `model.load_state_dict(torch.load(p)['model'])`, models/base.py:226-227
+ * `nn.utils.weight_norm`: the state dict holds weight_g [out, 1], weight_v [out, in], bias [out] per layer).  csrc/pack_blob.hip turns
+ * those tensors into the blobs every entry point above reads, entirely on the device and on the caller's stream: the weight_norm fold
+ * w = g * v / ||v||_row, the permutation into the kernels' fragment order (a closed form the library owns; tests/test_pack_plan.py holds it
+ * equal, entry for entry, to the numpy plans of nerfart_amd/packing.py that the CPU emulation walks) and, for the split programs, hi = rne(w),
+ * lo = rne(w - hi) in bf16 (precision 1) or fp16 (precision 4).  Call once per weight update (two launches per blob).
+ *   precision       : the C-ABI precision the blob is for: 0 fp32, 1 split bf16 ("bf16x3"; also what every training entry point reads),
+ *                     4 fp16 hi + lo ("fp16x2"; the sampler blob of nerfart_volsdf_render_mixed_fwd)
+ *   weight_g/_v/bias: HOST arrays of DEVICE pointers, one per layer: `implicit_surface.surface_fc_layers.{0..8}.*` (W 256, D 8, skips [4],
+ *                     embed_multires 6, W_geo_feat 256 - the four shipped configs) resp. `radiance_net.layers.{0..4}.*` (W 256, D 4;
+ *                     view_tiles 1: raw view directions, input 265; 3: embed_multires_view 4, input 289); surf8_*: the SDF net's LAST
+ *                     layer, whose rows 1..256 (the geometry feature) the radiance kernels evaluate
+ *   blob_out        : nerfart_*_blob_floats(precision, ...) floats (0 = bad arguments, see nerfart_last_error)
+ *   workspace       : nerfart_pack_workspace_bytes() bytes of scratch (the rows' 1 / ||v||)
+ * nerfart_pack_plan_debug is HOST-only (tests): the layout as plain gather tables - sizes[4] = {chunk elements, aux elements, total floats,
+ * chunks}; cindex / cmul (second factor) / aindex: flat indices into [tensors in state-dict order w0, b0, w1, ... | 0.0 | 1.0]; cscale per
+ * chunk element; header: the 512 header words.  Any table may be NULL. */
+long long nerfart_surface_blob_floats(int precision, int multires);
+long long nerfart_radiance_blob_floats(int precision, int view_tiles);
+long long nerfart_pack_workspace_bytes(void);
+int nerfart_pack_surface_blob(int precision, int multires, const float* const* weight_g, const float* const* weight_v, const float* const* bias,
+                              float* blob_out, long long blob_floats, void* workspace, long long workspace_bytes, void* stream);
+int nerfart_pack_radiance_blob(int precision, int view_tiles, const float* surf8_g, const float* surf8_v, const float* surf8_bias,
+                               const float* const* weight_g, const float* const* weight_v, const float* const* bias, float* blob_out, long long blob_floats,
+                               void* workspace, long long workspace_bytes, void* stream);
+int nerfart_pack_plan_debug(int program, int view_tiles, int fp16, long long* sizes, int* header, int* cindex, int* cmul, float* cscale, int* aindex);
 
 /* The GEMM kernel of the encoder on its own (tests): C[M,N] fp32 = A[M,K] fp16 . W[N,K]^T fp16; M, N, K multiples of 64. */
 int nerfart_gemm_f16_nt(const void* A, const void* W, int M, int N, int K, float* C, void* stream);

@@ -118,6 +118,12 @@ _SIGS = {
     "nerfart_folded_grads_layout": (_ll, [_i, _i, _p]),
     "nerfart_fold_weight_grads": (_i, [_p, _i, _i, _p, _p]),
     "nerfart_weight_norm_bwd": (_i, [_p, _p, _p, _i, _i, _p, _p, _i, _p]),
+    "nerfart_surface_blob_floats": (_ll, [_i, _i]),
+    "nerfart_radiance_blob_floats": (_ll, [_i, _i]),
+    "nerfart_pack_workspace_bytes": (_ll, []),
+    "nerfart_pack_surface_blob": (_i, [_i, _i, _p, _p, _p, _p, _ll, _p, _ll, _p]),
+    "nerfart_pack_radiance_blob": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p, _ll, _p, _ll, _p]),
+    "nerfart_pack_plan_debug": (_i, [_i, _i, _i] + [_p] * 6),
 }
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)          # AttributeError here = header / library mismatch
@@ -149,6 +155,58 @@ def _dev(t: torch.Tensor, dtype=torch.float32, name="tensor") -> int:
     if not t.is_contiguous():
         raise NerfartHipError(f"{name} must be contiguous")
     return t.data_ptr()
+
+
+def _ptr_table(tensors, name):
+    """HOST array of device pointers (what the pack entry points take for per-layer tensors)."""
+    return (C.c_void_p * len(tensors))(*[_dev(t, name=f"{name}[{i}]") for i, t in enumerate(tensors)])
+
+
+def pack_surface_blob(precision: int, multires: int, weight_g, weight_v, bias) -> torch.Tensor:
+    """nerfart_pack_surface_blob: the SDF net's blob for C-ABI `precision` (0 fp32, 1 split bf16, 4 fp16 hi + lo) from the state dict's
+    per-layer weight_g [out, 1] / weight_v [out, in] / bias [out] (9 layers) - weight_norm fold, unit-order permutation and hi / lo split on
+    the device.  The returned tensor carries `.nerfart_term` ('fp32' | 'bf16' | 'fp16') for the wrappers of entry points that read one encoding only."""
+    dev = weight_v[0].device
+    n = int(lib.nerfart_surface_blob_floats(int(precision), int(multires)))
+    if n <= 0:
+        raise NerfartHipError(f"nerfart_surface_blob_floats: {lib.nerfart_last_error().decode(errors='replace')}")
+    blob = torch.empty(n, dtype=torch.float32, device=dev)
+    ws = _workspace(int(lib.nerfart_pack_workspace_bytes()), dev)
+    g = [t.detach().reshape(-1).contiguous() for t in weight_g]
+    v = [t.detach().contiguous() for t in weight_v]
+    b = [t.detach().contiguous() for t in bias]
+    _check(lib.nerfart_pack_surface_blob(int(precision), int(multires), _ptr_table(g, "weight_g"), _ptr_table(v, "weight_v"), _ptr_table(b, "bias"),
+                                         _dev(blob), n, ws.data_ptr(), ws.numel(), _stream()), "nerfart_pack_surface_blob")
+    blob.nerfart_term = {0: "fp32", 1: "bf16", 4: "fp16"}[int(precision)]
+    return blob
+
+
+def pack_radiance_blob(precision: int, view_tiles: int, surf8, weight_g, weight_v, bias) -> torch.Tensor:
+    """nerfart_pack_radiance_blob: surf8 = (weight_g, weight_v, bias) of the SDF net's last layer (its rows 1.. make the geometry feature),
+    then the 5 radiance layers' tensors."""
+    dev = weight_v[0].device
+    n = int(lib.nerfart_radiance_blob_floats(int(precision), int(view_tiles)))
+    if n <= 0:
+        raise NerfartHipError(f"nerfart_radiance_blob_floats: {lib.nerfart_last_error().decode(errors='replace')}")
+    blob = torch.empty(n, dtype=torch.float32, device=dev)
+    ws = _workspace(int(lib.nerfart_pack_workspace_bytes()), dev)
+    s8 = [surf8[0].detach().reshape(-1).contiguous(), surf8[1].detach().contiguous(), surf8[2].detach().contiguous()]
+    g = [t.detach().reshape(-1).contiguous() for t in weight_g]
+    v = [t.detach().contiguous() for t in weight_v]
+    b = [t.detach().contiguous() for t in bias]
+    _check(lib.nerfart_pack_radiance_blob(int(precision), int(view_tiles), _dev(s8[0], name="surf8_g"), _dev(s8[1], name="surf8_v"), _dev(s8[2], name="surf8_bias"),
+                                          _ptr_table(g, "weight_g"), _ptr_table(v, "weight_v"), _ptr_table(b, "bias"), _dev(blob), n, ws.data_ptr(), ws.numel(),
+                                          _stream()), "nerfart_pack_radiance_blob")
+    blob.nerfart_term = {0: "fp32", 1: "bf16", 4: "fp16"}[int(precision)]
+    return blob
+
+
+def need_term(blob, term: str, who: str):
+    """Entry points that read ONE fragment encoding (the training kernels: split bf16) refuse a blob packed for another - the sizes and the
+    program id of a bf16 and an fp16 blob coincide, only header word 10 differs."""
+    have = getattr(blob, "nerfart_term", None)
+    if have is not None and have != term:
+        raise NerfartHipError(f"{who} reads {term} blobs; this blob was packed as {have}")
 
 
 def linspace(start: float, end: float, n: int) -> torch.Tensor:
@@ -469,6 +527,7 @@ def volsdf_render_bwd(surf_blob, rad_blob, view_tiles: int, multires: int, rays_
     """rgb.backward(g_rgb) + eikonal.backward() of one launch group of VolSDF rays (volsdf.py:759-770) -> accumulated into `raw`.
     rays_d un-normalised; d_all [R, P] from pass 1; state = (sdf [R P], nabla [R P, 3], h7 [R P, 256]) kept from pass 1 or None."""
     R, P = d_all.shape
+    need_term(surf_blob, "bf16", "nerfart_volsdf_render_bwd"); need_term(rad_blob, "bf16", "nerfart_volsdf_render_bwd")
     sdf, nab, h7 = state if state is not None else (None, None, None)
     nb = int(lib.nerfart_volsdf_render_bwd_workspace_bytes(R, P, int(state is not None)))
     ws = _workspace(nb, d_all.device)
@@ -484,6 +543,7 @@ def neus_render_bwd(surf_blob, rad_blob, view_tiles: int, multires: int, rays_o,
                     w_eikonal: float = 0.0, eik_group_rays: int = 0, train_radiance: bool = False, g_acc=None, state=None):
     """The same for NeuS (neus.py:520-576): state = (sdf [R P], nabla [R P, 3]) at the samples or None."""
     R, P = d_all.shape
+    need_term(surf_blob, "bf16", "nerfart_neus_render_bwd"); need_term(rad_blob, "bf16", "nerfart_neus_render_bwd")
     sdf, nab = state if state is not None else (None, None)
     nb = int(lib.nerfart_neus_render_bwd_workspace_bytes(R, P, int(state is not None)))
     ws = _workspace(nb, d_all.device)
@@ -497,6 +557,7 @@ def neus_render_bwd(surf_blob, rad_blob, view_tiles: int, multires: int, rays_o,
 def sdf_param_bwd(surf_blob, multires: int, pts, nbar, raw, sbar=None, hbar7=None):
     """Parameter gradients of sbar . sdf + hbar7 . h7 + nbar . grad_x sdf at pts [M, 3], accumulated into `raw`."""
     M = pts.shape[0]
+    need_term(surf_blob, "bf16", "nerfart_sdf_param_bwd")
     nb = int(lib.nerfart_sdf_param_bwd_workspace_bytes(M))
     ws = _workspace(nb, pts.device)
     _check(lib.nerfart_sdf_param_bwd(_dev(surf_blob), int(multires), _dev(pts, name="pts"), M, _dev(sbar, name="sbar"), _dev(hbar7, name="hbar7"),

@@ -17,7 +17,6 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import packing
 from . import hip
 
 
@@ -144,7 +143,6 @@ class _PackedModel(nn.Module):
             raise NotImplementedError("radiance embed_multires must be -1 and embed_multires_view in (-1, 4)")
         self.view_tiles = 1 if r.embed_multires_view == -1 else 3
         self._bind_owner()
-        self._plans = {}
         self._blobs = None
         self._blob_key = None
         self.precision = "fp32"
@@ -209,24 +207,31 @@ class _PackedModel(nn.Module):
         self._sampler_blob = None
         return self
 
+    def _surface_layers(self):
+        L = list(self.implicit_surface.surface_fc_layers)
+        return [l.weight_g for l in L], [l.weight_v for l in L], [l.bias for l in L]
+
+    def _pack_surface(self, precision: str) -> torch.Tensor:
+        """The SDF net's blob at `precision` through the C ABI (nerfart_pack_surface_blob: weight_norm fold, unit-order permutation, hi / lo split
+        on the device).  nerfart_amd/packing.py keeps the same layout as numpy plans - the source of truth of the CPU emulation
+        (tests/emul_chain.py) - and tests/test_pack_plan.py holds the library's closed-form layout equal to them, entry for entry."""
+        g, v, b = self._surface_layers()
+        return hip.pack_surface_blob(hip.PRECISIONS[precision], self.implicit_surface.embed_multires, g, v, b)
+
+    def _pack_radiance(self, precision: str) -> torch.Tensor:
+        last = self.implicit_surface.surface_fc_layers[self.implicit_surface.D]
+        R = list(self.radiance_net.layers)
+        return hip.pack_radiance_blob(hip.PRECISIONS[precision], self.view_tiles, (last.weight_g, last.weight_v, last.bias),
+                                      [l.weight_g for l in R], [l.weight_v for l in R], [l.bias for l in R])
+
     def packed_sampler(self):
         """(surface blob, precision id) for the sampler when it runs at its own precision; None otherwise."""
         if self.sampler_precision is None or self.sampler_precision == self.precision:
             return None
         key = (self.sampler_precision,) + tuple((p.data_ptr(), p._version) for p in self.implicit_surface.parameters())
         if self._sampler_blob is None or self._sampler_blob[0] != key:
-            s = self.implicit_surface
-            pkey = ("sampler", self.sampler_precision)
-            if pkey not in self._plans:                        # building a plan's index arrays takes ~0.1 s: once, not once per weight update
-                if self.sampler_precision == "fp32":
-                    self._plans[pkey] = packing.surface_plan(s.W, s.D, tuple(s.skips), s.embed_multires, s.W_geo_feat)
-                else:
-                    self._plans[pkey] = packing.surface_plan_bf16(s.W, s.D, tuple(s.skips), s.embed_multires, s.W_geo_feat,
-                                                                  term="fp16" if self.sampler_precision == "fp16x2" else "bf16")
-            plan = self._plans[pkey]
-            sd = {k: v.detach() for k, v in self.state_dict().items()}
             with torch.no_grad():
-                blob = plan.pack(packing.surface_tensors(sd, D=s.D))
+                blob = self._pack_surface(self.sampler_precision)
             self._sampler_blob = (key, blob)
         return self._sampler_blob[1], hip.PRECISIONS[self.sampler_precision]
 
@@ -234,32 +239,17 @@ class _PackedModel(nn.Module):
     def precision_id(self) -> int:
         return hip.PRECISIONS[self.precision]
 
-    def _get_plans(self):
-        if self.precision not in self._plans:
-            s, r = self.implicit_surface, self.radiance_net
-            if self.precision == "fp32":
-                self._plans[self.precision] = (packing.surface_plan(s.W, s.D, tuple(s.skips), s.embed_multires, s.W_geo_feat),
-                                               packing.radiance_plan(self.view_tiles, r.W, r.D, s.W_geo_feat))
-            else:
-                term = "fp16" if self.precision == "fp16x2" else "bf16"
-                self._plans[self.precision] = (packing.surface_plan_bf16(s.W, s.D, tuple(s.skips), s.embed_multires, s.W_geo_feat, term=term),
-                                               packing.radiance_plan_bf16(self.view_tiles, r.W, r.D, s.W_geo_feat, term=term))
-        return self._plans[self.precision]
-
     def _param_key(self):
         return (self.precision,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def packed(self):
         """(surface_blob, radiance_blob) for the current parameters; re-packed only after an
         in-place update (optimizer step / load_state_dict) - the reference re-folds weight_norm on
-        every forward, 77x per ray chunk."""
+        every forward, 77x per ray chunk.  Two kernel launches per blob (pack_blob.hip)."""
         key = self._param_key()
         if self._blobs is None or key != self._blob_key:
-            sd = {k: v.detach() for k, v in self.state_dict().items()}
-            sp, rp = self._get_plans()
             with torch.no_grad():
-                self._blobs = (sp.pack(packing.surface_tensors(sd, D=self.implicit_surface.D)),
-                               rp.pack(packing.radiance_tensors(sd, D_surf=self.implicit_surface.D, D=self.radiance_net.D)))
+                self._blobs = (self._pack_surface(self.precision), self._pack_radiance(self.precision))
             self._blob_key = key
         return self._blobs
 

@@ -278,6 +278,7 @@ def radiance_plan(view_tiles: int, W: int = 256, D: int = 4, W_geo_feat: int = 2
 PROG_SURFACE_BF16 = 3
 PROG_RADIANCE_BF16 = 4
 TS_FLOATS = 512           # one (k-step, output tile) of a chunk: (hi, lo) x 64 lanes x 8 bf16 = 2 KiB
+TERM_WORD = {"bf16": 1, "fp16": 2}      # header word 10 (ABI 3): the fragment encoding of a split blob - bf16 hi + lo / fp16 hi + lo
 
 
 def unit_feature_hidden(ks: int, g: int, e: int) -> int:
@@ -596,6 +597,7 @@ def surface_plan_bf16(W: int = 256, D: int = 8, skips=(4,), multires: int = 6, W
     # cat[h, enc] / sqrt(2) (base.py:250) is applied to the skip layer's weights instead of its inputs
     plan.scale = {f"w{l}": 1.0 / float(np.sqrt(2.0)) for l in skips}
     plan.term = term
+    plan.header[10] = TERM_WORD[term]
     return plan
 
 
@@ -644,6 +646,7 @@ def radiance_plan_bf16(view_tiles: int, W: int = 256, D: int = 4, W_geo_feat: in
         chunks.append(np.concatenate([_kstep_index_T(flat, "w8", ks, unit_feature_hidden, nat, row0=1) for ks in range(c0, c0 + CHUNK_KS)]))
     plan = PackPlanBF16(PROG_RADIANCE_BF16, flat, chunks, aux, nc_main=nc_fwd)
     plan.term = term
+    plan.header[10] = TERM_WORD[term]
     return plan
 
 

@@ -109,3 +109,24 @@ def test_documented_c_abi_only_render_binding_matches_the_trainer():
         else:
             assert torch.equal(got[n], p.grad), n
         assert float(p.grad.abs().max()) > 0, n
+
+
+def test_documented_pack_binding_produces_the_package_blobs():
+    """Section B's `_nerfart_pack.pack_blobs` (state-dict tensors -> blobs on the C ABI alone), executed as written, for the three precisions
+    and both view embeddings: the blobs of the package's own models, bit for bit - and the section C binding can render and differentiate
+    from them without importing anything of this repo."""
+    from nerfart_amd import hip, scene
+    text = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    code = next(b for b in blocks if "_nerfart_pack.py" in b and "def pack_blobs" in b)
+    code = code.replace('C.CDLL("libnerfart_hip.so")', f'C.CDLL({hip.LIB_PATH!r})')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md#B-pack", "exec"), ns)
+    for fw, vt in (("VolSDF", 1), ("NeuS", 3)):
+        for precision, pid in (("fp32", 0), ("bf16x3", 1), ("fp16x2", 4)):
+            model, _, _ = scene.build_model(fw, seed=0, beta=0.01 if fw == "VolSDF" else None, device=DEV, precision=precision)
+            surf, rad = ns["pack_blobs"](model, precision=pid, view_tiles=vt)
+            surf_pkg, rad_pkg = model.packed()
+            torch.cuda.synchronize()
+            assert torch.equal(surf.view(torch.int32), surf_pkg.view(torch.int32)), (fw, precision, "surface")
+            assert torch.equal(rad.view(torch.int32), rad_pkg.view(torch.int32)), (fw, precision, "radiance")

@@ -681,5 +681,6 @@ def test_finetune_branch_perturb_true_matches_the_reference_trainer(fw):
             assert worst_n <= P_NORM_TOL and worst_h < P_HEAD_TOL, (worst_n, worst_h)
         else:
             assert [a[0] for a in asked] == [1], asked                 # pass 2 reused pass 1's samples
-    if fw == "VolSDF":
-        assert results["reuse"][0] > 2 * NORM_TOL, ("re-using pass 1's samples is a different estimator under perturb=True", results)
+    # re-using pass 1's samples is a DIFFERENT estimator under perturb=True: measured leading-entries error 1.4e-1 (VolSDF) / 3.1e-2 (NeuS)
+    # against 9.5e-3 / 2.0e-3 when pass 2 draws its own samples as the reference does
+    assert results["reuse"][1] > 2 * P_HEAD_TOL and results["reuse"][1] > 3 * results["reference"][1], results
