@@ -455,6 +455,16 @@ int nerfart_pack_radiance_blob(int precision, int view_tiles, const float* surf8
                                void* workspace, long long workspace_bytes, void* stream);
 int nerfart_pack_plan_debug(int program, int view_tiles, int fp16, long long* sizes, int* header, int* cindex, int* cmul, float* cscale, int* aindex);
 
+/* The packers of the CLIP / VGG blobs (ABI 3; the weights are frozen: once per run).  CLIP: `tensors` = HOST array of
+ * nerfart_clip_vitb32_n_tensors() (= 152) DEVICE pointers to fp32 copies of the `visual.*` entries of the CLIP state dict, tensor i being
+ * `visual.` + the name nerfart_clip_vitb32_tensor_name(i, buf, len) writes (its return value: the element count; 0 = bad index) - matrices are
+ * stored fp16 (round to nearest even, like `clip.load(device="cuda")`'s weights), vectors fp32.  VGG16: weight[l] [Cout, Cin, 3, 3] / bias[l] of
+ * torchvision's `features.{0, 2, 5, 7, 10, 12, 14}` (criteria/perp_loss.py:9-33), fp32 -> the forward / transposed-flipped backward / bias sections. */
+int nerfart_clip_vitb32_n_tensors(void);
+long long nerfart_clip_vitb32_tensor_name(int i, char* name_out, int name_len);
+int nerfart_clip_vitb32_pack(const float* const* tensors, void* blob, long long blob_bytes, void* stream);
+int nerfart_vgg16_pack(const float* const* weight, const float* const* bias, void* blob, long long blob_bytes, void* stream);
+
 /* The GEMM kernel of the encoder on its own (tests): C[M,N] fp32 = A[M,K] fp16 . W[N,K]^T fp16; M, N, K multiples of 64. */
 int nerfart_gemm_f16_nt(const void* A, const void* W, int M, int N, int K, float* C, void* stream);
 /* ... and C[M,N] = A[M,K] . Wt[K,N] (second operand read with its reduction index as the row: the backward GEMMs on the forward

@@ -25,44 +25,36 @@ def blob_layout():
     return list(offs), int(total)
 
 
+def tensor_names():
+    """[(`visual.`-relative state-dict name, element count)] in the order nerfart_clip_vitb32_pack takes its tensors - read from the library."""
+    out = []
+    buf = C.create_string_buffer(96)
+    for i in range(hip.lib.nerfart_clip_vitb32_n_tensors()):
+        n = int(hip.lib.nerfart_clip_vitb32_tensor_name(i, buf, len(buf)))
+        out.append((buf.value.decode(), n))
+    return out
+
+
 def pack_visual(state, device) -> torch.Tensor:
-    """`visual.*` entries of a CLIP state dict -> the weight blob (uint8 tensor on `device`): fp16 matrices (each stored
-    once), fp32 vectors, in the section order of csrc/clip_vit.hip."""
-    offs, total = blob_layout()
-    blob = torch.zeros(total, dtype=torch.uint8, device=device)
+    """`visual.*` entries of a CLIP state dict -> the weight blob (uint8 tensor on `device`) through nerfart_clip_vitb32_pack: fp16 matrices
+    (each stored once), fp32 vectors, in the section order of csrc/clip_vit.hip.  The library names the tensors it wants."""
+    _, total = blob_layout()
 
     def g(name):
-        return state["visual." + name].detach().to(device)
-
-    def put(i, t, dtype):
-        t = t.to(dtype).contiguous().reshape(-1)
-        n = t.numel() * t.element_size()
-        assert offs[i] + n <= offs[i + 1], (i, n, offs[i + 1] - offs[i])
-        blob[offs[i]: offs[i] + n] = t.view(torch.uint8)
-
-    def put_pair(i, w):                       # W [N, K] fp16, once: the backward GEMM reads it in place (section i + 1 is empty)
-        put(i, w.to(torch.float16), torch.float16)
+        return state["visual." + name].detach()
 
     if g("conv1.weight").shape != (WIDTH, 3, PATCH, PATCH) or g("positional_embedding").shape != (50, WIDTH) or g("proj").shape != (WIDTH, OUT):
         raise ValueError("clip_native: not a ViT-B/32 visual tower (conv1 768x3x32x32, 50 positions, proj 768x512)")
-    put_pair(0, g("conv1.weight").reshape(WIDTH, -1))
-    for l in range(LAYERS):
-        p = f"transformer.resblocks.{l}."
-        s, f = 2 + 8 * l, 104 + 8 * l
-        put_pair(s + 0, g(p + "attn.in_proj_weight"))
-        put_pair(s + 2, g(p + "attn.out_proj.weight"))
-        put_pair(s + 4, g(p + "mlp.c_fc.weight"))
-        put_pair(s + 6, g(p + "mlp.c_proj.weight"))
-        for j, n in enumerate(("ln_1.weight", "ln_1.bias", "attn.in_proj_bias", "attn.out_proj.bias", "ln_2.weight", "ln_2.bias",
-                               "mlp.c_fc.bias", "mlp.c_proj.bias")):
-            put(f + j, g(p + n), torch.float32)
-    put(99, g("proj").to(torch.float16), torch.float16)          # [768, 512]: forward reads it as Wt[K, N], backward as W[N, K]
-    put(100, g("class_embedding"), torch.float32)
-    put(101, g("positional_embedding"), torch.float32)
-    put(102, g("ln_pre.weight"), torch.float32)
-    put(103, g("ln_pre.bias"), torch.float32)
-    put(200, g("ln_post.weight"), torch.float32)
-    put(201, g("ln_post.bias"), torch.float32)
+    tensors = []
+    for name, n in tensor_names():
+        t = g(name).to(device=device, dtype=torch.float32).contiguous()
+        if t.numel() != n:
+            raise ValueError(f"clip_native: visual.{name} has {t.numel()} elements, the ViT-B/32 tower has {n}")
+        tensors.append(t)
+    blob = torch.empty(total, dtype=torch.uint8, device=device)
+    table = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    with torch.cuda.device(blob.device):
+        _check(hip.lib.nerfart_clip_vitb32_pack(table, _ptr(blob), total, _stream()), "nerfart_clip_vitb32_pack")
     return blob
 
 

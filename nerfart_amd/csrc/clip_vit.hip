@@ -24,6 +24,7 @@
 //   k_ln_fwd / k_ln_bwd  one wave per token row (768 = 64 lanes x 3 float4), statistics in fp32; backward recomputes them.
 //   k_patchify / k_unpatchify, k_embed_lnpre / k_lnpre_bwd, k_lnpost / k_lnpost_bwd, k_gscale: the ends of the chain.
 #include "gemm_f16.h"
+#include <stdio.h>
 #include <cmath>
 
 namespace nerfart {
@@ -430,6 +431,51 @@ static int check_blob_bytes(long long blob_bytes) {
     return 0;
 }
 
+// ---- packer (ABI 3): `visual.*` state-dict tensors -> blob sections ---------------------------------------------------------------
+// The tensors in the order nerfart_clip_vitb32_pack takes them (OpenAI CLIP parameter names below `visual.`): 5 stem tensors, 12 per
+// residual block, 3 tail tensors = 152.  sec: the blob section; half: stored as fp16 (the GEMM operands) or fp32 (vectors).
+struct PackEntry { const char* name; int sec; int half; long long n; };
+static const char* BLOCK_NAMES[12] = {"ln_1.weight", "ln_1.bias", "attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj.weight", "attn.out_proj.bias",
+                                      "ln_2.weight", "ln_2.bias", "mlp.c_fc.weight", "mlp.c_fc.bias", "mlp.c_proj.weight", "mlp.c_proj.bias"};
+constexpr int N_PACK_TENSORS = 5 + 12 * 12 + 3;
+static PackEntry pack_entry(int i, char* name_buf, int name_len) {
+    auto set = [&](const char* s) { if (name_buf) snprintf(name_buf, name_len, "%s", s); };
+    if (i == 0) { set("conv1.weight"); return {nullptr, 0, 1, (long long)D * PK}; }
+    if (i == 1) { set("class_embedding"); return {nullptr, 100, 0, D}; }
+    if (i == 2) { set("positional_embedding"); return {nullptr, 101, 0, (long long)L * D}; }
+    if (i == 3) { set("ln_pre.weight"); return {nullptr, 102, 0, D}; }
+    if (i == 4) { set("ln_pre.bias"); return {nullptr, 103, 0, D}; }
+    if (i < 5 + 144) {
+        const int l = (i - 5) / 12, j = (i - 5) % 12;
+        if (name_buf) snprintf(name_buf, name_len, "transformer.resblocks.%d.%s", l, BLOCK_NAMES[j]);
+        const int s = 2 + 8 * l, f = 104 + 8 * l;
+        switch (j) {
+            case 0: return {nullptr, f + 0, 0, D};
+            case 1: return {nullptr, f + 1, 0, D};
+            case 2: return {nullptr, s + 0, 1, 3LL * D * D};
+            case 3: return {nullptr, f + 2, 0, 3LL * D};
+            case 4: return {nullptr, s + 2, 1, (long long)D * D};
+            case 5: return {nullptr, f + 3, 0, D};
+            case 6: return {nullptr, f + 4, 0, D};
+            case 7: return {nullptr, f + 5, 0, D};
+            case 8: return {nullptr, s + 4, 1, (long long)DM * D};
+            case 9: return {nullptr, f + 6, 0, DM};
+            case 10: return {nullptr, s + 6, 1, (long long)D * DM};
+            default: return {nullptr, f + 7, 0, D};
+        }
+    }
+    if (i == 149) { set("ln_post.weight"); return {nullptr, 200, 0, D}; }
+    if (i == 150) { set("ln_post.bias"); return {nullptr, 201, 0, D}; }
+    set("proj"); return {nullptr, 99, 1, (long long)D * DOUT};
+}
+__global__ void __launch_bounds__(256) k_pack_section(const float* __restrict__ src, void* __restrict__ dst, long long n, int to_half) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (to_half) reinterpret_cast<half_t*>(dst)[i] = (half_t)src[i];           // round to nearest even, like torch's .to(float16)
+        else reinterpret_cast<float*>(dst)[i] = src[i];
+    }
+}
+
 }  // namespace clip
 }  // namespace nerfart
 
@@ -439,6 +485,33 @@ using namespace nerfart::clip;
 extern "C" {
 
 long long nerfart_clip_vitb32_blob_layout(long long* offsets) { return blob_layout(offsets); }
+
+// The packer of the blob above.  tensors: HOST array of nerfart_clip_vitb32_n_tensors() DEVICE pointers to fp32 copies of the `visual.*`
+// entries of a CLIP state dict, in the order nerfart_clip_vitb32_tensor_name(i) names them (name_out: a caller buffer; the return value is
+// the tensor's element count, 0 for a bad index).  The blob (blob_bytes from nerfart_clip_vitb32_blob_layout) is written entirely: fp16
+// matrices, fp32 vectors, zero padding.
+int nerfart_clip_vitb32_n_tensors(void) { return N_PACK_TENSORS; }
+long long nerfart_clip_vitb32_tensor_name(int i, char* name_out, int name_len) {
+    if (i < 0 || i >= N_PACK_TENSORS) return 0;
+    return pack_entry(i, name_out, name_len).n;
+}
+int nerfart_clip_vitb32_pack(const float* const* tensors, void* blob, long long blob_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!tensors || !blob) { set_last_error("clip_vitb32_pack: NULL argument"); return 2; }
+    if (check_blob_bytes(blob_bytes)) return 1;
+    long long off[N_SECTIONS + 1];
+    blob_layout(off);
+    NERFART_HIP(hipMemsetAsync(blob, 0, (size_t)blob_bytes, st));
+    for (int i = 0; i < N_PACK_TENSORS; ++i) {
+        const PackEntry e = pack_entry(i, nullptr, 0);
+        if (!tensors[i]) { set_last_error("clip_vitb32_pack: NULL tensor pointer"); return 2; }
+        if (e.n * (e.half ? 2 : 4) != section_bytes(e.sec)) { set_last_error("clip_vitb32_pack: internal section table mismatch"); return 3; }
+        const long long blocks = (e.n + 255) / 256;
+        hipLaunchKernelGGL(k_pack_section, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, tensors[i], (char*)blob + off[e.sec], e.n, e.half);
+    }
+    NERFART_HIP(hipGetLastError());
+    return 0;
+}
 long long nerfart_clip_vitb32_workspace_bytes(int B, int keep_for_bwd) { return B >= 1 ? work_layout(B, keep_for_bwd).total : 0; }
 
 // C[M, N] fp32 = A[M, K] fp16 . W[N, K]^T fp16 (fp32 accumulate): the GEMM kernel on its own (tests).  M, N, K multiples of 64.

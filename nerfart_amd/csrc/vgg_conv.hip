@@ -167,6 +167,27 @@ static int check_geo(int H, int W) {
 }
 static unsigned grid_for(long long n) { return (unsigned)((n + 255) / 256 < 4096 * 64 ? (n + 255) / 256 : 4096 * 64); }
 
+// ---- packer (ABI 3): torchvision `features.{idx}.weight` [Cout, Cin, 3, 3] / `.bias` -> the three sections of conv l -----------------
+__global__ void __launch_bounds__(256) k_pack_conv(const float* __restrict__ w, const float* __restrict__ b, int l, int cin, int cout,
+                                                   float* __restrict__ fwd, float* __restrict__ bwd, float* __restrict__ bias) {
+    const long long stride = (long long)gridDim.x * blockDim.x, t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l == 0) {                                   // fwd [64, 32]: column c 9 + ky 3 + kx < 27; bwd [64, 64]: row k < 27 = W[:, k]
+        for (long long i = t0; i < 64 * 32; i += stride) { const int o = (int)(i / 32), k = (int)(i % 32); fwd[i] = k < 27 ? w[o * 27 + k] : 0.f; }
+        for (long long i = t0; i < 64 * 64; i += stride) { const int k = (int)(i / 64), o = (int)(i % 64); bwd[i] = k < 27 ? w[o * 27 + k] : 0.f; }
+    } else {
+        const long long n = 9LL * cin * cout;
+        for (long long i = t0; i < n; i += stride) {   // fwd [Cout, 9 Cin]: column (ky 3 + kx) Cin + c
+            const int o = (int)(i / (9 * cin)), r = (int)(i % (9 * cin)), kk = r / cin, c = r % cin;
+            fwd[i] = w[((long long)o * cin + c) * 9 + kk];
+        }
+        for (long long i = t0; i < n; i += stride) {   // bwd [Cin, 9 Cout]: column (ky' 3 + kx') Cout + o = W[o, c, 2 - ky', 2 - kx']
+            const int c = (int)(i / (9 * cout)), r = (int)(i % (9 * cout)), kk = r / cout, o = r % cout;
+            bwd[i] = w[((long long)o * cin + c) * 9 + (8 - kk)];
+        }
+    }
+    for (long long i = t0; i < cout; i += stride) bias[i] = b[i];
+}
+
 }  // namespace vgg
 }  // namespace nerfart
 
@@ -176,6 +197,25 @@ using namespace nerfart::vgg;
 extern "C" {
 
 long long nerfart_vgg16_blob_layout(long long* offsets) { return blob_layout(offsets); }
+
+// The packer of that blob: weight[l] [Cout_l, Cin_l, 3, 3], bias[l] [Cout_l] (HOST arrays of 7 DEVICE fp32 pointers: torchvision vgg16
+// `features.{0, 2, 5, 7, 10, 12, 14}`, the convolutions up to relu3_3, criteria/perp_loss.py:9-33) -> forward / backward / bias sections.
+int nerfart_vgg16_pack(const float* const* weight, const float* const* bias, void* blob, long long blob_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!weight || !bias || !blob) { set_last_error("vgg16_pack: NULL argument"); return 2; }
+    if (blob_bytes != blob_layout(nullptr)) { set_last_error("vgg16_pack: blob_bytes differs from nerfart_vgg16_blob_layout()"); return 1; }
+    long long off[N_SECTIONS + 1];
+    blob_layout(off);
+    NERFART_HIP(hipMemsetAsync(blob, 0, (size_t)blob_bytes, st));
+    char* bl = (char*)blob;
+    for (int l = 0; l < NCONV; ++l) {
+        if (!weight[l] || !bias[l]) { set_last_error("vgg16_pack: NULL tensor pointer"); return 2; }
+        hipLaunchKernelGGL(k_pack_conv, dim3(1024), dim3(256), 0, st, weight[l], bias[l], l, CIN[l], COUT[l], (float*)(bl + off[3 * l]),
+                           (float*)(bl + off[3 * l + 1]), (float*)(bl + off[3 * l + 2]));
+    }
+    NERFART_HIP(hipGetLastError());
+    return 0;
+}
 long long nerfart_vgg16_workspace_bytes(int H, int W, int keep_for_bwd) { return (H >= 8 && W >= 8) ? work_layout(H, W, keep_for_bwd).total : 0; }
 
 // img2 [2, 3, H, W] fp32: the normalised (and resized) prediction, then the target.  loss_out[0] = mean |relu3_3(pred) - relu3_3(target)|.

@@ -124,6 +124,10 @@ _SIGS = {
     "nerfart_pack_surface_blob": (_i, [_i, _i, _p, _p, _p, _p, _ll, _p, _ll, _p]),
     "nerfart_pack_radiance_blob": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p, _ll, _p, _ll, _p]),
     "nerfart_pack_plan_debug": (_i, [_i, _i, _i] + [_p] * 6),
+    "nerfart_clip_vitb32_n_tensors": (_i, []),
+    "nerfart_clip_vitb32_tensor_name": (_ll, [_i, _p, _i]),
+    "nerfart_clip_vitb32_pack": (_i, [_p, _p, _ll, _p]),
+    "nerfart_vgg16_pack": (_i, [_p, _p, _p, _ll, _p]),
 }
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)          # AttributeError here = header / library mismatch

@@ -81,25 +81,18 @@ class VGGPerceptualLoss(nn.Module):
         from . import hip
         key = tuple((p.data_ptr(), p._version) for p in self.net.parameters())
         if getattr(self, "_blob_key", None) != key:
-            offs = (C.c_longlong * 22)()
-            total = hip.lib.nerfart_vgg16_blob_layout(C.cast(offs, C.c_void_p))
+            total = int(hip.lib.nerfart_vgg16_blob_layout(None))
             dev = self.mean.device
-            blob = torch.zeros(total, dtype=torch.uint8, device=dev)
-
-            def put(i, t, dtype):
-                t = t.detach().to(dev).to(dtype).contiguous().reshape(-1)
-                blob[offs[i]: offs[i] + t.numel() * t.element_size()] = t.view(torch.uint8)
-            for l, (idx, cin, cout, _) in enumerate(_CONVS):
-                w, b = self.net.features[str(idx)].weight.detach().float(), self.net.features[str(idx)].bias
-                if l == 0:
-                    wf = torch.zeros(64, 64)
-                    wf[:, :27] = w.reshape(64, 27).cpu()                      # column c 9 + ky 3 + kx
-                    put(0, wf[:, :32], torch.float32)
-                    put(1, wf.t(), torch.float32)                             # row k = W[:, k]
-                else:
-                    put(3 * l, w.permute(0, 2, 3, 1).reshape(cout, 9 * cin), torch.float32)                       # (ky, kx, c)
-                    put(3 * l + 1, w.flip(2, 3).permute(1, 2, 3, 0).reshape(cin, 9 * cout), torch.float32)        # W[o, c, 2-ky', 2-kx']
-                put(3 * l + 2, b, torch.float32)
+            blob = torch.empty(total, dtype=torch.uint8, device=dev)
+            # nerfart_vgg16_pack: forward [Cout, 9 Cin], flipped-transposed backward [Cin, 9 Cout] and bias sections, on the device
+            ws = [self.net.features[str(idx)].weight.detach().to(device=dev, dtype=torch.float32).contiguous() for idx, _, _, _ in _CONVS]
+            bs = [self.net.features[str(idx)].bias.detach().to(device=dev, dtype=torch.float32).contiguous() for idx, _, _, _ in _CONVS]
+            wt = (C.c_void_p * len(ws))(*[t.data_ptr() for t in ws])
+            bt = (C.c_void_p * len(bs))(*[t.data_ptr() for t in bs])
+            with torch.cuda.device(dev):
+                rc = hip.lib.nerfart_vgg16_pack(wt, bt, C.c_void_p(blob.data_ptr()), total, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            if rc != 0:
+                raise RuntimeError("nerfart_vgg16_pack: " + hip.lib.nerfart_last_error().decode())
             self._blob, self._blob_key = blob, key
         return self._blob
 

@@ -110,3 +110,61 @@ def test_render_on_c_packed_blobs_equals_render_on_torch_packed_blobs(precision)
     assert float(same.float().mean()) >= 0.99
     pixel_budget(rgb_c[0].cpu(), rgb_t[0].cpu(), f"C-packed vs torch-packed blobs ({precision})", stable=(same & (ex_t["iter_usage"][0] >= 0)).cpu(),
                  over_frac=1.5e-2, max_abs=2e-2, psnr_min=70.0)
+
+
+def test_clip_blob_from_the_c_packer_equals_the_torch_statement():
+    """nerfart_clip_vitb32_pack against the section-by-section torch statement of the blob (fp16 matrices stored once, fp32 vectors, zero
+    padding), byte for byte; the library names the tensors it wants (nerfart_clip_vitb32_tensor_name)."""
+    import ctypes as C
+    from nerfart_amd import clip_vit, clip_native, hip
+    model = clip_vit.build_clip(DEV, seed=0)
+    state = model.state_dict()
+    names = clip_native.tensor_names()
+    assert len(names) == 152 and names[0] == ("conv1.weight", 768 * 3 * 32 * 32) and names[-1] == ("proj", 768 * 512)
+    assert all(("visual." + n) in state and state["visual." + n].numel() == k for n, k in names)
+    blob = clip_native.pack_visual(state, DEV)
+    offs, total = clip_native.blob_layout()
+    ref = torch.zeros(total, dtype=torch.uint8, device=DEV)
+
+    def put(i, t, dtype):
+        t = t.detach().to(DEV).to(dtype).contiguous().reshape(-1)
+        ref[offs[i]: offs[i] + t.numel() * t.element_size()] = t.view(torch.uint8)
+    g = lambda n: state["visual." + n]
+    put(0, g("conv1.weight").reshape(768, -1), torch.float16)
+    for l in range(12):
+        p, s, f = f"transformer.resblocks.{l}.", 2 + 8 * l, 104 + 8 * l
+        for j, n in ((0, "attn.in_proj_weight"), (2, "attn.out_proj.weight"), (4, "mlp.c_fc.weight"), (6, "mlp.c_proj.weight")):
+            put(s + j, g(p + n), torch.float16)
+        for j, n in enumerate(("ln_1.weight", "ln_1.bias", "attn.in_proj_bias", "attn.out_proj.bias", "ln_2.weight", "ln_2.bias", "mlp.c_fc.bias", "mlp.c_proj.bias")):
+            put(f + j, g(p + n), torch.float32)
+    put(99, g("proj"), torch.float16)
+    for i, n in ((100, "class_embedding"), (101, "positional_embedding"), (102, "ln_pre.weight"), (103, "ln_pre.bias"), (200, "ln_post.weight"), (201, "ln_post.bias")):
+        put(i, g(n), torch.float32)
+    torch.cuda.synchronize()
+    assert torch.equal(blob, ref)
+
+
+def test_vgg_blob_from_the_c_packer_equals_the_torch_statement():
+    import ctypes as C
+    from nerfart_amd import vgg, hip
+    m = vgg.VGGPerceptualLoss().to(DEV)
+    blob = m.packed()
+    offs = (C.c_longlong * 22)()
+    total = hip.lib.nerfart_vgg16_blob_layout(C.cast(offs, C.c_void_p))
+    ref = torch.zeros(total, dtype=torch.uint8, device=DEV)
+
+    def put(i, t):
+        t = t.detach().to(DEV).float().contiguous().reshape(-1)
+        ref[offs[i]: offs[i] + 4 * t.numel()] = t.view(torch.uint8)
+    for l, (idx, cin, cout, _) in enumerate(vgg._CONVS):
+        w, b = m.net.features[str(idx)].weight.detach().float(), m.net.features[str(idx)].bias
+        if l == 0:
+            wf = torch.zeros(64, 64, device=w.device)
+            wf[:, :27] = w.reshape(64, 27)
+            put(0, wf[:, :32]); put(1, wf.t())
+        else:
+            put(3 * l, w.permute(0, 2, 3, 1).reshape(cout, 9 * cin))
+            put(3 * l + 1, w.flip(2, 3).permute(1, 2, 3, 0).reshape(cin, 9 * cout))
+        put(3 * l + 2, b)
+    torch.cuda.synchronize()
+    assert blob.numel() == total and torch.equal(blob, ref)
