@@ -110,6 +110,14 @@ class GradAccumulator:
         folded, offs = hip.fold_weight_grads(raw, surf.embed_multires, rad.embed_multires_view)
         layers = list(surf.surface_fc_layers) + list(rad.layers)
         train_rad = any(p.requires_grad for p in rad.parameters())
+        # nerfart_fold_weight_grads is built for the shipped architecture (D 8, skip at 4, multires 6; radiance x-embedding -1): a model of
+        # another shape must not get silently misaligned gradients
+        if rad.embed_multires != -1 or len(offs) < 2 * len(layers) + 1:
+            raise RuntimeError("GradAccumulator.flush: the gradient fold is built for radiance embed_multires = -1 and the 9 + 5 layer nets")
+        for k, lyr in enumerate(layers):
+            if lyr.weight_v.numel() != offs[2 * k + 1] - offs[2 * k] or lyr.bias.numel() != offs[2 * k + 2] - offs[2 * k + 1]:
+                raise RuntimeError(f"GradAccumulator.flush: layer {k} is {tuple(lyr.weight_v.shape)}, the folded layout holds "
+                                   f"{offs[2 * k + 1] - offs[2 * k]} weights / {offs[2 * k + 2] - offs[2 * k + 1]} biases")
         for k, lyr in enumerate(layers):
             if k >= len(surf.surface_fc_layers) and not train_rad:
                 break

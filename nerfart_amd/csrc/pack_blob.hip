@@ -5,8 +5,8 @@
 //   nerfart_pack_radiance_blob  geometry-feature rows of its last layer + RadianceNet (:312-391) -> program 2 / 4
 //
 // Three things happen per element, all on the device, nothing allocated here:
-//   fold        w[o, :] = g[o] * v[o, :] / ||v[o, :]||  (nn.utils.weight_norm, dim 0): k_row_rnorm (one wave per row) + two multiplies at
-//               gather time, in ATen's order (g * v) * (1 / ||v||);
+//   fold        w[o, :] = g[o] * v[o, :] / ||v[o, :]||  (nn.utils.weight_norm, dim 0): k_row_rnorm (one block per row, ATen's summation
+//               order) + two multiplies at gather time, in ATen's order (g * v) * (1 / ||v||);
 //   permutation the blob's element j of chunk c reads source element src_of(c, j): CLOSED FORM - `chunk_desc` (what chunk c of a program
 //               is) and `elem_src` (which weight its element j is) below are the library's statement of the layout the kernels consume
 //               (mlp_chain.hip, mlp_bf16_core.h, mlp_k2_w32.hip, mlp_grad_bf16.hip, mlp_backward_bf16.hip).  Both are
@@ -321,10 +321,14 @@ __device__ __forceinline__ float value_of(const PackArgs& a, Src s) {
     return w;
 }
 
-// 1 / ||v[row, :]|| for every row of every layer: one wave per row
+// 1 / ||v[row, :]|| for every row of every layer: one 256-thread block per row, summed in the order of ATen's weight_norm forward
+// (aten/src/ATen/native/cuda/WeightNorm.cu, weight_norm_fwd_first_dim_kernel + reduce_block_into_lanes: thread t accumulates columns
+// t, t + 256, ...; shared-memory halving 128, 64; x[t] + x[t + 32]; shuffle-down 16 .. 1; sqrtf; 1.f / result), so that the folded weights
+// - and with them every blob - equal torch._weight_norm's on the same device bit for bit (tests/test_gpu_pack.py)
 __global__ void __launch_bounds__(256) k_row_rnorm(Tensors t, Prog p, int n_layers, float* __restrict__ rnorm) {
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    int l = 0, row = wave;
+    __shared__ float x[256];
+    const int tid = threadIdx.x;
+    int l = 0, row = blockIdx.x;
     for (; l < n_layers; ++l) {
         const int rows = p.radiance ? (l == 0 ? 257 : rad_dims(l - 1, p.n_extra).rows) : surf_dims(l).rows;
         if (row < rows) break;
@@ -333,10 +337,19 @@ __global__ void __launch_bounds__(256) k_row_rnorm(Tensors t, Prog p, int n_laye
     if (l >= n_layers) return;
     const int cols = p.radiance ? (l == 0 ? 256 : rad_dims(l - 1, p.n_extra).cols) : surf_dims(l).cols;
     const float* v = t.v[l] + (size_t)row * cols;
-    float s = 0.f;
-    for (int c = lane; c < cols; c += 64) s += v[c] * v[c];
-    for (int m = 32; m; m >>= 1) s += __shfl_xor(s, m, 64);
-    if (lane == 0) rnorm[t.rn_off[l] + row] = 1.f / sqrtf(s);
+    float thread_sum = 0.f;
+    for (int c = tid; c < cols; c += 256) { const float val = v[c]; thread_sum += val * val; }
+    x[tid] = thread_sum;
+    __syncthreads();
+    if (tid < 128) x[tid] = x[tid] + x[tid + 128];
+    __syncthreads();
+    if (tid < 64) x[tid] = x[tid] + x[tid + 64];
+    __syncthreads();
+    if (tid < 32) {
+        float fin = x[tid] + x[tid + 32];
+        for (int i = 16; i >= 1; i >>= 1) fin = fin + __shfl_down(fin, i);
+        if (tid == 0) { const float result = sqrtf(fin); rnorm[t.rn_off[l] + row] = 1.f / result; }
+    }
 }
 
 __device__ __forceinline__ int find_chunk(const PackArgs& a, int off) {
@@ -419,7 +432,7 @@ static int launch_pack(const Prog& p, const Tensors& t, int n_layers, float* blo
     }
     if (!workspace || workspace_bytes < (long long)rows * 4) { set_last_error("pack: workspace smaller than nerfart_pack_workspace_bytes()"); return 2; }
     float* rnorm = (float*)workspace;
-    hipLaunchKernelGGL(k_row_rnorm, dim3((rows * 64 + 255) / 256), dim3(256), 0, stream, tt, p, n_layers, rnorm);
+    hipLaunchKernelGGL(k_row_rnorm, dim3(rows), dim3(256), 0, stream, tt, p, n_layers, rnorm);
     NERFART_HIP(hipGetLastError());
     PackArgs a{};
     a.p = p; a.t = tt; a.rnorm = rnorm; a.blob = blob; a.nc_total = L.nc_total; a.aux_off = L.aux_off; a.total = L.total;

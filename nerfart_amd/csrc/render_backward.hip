@@ -236,15 +236,16 @@ static inline long long max3(long long a, long long b, long long c) { return a >
 
 // scratch of the SDF net's share: dumps, the two narrow operands, zero cotangents when an input is NULL, partial sums, split-K partials
 struct SurfWs { void *f2, *r2, *E2, *SO; float *zeros_h7, *zeros_s, *partial; void* wg; long long wg_bytes; };
-static SurfWs carve_surf(Carver& c, long long M) {
+// zero_h7 / zero_s: the caller will pass a NULL hbar7 / sbar cotangent (VolSDF always supplies both: no 1 KiB per point of zeros carved)
+static SurfWs carve_surf(Carver& c, long long M, bool zero_h7 = true, bool zero_s = true) {
     SurfWs w;
     const long long Mp = up(M, 64);
     w.f2 = c.bytes((size_t)nerfart_sdf_fwd2_dump_bytes(M));
     w.r2 = c.bytes((size_t)nerfart_sdf_bwd2_dump_bytes(M));
     w.E2 = c.bytes((size_t)2 * Mp * 128);
     w.SO = c.bytes((size_t)2 * Mp * 128);
-    w.zeros_h7 = c.take<float>((size_t)M * 256);
-    w.zeros_s = c.take<float>((size_t)M);
+    w.zeros_h7 = zero_h7 ? c.take<float>((size_t)M * 256) : nullptr;
+    w.zeros_s = zero_s ? c.take<float>((size_t)M) : nullptr;
     w.partial = c.take<float>((size_t)kSumBlocks * 4);
     w.wg_bytes = max3(nerfart_wgrad_workspace_bytes(7, 2 * Mp, 256), nerfart_wgrad_workspace_bytes(2, 2 * Mp, 64), nerfart_wgrad_workspace_bytes(1, 2 * Mp, 64));
     w.wg = c.bytes((size_t)w.wg_bytes);
@@ -257,6 +258,7 @@ static int surf_param_bwd(const float* surf_blob, int multires, const float* pts
                           float* raw, const SurfWs& w, const void** a7, hipStream_t st) {
     const long long Mp = up(M, 64);
     const long long slot = 2 * Mp * 512;                                   // bytes between the dumps' slots
+    if ((!hbar7 && !w.zeros_h7) || (!sbar && !w.zeros_s)) { set_last_error("surf_param_bwd: NULL cotangent without a carved zero buffer (internal)"); return 3; }
     if (!hbar7) { NERFART_HIP(hipMemsetAsync(w.zeros_h7, 0, (size_t)M * 256 * 4, st)); hbar7 = w.zeros_h7; }
     if (!sbar) { NERFART_HIP(hipMemsetAsync(w.zeros_s, 0, (size_t)M * 4, st)); sbar = w.zeros_s; }
     if (int rc = nerfart_sdf_fwd2(surf_blob, pts, nbar, M, w.f2, st)) return rc;
@@ -350,7 +352,7 @@ static VolWs carve_volsdf(Carver& c, long long R, int P, int have_state) {
     w.eik_ray = c.take<float>((size_t)R);
     w.partial = c.take<float>((size_t)kSumBlocks * 4);
     w.rad = carve_rad(c, M);
-    w.surf = carve_surf(c, M);
+    w.surf = carve_surf(c, M, false, false);                               // sbar and hbar7 (= g_h7 of the radiance net) are always supplied
     return w;
 }
 

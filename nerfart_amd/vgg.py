@@ -8,7 +8,7 @@ On the GPU the conv stack, the L1 and the backward pass to the prediction's pixe
 csrc/vgg_conv.hip (implicit-GEMM convolutions on the matrix cores, fp32 operands like the reference's torchvision net, behind
 `nerfart_vgg16_l1_fwd / _bwd`); the ImageNet normalisation + bilinear resize in front is one `nerfart_resample_fwd` gather.
 The torch formulation below (im2col via `F.unfold` + matmul, prediction and target as one batch of two) is the CPU path.
-`native=False` at construction (or NERFART_VGG_NATIVE=0 in the environment) forces the torch formulation on the GPU too.
+`native=False` at construction forces the torch formulation on the GPU too (the cross-check; it warns once when it runs).
 
 Weights: pass torchvision's `vgg16` state dict (`features.N.weight / bias`; N = 0, 2, 5, 7, 10, 12, 14 are read).  No
 ImageNet checkpoint exists offline, so the default is torchvision's own initialiser (seeded).  The arithmetic - both
@@ -66,9 +66,9 @@ class VGGPerceptualLoss(nn.Module):
 
     def __init__(self, state_dict=None, resize: bool = True, seed: int = 0, native: bool = None):
         super().__init__()
-        import os
-        env = os.environ.get("NERFART_VGG_NATIVE")
-        self.native = native if native is not None else (True if env is None else env == "1")
+        # native=False: the torch formulation on the GPU too - the cross-check the kernels are tested against; an explicit constructor
+        # argument only (no environment switch), and it warns once when it runs (criteria._warn_library_path)
+        self.native = True if native is None else bool(native)
         self.net = VGG16Features(state_dict, seed)
         self.register_buffer("mean", torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1))
         self.register_buffer("std", torch.tensor(IMAGENET_STD).view(1, 3, 1, 1))
@@ -113,6 +113,10 @@ class VGGPerceptualLoss(nn.Module):
             H, W = (224, 224) if self.resize else input.shape[-2:]
             if H % 4 == 0 and W % 4 == 0 and (H * W // 16) % 64 == 0:          # the kernels' tile geometry (always true with resize=True)
                 return self._native(input, target)
+        if input.is_cuda:                                  # never silently: the torch formulation (library kernels) is running on the GPU
+            from .criteria import _warn_library_path
+            _warn_library_path("VGGPerceptualLoss: torch formulation on the GPU (native=False, a batch, or a frame size outside the kernels' "
+                               "tile geometry) - the cross-check, not the hand-written convolutions")
         xy = torch.cat([input, target.to(input.dtype)], dim=0)
         xy = (xy - self.mean) / self.std
         if self.resize:

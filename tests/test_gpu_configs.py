@@ -141,13 +141,15 @@ def test_cfg5_960x540_frame_properties_and_oracle_subset(sampler):
     assert (depth_s[0].cpu() - ref["depth_volume"])[same].abs().max() < 1e-2
 
 
-def pixel_budget(got, ref, label, stable=None, over_frac=2e-3, max_abs=5e-3, psnr_min=82.0):
+def pixel_budget(got, ref, label, stable=None, over_frac=2e-3, max_abs=4e-3, psnr_min=82.0):
     """The north-star "pixel-for-pixel within 1e-3" as a sample-size independent statement of what CAN hold:
 
     * HARD 1e-3 on every channel of every `stable` ray = rays whose error-bounded up-sampling converged on the CPU (iter_usage >= 0) in the
       same number of rounds as on the GPU;
-    * the rest - rays that NEVER converge (iter_usage -1: they end on a bisected beta+) or flip a round - get a budget: at most 0.2 % of
-      all rays (at least one) past 1e-3, none past 5e-3, PSNR over the sample >= 82 dB.
+    * the rest - rays that NEVER converge (iter_usage -1: they end on a bisected beta+) or flip a round - get a budget pinned to what was
+      measured: at most 0.2 % of all rays past 1e-3 (= 5 of 2,048; measured 3 / 2 pure bf16x3, 4 / 1 mixed, 3 / 0 exact fp32 on the two views),
+      none past 4e-3 (measured max 2.5e-3; the oracle against itself under one-ulp weight noise 2.1e-3), PSNR over the sample >= 82 dB
+      (measured 83.7 .. 90.7).  The 32-spp frame (cfg 1) passes its own, measured figures (test_cfg1_64x64_32spp_in_full_vs_oracle).
 
     Why a budget at all: the CPU oracle ITSELF moves such rays by more than 1e-3 when the SDF weights change by one fp32 ulp
     (tools/oracle_sensitivity.py, profiles/r05_oracle_sensitivity_cfg{1,2}.json: 3 of 2,048 rays, max 2.1e-3, 86.2 dB at cfg 2; 22 of
@@ -209,6 +211,8 @@ def test_cfg2_bf16x3_full_frame_vs_oracle(view):
         errs[precision] = pixel_budget(got, ref["rgb"], f"{precision} vs oracle ({view} view)", stable=same & (ref["iter_usage"] >= 0))
         print(f"    identical up-sampling rounds on {float(same.float().mean()):.4f} of the rays; max depth error on those {float((dep - ref['depth_volume'])[same].abs().max()):.2e}")
         assert same.float().mean() >= 0.99
+        # depth on same-rounds rays: 2e-2, not the 1e-2 of round 3 - the EXACT-fp32 mode itself measures 1.29e-2 on the bench view (1.23e-2 for
+        # bf16x3 on the default view): a never-converged ray counts as "same rounds" (-1 on both sides) and its depth moves with its bisected beta+
         assert (dep - ref["depth_volume"])[same].abs().max() < 2e-2
     for i in (errs["bf16x3"] > 1e-3).nonzero().flatten().tolist():
         print(f"    ray {int(sel[i])}: bf16x3 {float(errs['bf16x3'][i]):.2e}, fp32 {float(errs['fp32'][i]):.2e}; rounds oracle / bf16x3 / fp32 = "
