@@ -1,5 +1,5 @@
-"""CPU side of the native CLIP image encoder (rows a23 / B4): the weight blob's section table (C side) and the packer
-(Python side) agree - every section round-trips; every matrix is stored once (the sections that held the transposed copies in
+"""CPU side of the native CLIP image encoder (rows a23 / B4): the weight blob's section table and the packer's tensor table (both C side)
+agree with the tower's parameters; every matrix is stored once (the sections that held the transposed copies in
 round 2 are empty: the backward GEMMs read the forward matrices in place).  No compute (no GPU here)."""
 import numpy as np
 import torch
@@ -17,18 +17,14 @@ def test_blob_layout_and_packing_round_trip():
     n_vec = sum(p.numel() for n, p in model.visual.named_parameters() if p.dim() < 2 or "positional" in n)
     assert 2 * n_mat + 4 * n_vec <= total < 2 * n_mat + 4 * n_vec + 256 * clip_native.N_SECTIONS
     sd = {"visual." + k: v for k, v in model.visual.state_dict().items()}
-    blob = clip_native.pack_visual(sd, "cpu")
-    assert blob.numel() == total
-
-    def sec(i, dtype, shape):
-        n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
-        return blob[offs[i]: offs[i] + n].view(dtype).reshape(shape)
-    w = sd["visual.transformer.resblocks.7.mlp.c_proj.weight"].half()
-    assert torch.equal(sec(2 + 8 * 7 + 6, torch.float16, (768, 3072)), w)
-    assert torch.equal(sec(0, torch.float16, (768, 3072)), sd["visual.conv1.weight"].reshape(768, -1).half())
-    assert torch.equal(sec(99, torch.float16, (768, 512)), sd["visual.proj"].half())
-    assert torch.equal(sec(101, torch.float32, (50, 768)), sd["visual.positional_embedding"].float())
-    assert torch.equal(sec(104 + 8 * 3 + 2, torch.float32, (2304,)), sd["visual.transformer.resblocks.3.attn.in_proj_bias"].float())
-    assert torch.equal(sec(201, torch.float32, (768,)), sd["visual.ln_post.bias"].float())
+    # the packer is the library's since round 5 (nerfart_clip_vitb32_pack: needs the GPU - its VALUES are held byte for byte to the torch statement
+    # of the blob in tests/test_gpu_pack.py); on the CPU: the library names the tensors it takes, and they are exactly the tower's parameters
+    names = clip_native.tensor_names()
+    assert len(names) == 152 == len(sd) and len({n for n, _ in names}) == 152
+    assert all(("visual." + n) in sd and sd["visual." + n].numel() == k for n, k in names)
+    n_half = sum(k for n, k in names if sd["visual." + n].dim() >= 2 and "positional" not in n)
+    assert n_half == n_mat and sum(k for _, k in names) == n_mat + n_vec
+    with __import__("pytest").raises(Exception):
+        clip_native.pack_visual(sd, "cpu")                       # no CPU path
     from nerfart_amd import hip
     assert hip.lib.nerfart_clip_vitb32_workspace_bytes(16, 1) > hip.lib.nerfart_clip_vitb32_workspace_bytes(16, 0) > 0
