@@ -385,13 +385,20 @@ def main():
         # (volsdf.py:724-728, :759-766): pass 1 on the fused renderer with random final samples, nothing kept; pass 2 runs Algorithm 1 AGAIN with
         # fresh draws and nerfart_volsdf_render_bwd re-evaluates the per-point state (have_state = 0).  tests: FP_* goldens of the reference Trainer.
         m3p, loss3p, eik3p, _ = bench_util.finetune_steps(ctx3, 2, warmup=1, perturb=True)
+        ctx3["trainer"].share_algorithm1 = False          # ... and with a SECOND full run of Algorithm 1 in pass 2 (how round 5 first built it)
+        m3q, _, _, _ = bench_util.finetune_steps(ctx3, 2, warmup=1, perturb=True)
+        ctx3["trainer"].share_algorithm1 = True
         secondary["cfg3_finetune_step"]["perturb_true"] = {
             "value": round(sum(m3p), 4), "unit": "s/step", "higher_is_better": False, "steps": 2, "rays_per_s": round(H * W / sum(m3p), 1),
             "pass1_render_s": round(m3p[0], 4), "style_losses_fwd_bwd_s": round(m3p[1], 4), "pass2_render_bwd_s": round(m3p[2], 4), "adam_s": round(m3p[3], 4),
-            "pass2_sampler_alone_s": round(bench_util.pass2_sampler_seconds(ctx3), 4), "loss": round(loss3p, 5), "eikonal": round(float(eik3p), 7),
-            "what": "render_kwargs_train['perturb'] = True, the reference's default: pass 2 = second Algorithm 1 (pass2_sampler_alone_s, timed on "
-                    "its own over the same ray batches) + forward re-evaluation + backward; Trainer(reuse_pass1_samples=True) is the opt-in that "
-                    "avoids it (INTEGRATION.md section F)"}
+            "loss": round(loss3p, 5), "eikonal": round(float(eik3p), 7),
+            "with_a_second_algorithm1_run": {"value": round(sum(m3q), 4), "unit": "s/step", "steps": 2, "pass1_render_s": round(m3q[0], 4),
+                                             "pass2_render_bwd_s": round(m3q[2], 4), "sampler_alone_s": round(bench_util.pass2_sampler_seconds(ctx3), 4)},
+            "what": "render_kwargs_train['perturb'] = True, the reference's default: pass 2 back-propagates through its OWN random final samples.  "
+                    "Algorithm 1 runs ONCE (its rounds draw nothing and would repeat exactly: the weights do not change between the passes) with two "
+                    "draws per ray - pass 1's fine samples and pass 2's (Trainer.render_two_draws); pass 2 = forward re-evaluation at its samples + "
+                    "backward.  with_a_second_algorithm1_run: Trainer(share_algorithm1=False) - the same samples for the same draws, bit for bit (tests).  "
+                    "Trainer(reuse_pass1_samples=True) is the opt-in that uses pass 1's samples (INTEGRATION.md section F)"}
         # the same (perturb=False) step in the OTHER split-bf16 mode (no gradient flows through the sampler, volsdf.py:479; the kept state and
         # pass 2 are split-bf16 in both)
         ctx3["model"].set_precision(other)

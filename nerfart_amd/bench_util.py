@@ -37,8 +37,10 @@ def finetune_setup(dev, H: int, W: int, beta: float = 0.01, with_vgg: bool = Tru
 def finetune_steps(ctx, steps: int, warmup: int = 1, keep: bool = True, profile: bool = False, perturb: bool = False):
     """`warmup` untimed + `steps` timed fine-tune steps.  Returns (mean seconds of [pass 1, style, pass 2, adam], last loss, last
     eikonal, launch-profile dict or None).  profile: nerfart_profile_begin / _end around the timed steps.
-    perturb=True: the reference's default render_kwargs_train (volsdf.py:982) - pass 1 on the fused renderer with random final samples,
-    nothing kept; pass 2 runs the sampler AGAIN with fresh draws and re-evaluates the per-point state (Trainer.resamples)."""
+    perturb=True: the reference's default render_kwargs_train (volsdf.py:982) - pass 2 back-propagates through its OWN random final samples
+    (Trainer.resamples).  Trainer.share_algorithm1 (default): one run of Algorithm 1 with two draws per ray serves both passes
+    (render_two_draws), pass 2 re-evaluates the per-point state at its samples; False: pass 1 on the fused renderer, pass 2 runs the sampler
+    again."""
     from . import hip
     tr, opt, o, d, rk, H, W = ctx["trainer"], ctx["opt"], ctx["o"], ctx["d"], ctx["rk"], ctx["H"], ctx["W"]
     if perturb:
@@ -55,6 +57,9 @@ def finetune_steps(ctx, steps: int, warmup: int = 1, keep: bool = True, profile:
         if keep:
             rgb, depths_all = tr.render_keep(o, d, **rk), None
             kept, tr._kept = tr._kept, None
+        elif tr.shares_algorithm1(rk):                     # pass 2's samples from pass 1's run of Algorithm 1 (Trainer.render_two_draws)
+            rgb = tr.render_two_draws(o, d, **rk)
+            depths_all, kept, tr._depths2 = tr._depths2, None, None
         elif resample:
             rgb, depths_all, kept = tr.render_image(ctx["render_fn"], o, d, **rk), None, None
         else:

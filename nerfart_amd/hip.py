@@ -233,7 +233,7 @@ def profile_end():
 
 
 # ---- point queries -----------------------------------------------------------------------
-PRECISIONS = {"fp32": 0, "bf16x3": 1, "fp16x2": 4}      # 4: the 2-MFMA measurement variant (never the default)
+PRECISIONS = {"fp32": 0, "bf16x3": 1, "fp16x2": 4}      # 4: the 2-MFMA kernels: the sampler of the shipped "mixed" mode (nets.set_precision); everywhere: a measurement variant
 
 
 def sdf_fwd(surf_blob, pts, R_bg: float, precision: int = 0):

@@ -16,7 +16,8 @@ backward re-evaluates the per-point state (`have_state = 0`).  With perturb=Fals
 (same weights, deterministic sampler), so pass 1 keeps its depths - and for VolSDF sdf / nablas / h7 - in HBM and pass 2 reads them:
 the same numbers for one sampler and one forward evaluation less.  `Trainer(reuse_pass1_samples=True)` asks for that reuse under
 perturb=True as well (a deviation: the gradient is then taken at the samples the loss was evaluated on; INTEGRATION.md section F);
-`Trainer(resample_pass2=True / False)` forces either behaviour.
+`Trainer(resample_pass2=True / False)` forces either behaviour.  VolSDF: pass 2's samples come from pass 1's run of Algorithm 1
+(`share_algorithm1`, render_two_draws: the rounds draw nothing and repeat exactly, only the final inverse-CDF reads uniform numbers).
 
 Other differences from the reference, all deliberate: several reference patches share one launch group
 (per-patch eikonal means kept); NeuS keeps `radiance_net` frozen exactly like neus.py:455-456.
@@ -38,7 +39,7 @@ _WARNED_AUTOGRAD = False
 class Trainer(nn.Module):
     def __init__(self, model, w_eikonal: float = 0.1, use_eikonal: bool = True, pass2_rays: int = 1200, native: bool = None,
                  patches_per_launch: int = 4, freeze_radiance: bool = None, pass1_groups: int = 4, resample_pass2: bool = None,
-                 reuse_pass1_samples: bool = False):
+                 reuse_pass1_samples: bool = False, share_algorithm1: bool = True):
         super().__init__()
         if not isinstance(model, (VolSDF, NeuS)):
             raise TypeError("Trainer expects a nerfart_amd VolSDF or NeuS model")
@@ -57,6 +58,14 @@ class Trainer(nn.Module):
         if reuse_pass1_samples and resample_pass2:
             raise ValueError("Trainer: reuse_pass1_samples=True contradicts resample_pass2=True")
         self.resample_pass2, self.reuse_pass1_samples = resample_pass2, bool(reuse_pass1_samples)
+        # VolSDF, pass 2 re-sampling: ONE run of Algorithm 1 serves both passes.  The weights do not change between the passes, so the
+        # reference's second fine_sample call repeats the first one's rounds exactly (volsdf.py:159-285 draw nothing); only the final
+        # opacity_invert_cdf_sample (:122-136, :287-300) reads fresh uniform numbers.  The sampler kernels invert a converged ray's CDF at
+        # however many numbers they are given, so pass 1 asks for 2 x N_importance per ray: the first half are its own fine samples, the
+        # second half pass 2's - bit-identical to a second sampler run with those numbers (tests), 0.37 s less per 480 x 270 step.
+        # False: pass 2 runs the sampler again (the cross-check).  NeuS: every up-sampling round draws (neus.py:296): nothing to share.
+        self.share_algorithm1 = bool(share_algorithm1)
+        self._depths2 = None
         # the uniform numbers of perturb=True: None = torch.rand on the device; a callable (pass_no, first_ray, n_rays, n, device) ->
         # [n_rays, n] lets a test feed the draws the reference made (tests/golden/make_golden_finetune.py records them per pass)
         self.uniform_source = None
@@ -112,6 +121,10 @@ class Trainer(nn.Module):
         if self.resample_pass2 is not None:
             return bool(self.resample_pass2)
         return bool(render_kwargs.get("perturb", False))
+
+    def shares_algorithm1(self, render_kwargs) -> bool:
+        """Pass 2 re-samples AND takes its samples from pass 1's run of Algorithm 1 (render_two_draws): native VolSDF steps."""
+        return bool(self.share_algorithm1 and self.resamples(render_kwargs) and not self.is_neus and self._native is not False)
 
     def _uniform(self, pass_no: int, first_ray: int, n_rays: int, n: int, device):
         if self.uniform_source is not None:
@@ -229,6 +242,55 @@ class Trainer(nn.Module):
                 kept.append((dj, sdf, nab, h7))
                 rgbs.append(rgb)
         self._kept = kept
+        return torch.cat(rgbs, 0) if rgbs else torch.zeros(0, 3, device=o.device)
+
+    @torch.no_grad()
+    def render_two_draws(self, rays_o, rays_d, **rk):
+        """Pass 1 of a VolSDF fine-tune step whose pass 2 draws its own samples (perturb=True), with Algorithm 1 run ONCE: every batch of rays
+        goes through the sampler with 2 x N_importance uniform numbers per ray - columns 0.. are pass 1's draw, N_importance.. pass 2's.
+        Pass 1's image is evaluated at the first set (sdf + nabla, radiance, composite: the fused renderer's stages, nothing kept); the
+        depths of the second set wait in self._depths2 [N, P] for backward_patches(depths_all=...), whose nerfart_volsdf_render_bwd
+        (have_state = 0) evaluates the per-point state there.  Returns rgb [N, 3]."""
+        m = self.model
+        if self.is_neus:
+            raise RuntimeError("render_two_draws: VolSDF only (NeuS draws in every up-sampling round)")
+        if m.precision != "bf16x3":
+            raise RuntimeError("render_two_draws feeds the native pass 2: set_precision('mixed') or ('bf16x3') first")
+        o = rays_o.reshape(-1, 3).float().contiguous()
+        d_raw = rays_d.reshape(-1, 3).float().contiguous()
+        surf_blob, rad_blob = m.packed()
+        samp_blob, samp_prec = m.packed_sampler() or (surf_blob, m.precision_id)
+        alpha, beta = m.forward_ab()
+        ab = (float(alpha.detach()), float(beta.detach()))
+        white = rk.get("white_bkgd", False)
+        ns, ni = rk.get("N_samples", 128), rk.get("N_importance", 64)
+        near, far = rk.get("near", 0.0), rk.get("far", 6.0)
+        P = ns + ni
+        step = self._launch_rays(P)
+        big = step * self.pass1_groups
+        t = hip.lin_table(ns, o.device)
+        rgbs, deps2 = [], []
+        for i in range(0, o.shape[0], big):
+            oi, di = o[i:i + big], d_raw[i:i + big]
+            n = oi.shape[0]
+            dn = hip.normalize_dirs(di)
+            u = torch.cat([self._uniform(1, i, n, ni, o.device), self._uniform(2, i, n, ni, o.device)], dim=1).contiguous()
+            d_fine, _, _ = hip.volsdf_fine_sample(samp_blob, oi, dn, near, far, rk.get("obj_bounding_radius", 3.0), ab[0], ab[1], rk.get("epsilon", 0.1),
+                                                  4 * ns, 4 * ns, 2 * ni, rk.get("max_upsample_steps", 5), rk.get("max_bisection_steps", 10),
+                                                  precision=samp_prec, u_final=u)
+            d_coarse = (near * (1.0 - t) + far * t)[None, :].expand(n, ns)
+            dep1 = torch.sort(torch.cat([d_coarse, d_fine[:, :ni]], dim=-1), dim=-1)[0]
+            deps2.append(torch.sort(torch.cat([d_coarse, d_fine[:, ni:]], dim=-1), dim=-1)[0])
+            for j in range(0, n, step):
+                dj = dep1[j:j + step].contiguous()
+                Rj = dj.shape[0]
+                pts, v = hip.ray_points(oi[j:j + step], dn[j:j + step], dj)
+                sdf, nab, h7 = hip.sdf_nabla_fwd(surf_blob, pts, m.obj_bounding_radius, precision=m.precision_id)
+                rgb_pt = hip.radiance_fwd(rad_blob, m.view_tiles, pts, v, nab, h7, precision=m.precision_id)
+                rgb, _, _ = hip.volsdf_composite(dj, sdf.reshape(Rj, P), rgb_pt.reshape(Rj, P, 3), ab[0], ab[1], white)
+                rgbs.append(rgb)
+                del sdf, nab, h7, rgb_pt
+        self._depths2 = torch.cat(deps2, 0) if deps2 else torch.zeros(0, P, device=o.device)
         return torch.cat(rgbs, 0) if rgbs else torch.zeros(0, 3, device=o.device)
 
     def backward_patches(self, rays_o, rays_d, gradient, depths_all=None, kept=None, **render_kwargs):
@@ -507,12 +569,17 @@ class Trainer(nn.Module):
         tile = self.pass2_rays if tile is None else tile
         resample = self.resamples(render_kwargs)           # pass 2 draws its own samples (the reference under perturb=True)
         keep = self.native and not resample                # pass 1 keeps its per-point state for pass 2 (render_keep)
-        self._kept = None
+        share = self.shares_algorithm1(render_kwargs)      # ... from the SAME run of Algorithm 1 (VolSDF: render_two_draws)
+        self._kept = self._depths2 = None
         if sharded:
             kw = {k: v for k, v in render_kwargs.items() if k != "rayschunk"}
             if keep:
                 def fn(ro, rd, **kw_):
                     r = self.render_keep(ro, rd, **kw_)
+                    return r, None, {"rgb": r[None]}
+            elif share:
+                def fn(ro, rd, **kw_):
+                    r = self.render_two_draws(ro, rd, **kw_)
                     return r, None, {"rgb": r[None]}
             else:
                 def fn(ro, rd, **kw_):
@@ -524,6 +591,9 @@ class Trainer(nn.Module):
             depths_all = None
         elif keep:
             rgb, depths_all = self.render_keep(rays_o, rays_d, **render_kwargs), None
+        elif share:
+            rgb = self.render_two_draws(rays_o, rays_d, **render_kwargs)
+            depths_all = self._depths2
         elif resample:
             rgb, depths_all = self.render_image(render_fn, rays_o, rays_d, **render_kwargs), None
         else:
@@ -539,7 +609,7 @@ class Trainer(nn.Module):
         if sharded:
             idx = nd.shard_plan(rgb.shape[1], tile, rgb.device).idx          # cached per (frame size, tile, world)
             eik = self.backward_patches(rays_o.reshape(-1, 3)[idx], rays_d.reshape(-1, 3)[idx], gradient[0][idx], kept=self._kept,
-                                        **render_kwargs)
+                                        depths_all=self._depths2, **render_kwargs)
             # ranks that own fewer parameters' gradients than others (none here: every rank touches every tensor)
             for p in self.model.parameters():
                 if p.requires_grad and p.grad is None:
@@ -547,7 +617,7 @@ class Trainer(nn.Module):
             nd.allreduce_gradients([p for p in self.model.parameters() if p.requires_grad])
         else:
             eik = self.backward_patches(rays_o, rays_d, gradient[0], depths_all=depths_all, kept=self._kept, **render_kwargs)
-        self._kept = None
+        self._kept = self._depths2 = None
         return {"loss": float(loss.detach()), "eikonal": eik, "rgb": rgb.detach()}
 
 

@@ -71,3 +71,45 @@ def test_get_model_configures_but_does_not_load_the_style_losses():
         cfg.training.is_finetune = False
         _, trainer2, _, _, _ = frameworks.get_model(cfg, [480, 270])
         assert trainer2._style_cfg is None
+
+
+def test_get_model_ships_the_mixed_mode_and_the_yaml_can_override_it():
+    """`model, trainer, ... = get_model(args); trainer(...)` must train without a further call: get_model sets the kernels' arithmetic -
+    'mixed' by default (split-bf16 for every value that reaches a pixel or carries a gradient, VolSDF's no-gradient Algorithm-1 sampler on
+    the 2-MFMA fp16 kernels; NeuS has no such sampler: split-bf16), `model.precision` in the YAML / `--model:precision` overrides it."""
+    from nerfart_amd import scene, frameworks
+    m, tr, rk_train, _, _ = frameworks.get_model(scene.synthetic_config("VolSDF"))
+    assert (m.precision, m.sampler_precision, m.mode) == ("bf16x3", "fp16x2", "mixed") and tr.native is True
+    assert rk_train["perturb"] is True                      # the reference's default render_kwargs_train (volsdf.py:982) ...
+    assert tr.resamples(rk_train) and not tr.resamples(dict(rk_train, perturb=False))      # ... under which pass 2 draws its own samples
+    n, _, _, _, _ = frameworks.get_model(scene.synthetic_config("NeuS"))
+    assert (n.precision, n.sampler_precision, n.mode) == ("bf16x3", None, "bf16x3")
+    for name, want in (("bf16x3", ("bf16x3", None)), ("fp32", ("fp32", None)), ("mixed", ("bf16x3", "fp16x2"))):
+        cfg = scene.synthetic_config("VolSDF")
+        cfg.model.precision = name
+        m2, tr2, _, _, _ = frameworks.get_model(cfg)
+        assert (m2.precision, m2.sampler_precision) == want
+        if name == "fp32":
+            with pytest.raises(RuntimeError, match="split-bf16"):
+                tr2.native
+    m.set_sampler_precision("fp32")
+    assert m.mode == "bf16x3+fp32 sampler"
+    m.set_precision("bf16x3")                               # a precision is the whole mode: it resets the sampler's
+    assert m.sampler_precision is None
+    with pytest.raises(ValueError):
+        m.set_precision("tf32")
+
+
+def test_trainer_two_pass_knobs():
+    from nerfart_amd import scene, frameworks
+    from nerfart_amd.trainer import Trainer
+    m, _, _, _, _ = frameworks.get_model(scene.synthetic_config("VolSDF"))
+    assert Trainer(m, reuse_pass1_samples=True).resamples({"perturb": True}) is False
+    assert Trainer(m, resample_pass2=True).resamples({"perturb": False}) is True
+    assert Trainer(m, resample_pass2=False).resamples({"perturb": True}) is False
+    with pytest.raises(ValueError, match="contradicts"):
+        Trainer(m, reuse_pass1_samples=True, resample_pass2=True)
+    tr = Trainer(m)
+    tr.uniform_source = lambda p, first, count, n, dev: __import__("torch").zeros(count + 1, n)
+    with pytest.raises(ValueError, match="uniform_source returned"):
+        tr._uniform(1, 0, 4, 64, "cpu")

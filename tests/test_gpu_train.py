@@ -684,3 +684,83 @@ def test_finetune_branch_perturb_true_matches_the_reference_trainer(fw):
     # re-using pass 1's samples is a DIFFERENT estimator under perturb=True: measured leading-entries error 1.4e-1 (VolSDF) / 3.1e-2 (NeuS)
     # against 9.5e-3 / 2.0e-3 when pass 2 draws its own samples as the reference does
     assert results["reuse"][1] > 2 * P_HEAD_TOL and results["reuse"][1] > 3 * results["reference"][1], results
+
+
+@pytest.mark.parametrize("sampler", [None, "fp16x2"])
+def test_one_run_of_algorithm1_serves_two_draws_bit_for_bit(sampler):
+    """Trainer.share_algorithm1: the sampler kernels invert a converged ray's opacity CDF at however many uniform numbers they are handed, so ONE
+    run with [u1 | u2] (2 x N_importance columns) must return exactly what two runs with u1 and with u2 return - every ray, every bit, converged in
+    round 0, later, or never (the three kernels that emit final samples)."""
+    from nerfart_amd import hip, scene, rend_util
+    model, rk, _ = scene.build_model("VolSDF", seed=0, beta=0.01, device=DEV, precision="bf16x3")
+    model.set_sampler_precision(sampler)
+    blob, prec = model.packed_sampler() or (model.packed()[0], model.precision_id)
+    H, W = 40, 30
+    c2w, K = scene.camera(H, W)
+    o, d, _ = rend_util.get_rays(c2w[None].to(DEV), K[None].to(DEV), H, W)
+    o, dn = o[0].contiguous(), hip.normalize_dirs(d[0].contiguous())
+    alpha, b = (float(x.detach()) for x in model.forward_ab())
+    g = torch.Generator(device=DEV).manual_seed(3)
+    u1, u2 = torch.rand(H * W, 64, device=DEV, generator=g), torch.rand(H * W, 64, device=DEV, generator=g)
+    run = lambda u, n: hip.volsdf_fine_sample(blob, o, dn, 0.0, 6.0, 3.0, alpha, b, 0.1, 512, 512, n, 6, 10, precision=prec, u_final=u)
+    d12, bm12, us12 = run(torch.cat([u1, u2], 1).contiguous(), 128)
+    d1, bm1, us1 = run(u1, 64)
+    d2, bm2, us2 = run(u2, 64)
+    kinds = {int(k): int(v) for k, v in zip(*torch.unique(us12, return_counts=True))}
+    print(f"  sampler {sampler or 'bf16x3'}: rays by iter_usage {kinds}")
+    assert -1 in kinds and len(kinds) >= 3, "the scene must exercise the never-converged and several converged paths"
+    assert torch.equal(us12, us1) and torch.equal(us12, us2) and torch.equal(bm12, bm1) and torch.equal(bm12, bm2)
+    assert torch.equal(d12[:, :64], d1) and torch.equal(d12[:, 64:], d2)
+
+
+def test_shared_algorithm1_step_equals_the_step_with_a_second_sampler_run():
+    """perturb=True with Trainer.share_algorithm1 (one sampler run, two draws: render_two_draws) against share_algorithm1=False (pass 2 runs the
+    sampler again), fed the same uniform numbers: pass 2 sees IDENTICAL depths and runs identical kernels - for the same d loss / d rgb the
+    parameter gradients are equal bit for bit (ln_beta: to the order of the compositor's atomics); pass 1's image (the renderer's stages called
+    one by one) equals the fused renderer's to 7e-6, and so do the whole steps."""
+    from nerfart_amd import scene, rend_util
+    from nerfart_amd.trainer import Trainer
+    H, W = 12, 9
+    c2w, K = scene.camera(H, W)
+    g = torch.Generator().manual_seed(5)
+    target = (torch.rand(1, H * W, 3, generator=g) * 0.3 + 0.5).to(DEV)
+    tables = {1: torch.rand(H * W, 64, generator=g), 2: torch.rand(H * W, 64, generator=g)}
+    cot = (torch.rand(H * W, 3, generator=g) * 1e-2).to(DEV)
+    source = lambda p, first, count, n, dev: tables[p][first:first + count, :n].to(dev)
+    model, rk, render_fn = scene.build_model("VolSDF", seed=0, beta=0.01, device=DEV, precision="mixed")
+    o, d, _ = rend_util.get_rays(c2w[None].to(DEV), K[None].to(DEV), H, W)
+    kw = dict({k: v for k, v in rk.items() if k != "rayschunk"}, perturb=True)
+    trs = {}
+    for share in (True, False):
+        trs[share] = Trainer(model, pass2_rays=40, patches_per_launch=2, pass1_groups=1, share_algorithm1=share)
+        trs[share].uniform_source = source
+        assert trs[share].resamples(kw) and trs[share].shares_algorithm1(kw) == share
+    # pass 2 on its own, same cotangent: depths from pass 1's sampler run vs a second sampler run
+    rgb_staged = trs[True].render_two_draws(o, d, **kw)
+    dep2 = trs[True]._depths2
+    grads = {}
+    for share in (True, False):
+        model.zero_grad()
+        eik = trs[share].backward_patches(o, d, cot, depths_all=dep2 if share else None, **kw)
+        grads[share] = (eik, {n: p.grad.clone() for n, p in model.named_parameters()})
+    assert grads[True][0] == grads[False][0]
+    for n in grads[True][1]:
+        if n == "ln_beta":                                   # d alpha / d beta are summed by the compositor's atomics: order-dependent in the last bits
+            assert torch.allclose(grads[True][1][n], grads[False][1][n], rtol=1e-5, atol=0), n
+        else:
+            assert torch.equal(grads[True][1][n], grads[False][1][n]), n
+    # pass 1: the stages one by one vs the fused renderer with the same draw
+    rgb_fused, _, _ = render_fn(o, d, require_nablas=True, calc_normal=True, detailed_output=False, uniforms=tables[1].to(DEV), **kw)
+    e = float((rgb_staged - rgb_fused[0]).abs().max())
+    print(f"  pass-1 image, stages vs fused renderer (same draw): max |diff| {e:.2e}")
+    assert e <= 2e-5                                         # measured 6.9e-6 (render_keep's stages against the fused renderer: held to 2e-4 since round 2)
+    # ... and the whole steps
+    res = {}
+    for share in (True, False):
+        model.zero_grad()
+        out = trs[share].finetune_step(render_fn, o, d, target, H, lambda pred, gt: ((pred - gt) ** 2).mean(), **kw)
+        res[share] = (out["rgb"].clone(), out["loss"], {n: p.grad.clone() for n, p in model.named_parameters()})
+    assert float((res[True][0] - res[False][0]).abs().max()) <= 2e-5 and abs(res[True][1] - res[False][1]) <= 1e-5 * abs(res[False][1])
+    for n in res[True][2]:
+        a, b = res[True][2][n], res[False][2][n]
+        assert float((a - b).norm()) <= 1e-3 * float(b.norm()) + 1e-12, n       # d loss / d rgb inherits the images' 7e-6

@@ -20,14 +20,18 @@ def main():
     ap.add_argument("--patches-per-launch", type=int, default=4)
     ap.add_argument("--no-keep", action="store_true")
     ap.add_argument("--perturb", action="store_true", help="render_kwargs_train as the reference builds them (perturb=True, volsdf.py:982): pass 2 re-samples")
+    ap.add_argument("--second-sampler-run", action="store_true", help="with --perturb: pass 2 runs Algorithm 1 again (Trainer(share_algorithm1=False)) "
+                    "instead of taking its samples from pass 1's run")
     ap.add_argument("--no-vgg", action="store_true", help="leave the VGG16 perceptual term (random weights) out of the style loss")
     args = ap.parse_args()
     from nerfart_amd import bench_util
     dev = torch.device("cuda", 0)
     H, W = args.H, args.W
     ctx = bench_util.finetune_setup(dev, H, W, with_vgg=not args.no_vgg, pass2_rays=args.pass2_rays, patches_per_launch=args.patches_per_launch)
+    ctx["trainer"].share_algorithm1 = not args.second_sampler_run
     m, loss, eik, _ = bench_util.finetune_steps(ctx, args.steps, warmup=1, keep=not args.no_keep, perturb=args.perturb)
-    extra = {"perturb": args.perturb, "pass2_resamples": ctx["trainer"].resamples(dict(ctx["rk"], perturb=args.perturb))}
+    rkp = dict(ctx["rk"], perturb=args.perturb)
+    extra = {"perturb": args.perturb, "pass2_resamples": ctx["trainer"].resamples(rkp), "one_algorithm1_run_for_both_passes": ctx["trainer"].shares_algorithm1(rkp)}
     if extra["pass2_resamples"]:
         extra["pass2_sampler_alone_s"] = round(bench_util.pass2_sampler_seconds(ctx), 3)
     print(json.dumps({**extra, "workload": f"fine-tune step {H}x{W}, VolSDF 128+64 spp, CLIP ViT-B/32 + VGG16 random weights", "steps": args.steps, "pass1_state_kept": not args.no_keep, "patches_per_launch": args.patches_per_launch, "vgg_perceptual_term": not args.no_vgg,
