@@ -13,7 +13,7 @@ import torch
 
 
 def finetune_setup(dev, H: int, W: int, beta: float = 0.01, with_vgg: bool = True, pass2_rays: int = 1200, patches_per_launch: int = 4,
-                   angle: float = 0.0, precision: str = "mixed"):
+                   angle: float = 0.0, precision: str = "mixed", pass1_groups: int = None):
     from . import scene, rend_util, criteria, clip_vit, vgg
     from .trainer import Trainer
     model, rk, render_fn = scene.build_model("VolSDF", seed=0, beta=beta, device=dev, precision=precision)
@@ -29,7 +29,7 @@ def finetune_setup(dev, H: int, W: int, beta: float = 0.01, with_vgg: bool = Tru
     g = torch.Generator(device="cpu").manual_seed(0)
     noise = torch.nn.functional.interpolate(torch.randn(1, 3, H // 8, W // 8, generator=g), size=(H, W), mode="bicubic", align_corners=False)
     target = (target.reshape(1, H, W, 3) + 0.1 * noise.permute(0, 2, 3, 1).to(dev)).clamp(0, 1).reshape(1, -1, 3)
-    tr = Trainer(model, pass2_rays=pass2_rays, patches_per_launch=patches_per_launch)
+    tr = Trainer(model, pass2_rays=pass2_rays, patches_per_launch=patches_per_launch, **({} if pass1_groups is None else {"pass1_groups": pass1_groups}))
     opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-5)
     return dict(model=model, rk=rk, render_fn=render_fn, o=o, d=d, style=style, target=target, trainer=tr, opt=opt, H=H, W=W)
 

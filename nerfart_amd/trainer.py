@@ -11,8 +11,8 @@
 The two passes and `perturb` (volsdf.py:724-728, :759-766, :982; neus.py:520-576, :742): the reference calls its renderer with
 `render_kwargs_train` in BOTH passes, and `perturb` defaults to True there - pass 2 draws NEW uniform numbers for the 64 inverse-CDF
 samples of every ray and back-propagates d loss / d rgb (evaluated on pass 1's image) through THOSE samples.  This Trainer does the
-same: with perturb=True pass 1 keeps nothing, every group of pass 2 runs the sampler again with fresh draws and the ray-level
-backward re-evaluates the per-point state (`have_state = 0`).  With perturb=False re-sampling reproduces pass 1's samples exactly
+same: with perturb=True pass 1 keeps no per-point state, pass 2 gets fresh random samples (NeuS: the sampler runs again; VolSDF: see
+`share_algorithm1` below) and the ray-level backward re-evaluates the per-point state there (`have_state = 0`).  With perturb=False re-sampling reproduces pass 1's samples exactly
 (same weights, deterministic sampler), so pass 1 keeps its depths - and for VolSDF sdf / nablas / h7 - in HBM and pass 2 reads them:
 the same numbers for one sampler and one forward evaluation less.  `Trainer(reuse_pass1_samples=True)` asks for that reuse under
 perturb=True as well (a deviation: the gradient is then taken at the samples the loss was evaluated on; INTEGRATION.md section F);

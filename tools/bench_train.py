@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--W", type=int, default=270)
     ap.add_argument("--pass2-rays", type=int, default=1200)
     ap.add_argument("--patches-per-launch", type=int, default=4)
+    ap.add_argument("--pass1-groups", type=int, default=None, help="launch groups per set of sampler launches (Trainer.pass1_groups; default 4)")
     ap.add_argument("--no-keep", action="store_true")
     ap.add_argument("--perturb", action="store_true", help="render_kwargs_train as the reference builds them (perturb=True, volsdf.py:982): pass 2 re-samples")
     ap.add_argument("--second-sampler-run", action="store_true", help="with --perturb: pass 2 runs Algorithm 1 again (Trainer(share_algorithm1=False)) "
@@ -27,7 +28,7 @@ def main():
     from nerfart_amd import bench_util
     dev = torch.device("cuda", 0)
     H, W = args.H, args.W
-    ctx = bench_util.finetune_setup(dev, H, W, with_vgg=not args.no_vgg, pass2_rays=args.pass2_rays, patches_per_launch=args.patches_per_launch)
+    ctx = bench_util.finetune_setup(dev, H, W, with_vgg=not args.no_vgg, pass2_rays=args.pass2_rays, patches_per_launch=args.patches_per_launch, pass1_groups=args.pass1_groups)
     ctx["trainer"].share_algorithm1 = not args.second_sampler_run
     m, loss, eik, _ = bench_util.finetune_steps(ctx, args.steps, warmup=1, keep=not args.no_keep, perturb=args.perturb)
     rkp = dict(ctx["rk"], perturb=args.perturb)
