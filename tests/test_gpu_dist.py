@@ -65,6 +65,60 @@ def test_sharded_finetune_step_two_ranks_one_gpu(tmp_path):
     assert sorted(f for f in os.listdir(tmp_path)) == ["ok0", "ok1"]
 
 
+def _perturb_worker(rank, world, port, out_dir):
+    """The sharded fine-tune step at the reference's DEFAULT render_kwargs_train (perturb=True): pass 2 back-propagates through its own random
+    samples, taken from pass 1's run of Algorithm 1 (Trainer.render_two_draws) on the rank's rays.  Fed per-ray uniform tables (indexed by
+    the GLOBAL ray id), the all-reduced gradients equal the single-process step's."""
+    import torch.distributed as dist
+    from nerfart_amd import scene, rend_util, dist as nd
+    from nerfart_amd.trainer import Trainer
+    try:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        dev = "cuda"
+        model, rk, render_fn = scene.build_model("VolSDF", seed=0, beta=0.01, device=dev, precision="mixed")
+        H, W = 10, 7
+        c2w, K = scene.camera(H, W)
+        o, d, _ = rend_util.get_rays(c2w[None].to(dev), K[None].to(dev), H, W)
+        g = torch.Generator().manual_seed(2)
+        target = (torch.rand(1, H * W, 3, generator=g) * 0.2 + 0.6).to(dev)
+        tables = {1: torch.rand(H * W, 64, generator=g), 2: torch.rand(H * W, 64, generator=g)}
+        loss_fn = lambda pred, gt: ((pred - gt) ** 2).mean()
+        kw = dict({k: v for k, v in rk.items() if k != "rayschunk"}, perturb=True)
+        mine = nd.my_ray_indices(H * W, 8, rank, world)
+        tr = Trainer(model, pass2_rays=8, patches_per_launch=2)
+        assert tr.shares_algorithm1(kw)
+        tr.uniform_source = lambda p, first, count, n, dv: tables[p][mine[first:first + count], :n].to(dv)
+        model.zero_grad()
+        out = tr.finetune_step(render_fn, o, d, target, H, loss_fn, **kw)
+        sharded = {n: p.grad.clone() for n, p in model.named_parameters()}
+        rgb_sharded, loss_sharded = out["rgb"].clone(), out["loss"]
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank == 0:
+            ref_tr = Trainer(model, pass2_rays=8, patches_per_launch=2)
+            ref_tr.uniform_source = lambda p, first, count, n, dv: tables[p][first:first + count, :n].to(dv)
+            model.zero_grad()
+            ref = ref_tr.finetune_step(render_fn, o, d, target, H, loss_fn, **kw)
+            assert float((rgb_sharded - ref["rgb"]).abs().max()) <= 1e-6 and abs(loss_sharded - ref["loss"]) < 1e-7
+            for n, p in model.named_parameters():
+                rel = float((sharded[n] - p.grad).norm() / (p.grad.norm() + 1e-12))
+                assert rel < 1e-4, (n, rel)
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    except Exception:
+        import traceback
+        open(os.path.join(out_dir, f"err{rank}"), "w").write(traceback.format_exc())
+        raise
+
+
+def test_sharded_finetune_step_perturb_true_two_ranks_one_gpu(tmp_path):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_perturb_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    errs = [open(tmp_path / f).read() for f in os.listdir(tmp_path) if f.startswith("err")]
+    assert not errs, errs[0]
+    assert sorted(f for f in os.listdir(tmp_path)) == ["ok0", "ok1"]
+
+
 def _nccl_worker(rank, world, port, out_dir):
     """One rank per GPU over RCCL (the production backend): the sharded frame equals the single-process frame bit for bit and the
     sharded fine-tune step's all-reduced gradients equal the single-process step's."""
