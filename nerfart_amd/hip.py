@@ -694,6 +694,66 @@ def volsdf_render_mixed(surf_blob, rad_blob, sampler_blob, sampler_precision: in
 NEUS_UPSAMPLE_ALGOS = {"official_solution": 0, "direct_use": 1, "direct_more": 2}      # neus.py:242-303
 
 
+def neus_sample(surf_blob, rays_o, rays_d, *, obj_bounding_radius, n_samples=64, n_importance=64, n_upsample_iters=4, precision=0, u_new=None,
+                upsample_algo="official_solution", n_nograd_samples=2048, fixed_s_recp=1 / 64.):
+    """The SAMPLER of nerfart_neus_render_algo_fwd on its own, on the stage entry points in the fused renderer's order (near / far, coarse depths,
+    SDF queries, up-sampling steps, merges): the P = n_samples + n_importance sorted sample depths [R, P] of every ray, bit-identical to the
+    renderer's `d_all` (tests) - what pass 2 of a perturb=True NeuS fine-tune step needs, without rendering a frame to get it (neus.py:240-303 run
+    under no_grad: only the depths leave the block)."""
+    if upsample_algo not in NEUS_UPSAMPLE_ALGOS:
+        raise ValueError(f"upsample_algo must be one of {list(NEUS_UPSAMPLE_ALGOS)}")
+    algo = NEUS_UPSAMPLE_ALGOS[upsample_algo]
+    R, dev = rays_o.shape[0], rays_o.device
+    P = n_samples + n_importance
+    if u_new is not None and tuple(u_new.shape) != (R, n_importance):
+        raise ValueError(f"u_new must be [{R}, {n_importance}]")
+    f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+    if R == 0:
+        return f(0, P)
+    dn = normalize_dirs(rays_d)
+    near, far = f(R), f(R)
+    _check(lib.nerfart_near_far_from_sphere(_dev(rays_o, name="rays_o"), _dev(dn), R, float(obj_bounding_radius), _dev(near), _dev(far), _stream()),
+           "nerfart_near_far_from_sphere")
+    d, sd = f(R, P), f(R, P)
+
+    def depths(table, n, out, stride):
+        _check(lib.nerfart_linspace_depths(_dev(table), n, _dev(near), _dev(far), 0.0, 0.0, R, _dev(out), stride, _stream()), "nerfart_linspace_depths")
+
+    def query(depth, n, stride, out, out_stride):
+        _check(lib.nerfart_sdf_fwd_rays(_dev(surf_blob), int(precision), _dev(rays_o), _dev(dn), None, _dev(depth), R, n, stride, 0.0, _dev(out), out_stride,
+                                        _stream()), "nerfart_sdf_fwd_rays")
+
+    def merge(n, d_new, s_new, n_new):
+        _check(lib.nerfart_merge_sorted_pairs(R, n, P, n_new, _dev(d), _dev(sd), _dev(d_new), _dev(s_new), _stream()), "nerfart_merge_sorted_pairs")
+    depths(lin_table(n_samples, dev), n_samples, d, P)
+    query(d, n_samples, P, sd, P)
+    n = n_samples
+    if algo == 0:
+        n_new = n_importance // n_upsample_iters
+        table = lin_table(n_new, dev) if u_new is None else u_new.contiguous()
+        d_new, s_new = f(R, n_new), f(R, n_new)
+        for i in range(n_upsample_iters):
+            u_ptr = table.data_ptr() + (4 * i * n_new if u_new is not None else 0)
+            _check(lib.nerfart_neus_upsample_step(R, n, P, n_new, 64.0 * (1 << i), _dev(d), _dev(sd), u_ptr, n_importance if u_new is not None else 0,
+                                                  _dev(d_new), _stream()), "nerfart_neus_upsample_step")
+            query(d_new, n_new, n_new, s_new, n_new)
+            merge(n, d_new, s_new, n_new)
+            n += n_new
+    else:
+        bins_d, bins_s, n_bins, cap = d, sd, n_samples, P
+        if algo == 2:
+            bins_d, bins_s, n_bins, cap = f(R, n_nograd_samples), f(R, n_nograd_samples), int(n_nograd_samples), int(n_nograd_samples)
+            depths(lin_table(n_bins, dev), n_bins, bins_d, n_bins)
+            query(bins_d, n_bins, n_bins, bins_s, n_bins)
+        table = lin_table(n_importance, dev) if u_new is None else u_new.contiguous()
+        d_new, s_new = f(R, n_importance), f(R, n_importance)
+        _check(lib.nerfart_neus_direct_upsample_step(R, n_bins, cap, n_importance, 1.0 / float(fixed_s_recp), _dev(bins_d), _dev(bins_s), _dev(table),
+                                                     n_importance if u_new is not None else 0, _dev(d_new), _stream()), "nerfart_neus_direct_upsample_step")
+        query(d_new, n_importance, n_importance, s_new, n_importance)
+        merge(n, d_new, s_new, n_importance)
+    return d
+
+
 def neus_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, obj_bounding_radius, s, n_samples=64, n_importance=64,
                 n_upsample_iters=4, white_bkgd=False, calc_normal=True, detailed=False, k3_rays_chunk=8192, precision=0,
                 u_new=None, upsample_algo="official_solution", n_nograd_samples=2048, fixed_s_recp=1 / 64.):

@@ -160,12 +160,10 @@ class Trainer(nn.Module):
         perturb = bool(rk.get("perturb", False))
         if self.is_neus:
             ni = rk.get("N_importance", 64)
-            out = hip.neus_render(surf_blob, rad_blob, m.view_tiles, o, d_raw, obj_bounding_radius=rk.get("obj_bounding_radius", 1.0),
-                                  s=float(m.forward_s().detach()), n_samples=rk.get("N_samples", 64),
-                                  n_importance=ni, n_upsample_iters=rk.get("N_upsample_iters", 4),
-                                  calc_normal=False, detailed=True, precision=m.precision_id, **self._neus_algo(rk),
-                                  u_new=self._uniform(pass_no, first_ray, o.shape[0], ni, o.device) if perturb else None)
-            return out["d_all"]
+            # the renderer's sampler on its own (its stage entry points: bit-identical depths, no frame rendered to get them)
+            return hip.neus_sample(surf_blob, o, d_raw, obj_bounding_radius=rk.get("obj_bounding_radius", 1.0), n_samples=rk.get("N_samples", 64),
+                                   n_importance=ni, n_upsample_iters=rk.get("N_upsample_iters", 4), precision=m.precision_id, **self._neus_algo(rk),
+                                   u_new=self._uniform(pass_no, first_ray, o.shape[0], ni, o.device) if perturb else None)
         alpha, beta = m.forward_ab()
         ns, ni = rk.get("N_samples", 128), rk.get("N_importance", 64)
         near, far = rk.get("near", 0.0), rk.get("far", 6.0)

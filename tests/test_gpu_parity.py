@@ -458,6 +458,30 @@ def test_neus_direct_upsampling_matches_reference_golden(neus_algos_golden, algo
     close("perturb mask", ex_p["mask_volume"][0], ag[tag + "perturb_mask_volume"], 1e-3)
 
 
+@pytest.mark.parametrize("algo", ["official_solution", "direct_use", "direct_more"])
+def test_neus_sampler_on_its_own_equals_the_renderers_depths(algo):
+    """hip.neus_sample (the NeuS sampler on the stage entry points: what pass 2 of a perturb=True NeuS fine-tune step calls) returns the fused
+    renderer's `d_all` bit for bit - deterministic and with given uniform numbers, fp32 and split-bf16, a ray count off every tile size."""
+    from nerfart_amd import hip, scene, rend_util
+    H, W = 19, 13
+    c2w, K = scene.camera(H, W)
+    g = torch.Generator().manual_seed(8)
+    u = torch.rand(H * W, 64, generator=g).to(DEV)
+    for precision in ("fp32", "bf16x3"):
+        model, rk, _ = scene.build_model("NeuS", seed=0, beta=None, device=DEV, precision=precision)
+        o, d, _ = rend_util.get_rays(c2w[None].to(DEV), K[None].to(DEV), H, W)
+        o, d = o[0].contiguous(), d[0].contiguous()
+        surf, rad = model.packed()
+        for un in (None, u):
+            ref = hip.neus_render(surf, rad, model.view_tiles, o, d, obj_bounding_radius=rk["obj_bounding_radius"], s=float(model.forward_s()),
+                                  n_upsample_iters=rk["N_upsample_iters"], calc_normal=False, detailed=True, precision=model.precision_id, u_new=un,
+                                  upsample_algo=algo)["d_all"]
+            got = hip.neus_sample(surf, o, d, obj_bounding_radius=rk["obj_bounding_radius"], n_upsample_iters=rk["N_upsample_iters"],
+                                  precision=model.precision_id, u_new=un, upsample_algo=algo)
+            assert got.shape == ref.shape == (H * W, 128) and torch.equal(got, ref), (algo, precision, un is not None)
+    assert hip.neus_sample(surf, o[:0], d[:0], obj_bounding_radius=1.0).shape == (0, 128)
+
+
 def test_render_fn_perturb_draws_fresh_samples():
     """render_fn(perturb=True) (the reference's training default, volsdf.py:982): two calls draw different final samples,
     the coarse samples stay, and the image stays close to the deterministic render (it is the same quadrature rule)."""
