@@ -622,7 +622,7 @@ def main():
                        "parallelism": ("1 GPU" if world == 1 else
                                        f"one frame per step in 2,048-ray tiles round-robin over {world} ranks, one all_gather" if primary_tiles else
                                        f"views round-robin over {world} rank(s), all_gather of [rays,7] tiles"),
-                       "rayschunk": "the configured val_rayschunk (%s) is NOT used: the whole frame is one 65,536-ray-chunked call "
+                       "rayschunk": "the configured val_rayschunk (%s) is NOT used: the whole frame is one call in chunks of volsdf.DEFAULT_RAYSCHUNK = 131,072 rays "
                                     "(results are bit-identical for any chunking: tests/test_gpu_parity.py)" % rk.get("rayschunk"),
                        "samples_per_sec": round(value * (N_SAMPLES + N_IMPORTANCE), 1),
                        "iter_usage_hist": hist,

@@ -75,7 +75,7 @@ class Trainer(nn.Module):
         # render_keep (VolSDF): pass 1 SAMPLES this many of pass 2's launch groups per set of sampler launches (its rounds each cost
         # a host read; results are chunk-invariant bit for bit); the per-point state is then evaluated group by group into tensors
         # of its own, which pass 2 releases as it consumes them (1 KiB per point: ~1 GB per 4 x 1200-ray group at P = 192).  14 groups =
-        # 67,200 rays per sampler batch, about the fused renderer's 65,536-ray chunk (measured: 4 -> 14 takes 8 ms off a 480 x 270 step)
+        # 67,200 rays per sampler batch, about half the fused renderer's 131,072-ray chunk (measured: 4 -> 14 takes 8 ms off a 480 x 270 step)
         self.pass1_groups = max(1, pass1_groups)
         self._kept = None
         # neus.py:455-456: NeuS fine-tuning trains only the SDF net (and ln_s); pass freeze_radiance=False for the
