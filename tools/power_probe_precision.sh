@@ -1,11 +1,11 @@
 #!/bin/bash
 # Run on the GPU box: bash tools/power_probe_precision.sh <tag>
-#   socket power and shader clock (rocm-smi, 5 Hz) while bench.py renders frames at the headline precision (bf16x3: 3 MFMAs per product) and at
+#   socket power and shader clock (rocm-smi, 5 Hz) while bench.py renders frames in the shipped mixed mode, at pure bf16x3 (3 MFMAs per product) and at
 #   the 2-MFMA measurement variant (fp16x2): does the matrix work saved show up as time at the SAME power (the frame is power capped), as lower
 #   power, or as a higher clock?  -> gpurun_out/<tag>_power_<precision>.json lines
 set -u
 REPO=$(pwd); TAG=$1; OUT=$REPO/gpurun_out; mkdir -p $OUT
-for prec in bf16x3 fp16x2; do
+for prec in ${PRECS:-mixed bf16x3 fp16x2}; do
   ( for i in $(seq 1 80); do rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power|sclk" | tr '\n' ' '; echo; sleep 0.2; done ) > $OUT/${TAG}_smi_$prec.txt &
   SMI=$!
   python bench.py --precision $prec --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/${TAG}_bench_$prec.json 2> /dev/null
