@@ -13,17 +13,18 @@ import torch
 
 
 def finetune_setup(dev, H: int, W: int, beta: float = 0.01, with_vgg: bool = True, pass2_rays: int = 1200, patches_per_launch: int = 4,
-                   angle: float = 0.0, precision: str = "mixed", pass1_groups: int = None):
+                   angle: float = 0.0, precision: str = "mixed", pass1_groups: int = None, framework: str = "VolSDF"):
     from . import scene, rend_util, criteria, clip_vit, vgg
     from .trainer import Trainer
-    model, rk, render_fn = scene.build_model("VolSDF", seed=0, beta=beta, device=dev, precision=precision)
+    model, rk, render_fn = scene.build_model(framework, seed=0, beta=beta if framework == "VolSDF" else None, device=dev, precision=precision)
     c2w, K = scene.camera(H, W, angle=angle)
     o, d, _ = rend_util.get_rays(c2w[None].to(dev), K[None].to(dev), H, W)
     feats = criteria.ClipFeatures(model=clip_vit.build_clip(dev, seed=0), device=dev, synthetic=True)
     style = criteria.StyleLoss(feats, (H, W), neg_texts=[f"negative prompt {i}" for i in range(16)],
                                perceptual=vgg.VGGPerceptualLoss().to(dev) if with_vgg else None)
     with torch.no_grad():
-        target, _, _ = render_fn(o, d, detailed_output=False, require_nablas=True, calc_normal=True, **{k: v for k, v in rk.items() if k != "rayschunk"})
+        target, _, _ = render_fn(o, d, detailed_output=False, calc_normal=True, **({"require_nablas": True} if framework == "VolSDF" else {}),
+                                 **{k: v for k, v in rk.items() if k != "rayschunk"})
     # the "photo" the render is compared with: the render itself, low-pass perturbed (pred == gt would make the directional loss 0/0,
     # as in the reference)
     g = torch.Generator(device="cpu").manual_seed(0)
