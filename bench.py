@@ -473,7 +473,8 @@ def main():
                 kk = js["kernels"][kname]
                 if any("bench.py" not in c or "bench_" in c for c in js.get("commands", [])):
                     raise ValueError("not a profile of bench.py")
-                fresh = js.get("csrc_sha256") == hip.csrc_sha256()
+                from nerfart_amd import volsdf as _volsdf       # (per-launch bytes of the sampler's kernel scale with the rays per chunk)
+                fresh = js.get("csrc_sha256") == hip.csrc_sha256() and js.get("default_rayschunk") == _volsdf.DEFAULT_RAYSCHUNK
                 roofline["traffic_profiled"] = {"bytes_per_launch": int(kk["hbm_bytes_corrected_per_launch"]), "source": os.path.basename(pm[-1]),
                                                 "profile_csrc_sha256": js.get("csrc_sha256"), "matches_this_build": fresh,
                                                 "mfma_busy_pmc": round(kk.get("mfma_util", 0.0), 4)}

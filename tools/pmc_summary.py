@@ -39,7 +39,12 @@ def main():
         sha = hip.csrc_sha256()
     except Exception:
         sha = None
-    json.dump({"kernels": kern, "note": note, "csrc_sha256": sha, "commands": sorted(commands)}, open(out, "w"), indent=1, sort_keys=True)
+    try:                                    # the sampler's launches are per chunk of rays: per-launch figures scale with the default chunk
+        from nerfart_amd import volsdf
+        chunk = volsdf.DEFAULT_RAYSCHUNK
+    except Exception:
+        chunk = None
+    json.dump({"kernels": kern, "note": note, "csrc_sha256": sha, "default_rayschunk": chunk, "commands": sorted(commands)}, open(out, "w"), indent=1, sort_keys=True)
     print(out, len(kern), "kernels")
 
 
