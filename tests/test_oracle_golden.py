@@ -228,3 +228,34 @@ def test_G10b_neus_direct_upsampling(neus_algos_golden, neus_state, algo):
         out = render.neus_render(sd, o, d, obj_bounding_radius=rk["obj_bounding_radius"], upsample_algo=algo, u_new=tt(ag[tag + "perturb_u"]))
     for k in ("rgb", "depth_volume", "d_final", "mask_volume"):
         close(out[k], ag[tag + "perturb_" + k], 3e-5, 2e-4)
+
+
+def test_the_two_passes_of_a_finetune_step_differ_only_in_the_final_inversion(volsdf_state):
+    """What Trainer.share_algorithm1 rests on, from the reference itself and from the oracle.  (1) The reference's Trainer.forward at perturb=True
+    (tests/golden/make_golden_finetune.py, keys FP_*): the rays of its pass 2 took exactly the rounds of its pass 1 (iter_usage equal on every
+    ray) although the two passes drew different uniform numbers - Algorithm 1's rounds draw nothing (volsdf.py:159-285).  (2) The oracle: ONE
+    fine_sample call that inverts every ray's final CDF at [u1 | u2] returns exactly what two calls with u1 and with u2 return."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "finetune_golden.npz"))
+    np.testing.assert_array_equal(z["FP_VolSDF_iter_usage_pass1"], z["FP_VolSDF_iter_usage_pass2"])
+    assert not np.array_equal(z["FP_VolSDF_u_pass1"], z["FP_VolSDF_u_pass2"])
+    assert len(set(z["FP_VolSDF_iter_usage_pass1"].tolist())) >= 2
+    sd, rk = volsdf_state
+    o, d = render.get_rays(tt(z["F_c2w"]), tt(z["F_K"]), 8, 8)
+    dn = torch.nn.functional.normalize(d, dim=-1)
+    alpha, beta = nets.volsdf_ab(sd) if hasattr(nets, "volsdf_ab") else (None, None)
+    if alpha is None:
+        beta = torch.exp(sd["ln_beta"] * 10.0)
+        alpha = 1.0 / beta
+    t = torch.linspace(0, 1, 512).float()
+    d_init = (0.0 * (1 - t) + 6.0 * t)[None, :].expand(64, 512)
+    u1, u2 = tt(z["FP_VolSDF_u_pass1"]), tt(z["FP_VolSDF_u_pass2"])
+    run = lambda u, n: sampling.fine_sample(lambda x: nets.volsdf_forward_surface(sd, x)[0], d_init, o, dn, alpha, beta, 6.0, eps=0.1, max_iter=6,
+                                            max_bisection=10, final_N_importance=n, N_up=512, det=False, u_final=u)
+    with torch.no_grad():
+        d12, b12, us12 = run(torch.cat([u1, u2], 1), 128)
+        d1, b1, us1 = run(u1, 64)
+        d2, b2, us2 = run(u2, 64)
+    assert torch.equal(us12, us1) and torch.equal(us12, us2) and torch.equal(b12, b1) and torch.equal(b12, b2)
+    assert torch.equal(d12[:, :64], d1) and torch.equal(d12[:, 64:], d2)
+    np.testing.assert_array_equal(us1.numpy(), z["FP_VolSDF_iter_usage_pass1"])
