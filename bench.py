@@ -57,6 +57,51 @@ PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0
 
 
+def cached_n1_line():
+    """The newest committed single-GPU bench line under profiles/ (rNN*_bench_line.json with n_gpus == 1 on the 480x270 metric): what an N > 1 line
+    quotes as its N = 1 reference (value, cpu_baseline) - the contract measures the CPU baseline on rank 0 at N = 1 only.  (name, dict) or (None, None)."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_line.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if isinstance(d, dict) and d.get("n_gpus") == 1 and "480x270" in str(d.get("metric", "")) and d.get("value"):
+            return os.path.relpath(f, ROOT), d
+    return None, None
+
+
+def scale_fields(world: int, primary_tiles: bool, value: float, ms_per_step: float, secondary: dict, rank_step_ms: list, n1_name, n1_line):
+    """The fields that make an N > 1 line readable on its own - pure function of numbers, tested on the CPU:
+      strong        the ONE-frame-over-N-GPUs figure (north_star's "ray-parallel scaling"), whichever mode is primary: value, ms_per_step and
+                    `speedup_vs_cached_n1` = its rate / the newest committed N = 1 line's (a HINT - the driver computes efficiency itself);
+      weak          the views-per-rank figure likewise;
+      rank_step_ms  max / mean / min over the ranks of the timed region per step (tile or view imbalance: the max is what `value` is made of);
+      cpu_baseline  at N > 1: an explicit marker naming the cached N = 1 figure instead of null."""
+    if world == 1:
+        return {}
+    sec = secondary or {}
+    other = sec.get("weak_views" if primary_tiles else "strong_tiles") or {}
+    mine = {"value": round(value, 1), "unit": "rays/s", "ms_per_step": round(ms_per_step, 2)}
+    strong = dict(mine if primary_tiles else {k: other.get(k) for k in ("value", "unit", "ms_per_step")}, is_primary=bool(primary_tiles),
+                  what=f"ONE 480x270 frame per step sharded over {world} ranks in 2,048-ray tiles + one all_gather (strong scaling)")
+    weak = dict({k: other.get(k) for k in ("value", "unit", "ms_per_step")} if primary_tiles else mine, is_primary=not primary_tiles,
+                what=f"one view per rank per step, {world} frames per step (weak scaling)")
+    n1 = float(n1_line["value"]) if n1_line else None
+    for d in (strong, weak):
+        d["speedup_vs_cached_n1"] = round(d["value"] / n1, 3) if (n1 and d.get("value")) else None
+    strong["efficiency_vs_n1_hint"] = round(strong["speedup_vs_cached_n1"] / world, 4) if strong["speedup_vs_cached_n1"] else None
+    t = [float(x) for x in rank_step_ms]
+    out = {"strong": strong, "weak": weak,
+           "rank_step_ms": {"max": round(max(t), 2), "mean": round(sum(t) / len(t), 2), "min": round(min(t), 2), "imbalance_max_over_mean": round(max(t) / (sum(t) / len(t)), 4)},
+           "n1_reference": None if not n1_line else {"from": n1_name, "value": n1, "unit": "rays/s", "note": "cached line of an earlier single-GPU run, not measured in this job"},
+           "cpu_baseline": {"value": None, "n/a at N>1": True, "unit": "rays/s",
+                            "note": "the CPU baseline is timed on rank 0 at N = 1 only (bench contract)",
+                            "cached_n1": None if not (n1_line and n1_line.get("cpu_baseline")) else
+                            {k: n1_line["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "kind", "sample")}}}
+    return out
+
+
 def launch_plan(n_gpus: int, env: dict, n_devices: int, argv: list, port: int = None):
     """What `python bench.py --gpus N` has to do before anything else.  Returns one of
       ("run", None)        this process is a rank (WORLD_SIZE set by a launcher) or N = 1: go on;
@@ -148,10 +193,15 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but the process group has {ranks_seen} ranks", file=sys.stderr, flush=True)
         sys.exit(2)
 
-    from nerfart_amd import scene, rend_util, hip, dist as nd
+    from nerfart_amd import scene, rend_util, hip, bench_util, dist as nd
 
     model, rk, render_fn = scene.build_model("VolSDF", seed=0, beta=args.beta, device=dev, precision=args.precision)
-    kw = {k: v for k, v in rk.items() if k != "rayschunk"}
+    # render_kwargs_test AS get_model BUILDS THEM, `rayschunk` = val_rayschunk (1024) included: every call below is
+    # render_fn(rays_o, rays_d, ..., **render_kwargs_test), the reference's own call shape (render.py:527, train.py:189).  volsdf.launch_rays reads the
+    # value as the memory hint it is (results are chunk-invariant bit for bit); `secondary.as_the_reference_calls_it` times render.py's 2048 too and
+    # the exact honouring (honor_rayschunk=True) beside them
+    kw = dict(rk)
+    model.render_stats = {}
     n_views = args.warmup + args.steps
     angles = scene.spiral(max(90, n_views * world))
     rays = []
@@ -184,6 +234,8 @@ def main():
         o, d = shared_mine[s]
         return nd.render_sharded(render_fn, o, d, tile=2048, n_rays=H * W, require_nablas=True, calc_normal=True, detailed_output=False, **kw)
 
+    rank_times = {}
+
     def timed(fn, profile=False):
         """W warm-up calls, then exactly K timed ones between barrier + synchronize pairs; max over ranks."""
         for s_ in range(args.warmup):
@@ -198,15 +250,18 @@ def main():
         for s_ in range(args.warmup, args.warmup + args.steps):
             fn(s_)
         torch.cuda.synchronize()
+        t_own = time.perf_counter() - t0              # this rank's own K steps (its collectives included), before it waits for the others
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         dt_ = time.perf_counter() - t0
         prof_ = hip.profile_end() if profile else None
         if dist is not None:
-            tmax = torch.tensor([dt_], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt_ = float(tmax)
+            # max over ranks = the contract's time; the per-rank times before the closing barrier show tile / view imbalance
+            tall = [None] * dist.get_world_size()
+            dist.all_gather_object(tall, (dt_, t_own))
+            rank_times[fn.__name__] = [t_[1] / args.steps * 1e3 for t_ in tall]
+            dt_ = max(t_[0] for t_ in tall)
         return dt_, prof_
 
     primary_tiles = args.shard == "tiles" and world > 1
@@ -337,11 +392,31 @@ def main():
                 fn(oo, dd, calc_normal=True, detailed_output=False, **extra)
             torch.cuda.synchronize()
             return (time.perf_counter() - t_) / N_SEC
+        # the frame through the reference's call shapes, `rayschunk` left in - val_rayschunk 1024 (volsdf.py:990 -> train.py:189,
+        # render.py:527; = the primary line's kwargs) and render.py's own default 2048 (render.py:488,614) - and, for the record, what slicing exactly as
+        # asked costs (127 / 64 launches per frame, each with its own <= 7 host-synchronised sampler rounds)
+        as_ref = {}
+        for rc_ in (1024, 2048):
+            t_rc = frames(render_fn, H, W, require_nablas=True, **dict(kw, rayschunk=rc_))
+            as_ref[f"rayschunk_{rc_}"] = {"value": round(H * W / t_rc, 1), "unit": "rays/s", "ms_per_step": round(t_rc * 1e3, 2), "steps": N_SEC,
+                                          "frac_of_primary": round(H * W / t_rc / value, 4)}
+        oo_, dd_ = rays[0]
+        render_fn(oo_, dd_, require_nablas=True, calc_normal=True, detailed_output=False, **dict(kw, rayschunk=2048, honor_rayschunk=True))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        render_fn(oo_, dd_, require_nablas=True, calc_normal=True, detailed_output=False, **dict(kw, rayschunk=2048, honor_rayschunk=True))
+        torch.cuda.synchronize()
+        t_h = time.perf_counter() - t1
+        as_ref["rayschunk_2048_honoured_exactly"] = {"value": round(H * W / t_h, 1), "unit": "rays/s", "ms_per_step": round(t_h * 1e3, 2), "steps": 1}
+        as_ref["what"] = ("render_fn(rays_o, rays_d, ..., **render_kwargs_test) with the `rayschunk` key left in, 3 frames each: the library reads it as the "
+                          "reference's 24 GB memory hint and launches max(rayschunk, 131,072) rays (volsdf.launch_rays; bit-identical results, "
+                          "tests/test_gpu_configs.py); honor_rayschunk=True slices exactly as asked")
+        secondary["as_the_reference_calls_it"] = as_ref
         t5 = frames(render_fn, 960, 540, require_nablas=True, **kw)
         secondary["cfg5_frame_960x540"] = {"value": round(960 * 540 / t5, 1), "unit": "rays/s", "ms_per_step": round(t5 * 1e3, 2), "steps": N_SEC,
                                            "what": "configs[4] frame size (518,400 rays, VolSDF 128 + 64 spp) on ONE GPU"}
         mn, rkn, fn_n = scene.build_model("NeuS", seed=0, beta=None, device=dev, precision=args.precision)
-        t4 = frames(fn_n, H, W, **{k: v for k, v in rkn.items() if k != "rayschunk"})
+        t4 = frames(fn_n, H, W, **rkn)                  # rayschunk = val_rayschunk (512) left in, as neus.py:747 builds the kwargs
         F_NEUS = 128 * F_SDF + 128 * (F_SDF + F_NABLA) + 127 * (F_SDF + F_NABLA + 542720)          # 704.8 MFLOP per ray
         secondary["cfg4_neus_480x270"] = {"value": round(H * W / t4, 1), "unit": "rays/s", "ms_per_step": round(t4 * 1e3, 2), "steps": N_SEC,
                                           "end_to_end_tflops": round(H * W * F_NEUS / t4 / 1e12, 1),
@@ -352,7 +427,6 @@ def main():
         # BASELINE configs[2] (SURVEY cfg 3): the fine-tune step - HIP pass 1 with kept state, CLIP + VGG style losses on the hand-written
         # kernels, native pass 2 (nerfart_volsdf_render_bwd per launch group), Adam.  One warm-up + N_SEC timed steps; the dominant
         # pass-2 kernel (k_wgrad<256>, HBM bound) priced from the library's own event records of these steps.
-        from nerfart_amd import bench_util
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()
         ctx3 = bench_util.finetune_setup(dev, H, W, beta=args.beta, angle=angles[2], precision=args.precision)
@@ -536,6 +610,15 @@ def main():
                   "max_abs_rgb_all": float(f"{float(e_pix.max()):.3e}"), "rays_over_1e-3": int((e_pix > 1e-3).sum()),
                   "psnr_db": round(float(-10 * torch.log10(((g_rgb[0].cpu() - ref["rgb"]) ** 2).mean().clamp_min(1e-20))), 1),
                   "max_abs_depth_same_rounds": float(f"{float((g_depth[0].cpu() - ref['depth_volume'])[same].abs().max()):.3e}")}
+        # ... held to the SAME statement tests/test_gpu_configs.py::test_cfg2_mixed_mode_over_eight_orbit_views asserts on 8 views (bench_util.view_budget):
+        # the view sampled here is orbit pose `warmup` - 5 on the driver's command, 1 at the defaults, both among the tested views
+        st_ = bench_util.pixel_stats(g_rgb[0].cpu(), g_ex["iter_usage"][0].cpu(), ref["rgb"], ref["iter_usage"])
+        viol_ = bench_util.view_budget(st_)
+        parity["rays_over_1e-3_among_oracle_converged"] = st_["rays_over_1e-3_among_oracle_converged"]
+        parity["view"] = f"orbit pose {args.warmup % len(angles)} of scene.spiral({len(angles)})"
+        parity["within_the_tests_budget"] = not viol_
+        if viol_:
+            parity["budget_violations"] = viol_
         # the exact-fp32 mode against the oracle on the SAME rays: says whether a ray past 1e-3 is the split-bf16 arithmetic or
         # Algorithm 1's own discontinuities (a ray that flips under any change of rounding; tools/fp32_outlier.py)
         if headline_split and not args.no_secondary:
@@ -623,8 +706,13 @@ def main():
                        "parallelism": ("1 GPU" if world == 1 else
                                        f"one frame per step in 2,048-ray tiles round-robin over {world} ranks, one all_gather" if primary_tiles else
                                        f"views round-robin over {world} rank(s), all_gather of [rays,7] tiles"),
-                       "rayschunk": "the configured val_rayschunk (%s) is NOT used: the whole frame is one call in chunks of volsdf.DEFAULT_RAYSCHUNK = 131,072 rays "
-                                    "(results are bit-identical for any chunking: tests/test_gpu_parity.py)" % rk.get("rayschunk"),
+                       "rayschunk": "render_kwargs_test['rayschunk'] = val_rayschunk = %s is PASSED to render_fn, as the reference does (train.py:189, render.py:527); "
+                                    "the library reads it as the memory hint it is and launches max(rayschunk, volsdf.DEFAULT_RAYSCHUNK = 131,072) rays "
+                                    "(volsdf.launch_rays; results are bit-identical for any chunking: tests/test_gpu_configs.py)" % rk.get("rayschunk"),
+                       "sampler_guard": None if not getattr(model, "sampler_guard", 0.0) else {
+                           "guard": model.sampler_guard, "rays_sampled_twice_frac": round(model.render_stats.get("escalated", 0) / max(model.render_stats.get("rays", 1), 1), 5),
+                           "what": "mixed mode: rays whose convergence decision in Algorithm 1 lies within guard * eps of eps, and rays that never converge, are "
+                                   "sampled again on the split-bf16 kernels (nerfart_volsdf_fine_sample_guarded); share over every render call of this run"},
                        "samples_per_sec": round(value * (N_SAMPLES + N_IMPORTANCE), 1),
                        "iter_usage_hist": hist,
                        "algorithmic_tflop_per_frame": round(flops_frame / 1e12, 2),
@@ -635,6 +723,10 @@ def main():
             "cpu_baseline": cpu,
             "secondary": secondary or None,
         }
+        if world > 1:
+            n1_name, n1_line = cached_n1_line()
+            out.update(scale_fields(world, primary_tiles, value, dt / args.steps * 1e3, secondary,
+                                    rank_times[(step_tiles if primary_tiles else step).__name__], n1_name, n1_line))
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

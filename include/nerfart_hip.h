@@ -39,7 +39,9 @@
 extern "C" {
 #endif
 
-/* 3 (round 5).  History: 2 -> 3, additions only (every version-2 entry point keeps its signature): the weight-blob packers
+/* 4 (round 6).  History: 3 -> 4, additions only: the guarded sampler (nerfart_volsdf_fine_sample_guarded) and the per-stage-precision renderer
+ * (nerfart_volsdf_render_staged_fwd), nerfart_pack_layer_dims, nerfart_geometry_feature.
+ * 2 -> 3, additions only (every version-2 entry point keeps its signature): the weight-blob packers
  * (nerfart_pack_surface_blob / nerfart_pack_radiance_blob + size queries; header word 10 of a split blob now names its fragment encoding),
  * nerfart_neus_render_algo_fwd / nerfart_neus_direct_upsample_step (upsample_algo 'direct_use' / 'direct_more').  1 -> 2: nerfart_sdf_nabla_fwd[_rays] take a caller-owned workspace; the CLIP blob stores every matrix once; the
  * VGG blob is fp32; the CLIP / VGG entry points take blob_bytes and reject blobs of another layout; new: the ray-level backward
@@ -160,6 +162,23 @@ int nerfart_volsdf_fine_sample(const float* surf_blob, int precision, const floa
  * u_final_per_ray != 0 (perturb=True: sample_cdf(det=False), rend_util.py:306-307): u_final_dev is [n_rays, n_final], the
  * caller's uniform random numbers, a row per ray (u_final_stride = n_final in the stage entry points; 0 = shared table). */
 
+
+/* GUARDED Algorithm 1 (ABI 4): the SDF queries on (surf_blob, precision) - the cheap arithmetic, e.g. precision 4 - with every ray whose outcome hangs
+ * on a marginal threshold decision sampled AGAIN, from its first query on, on (esc_blob, esc_precision):
+ *   (i)  a ray whose max error bound lies within guard * eps of eps at a convergence check (`max B > eps`, volsdf.py:162-163, :240-242);
+ *   (ii) a ray still active after the last round (volsdf.py:294-300: it is sampled with its last bisected beta+ - the rays ANY change of rounding
+ *        moves, the reference's own on another machine included: DESIGN.md 2).
+ * Rays are independent (volsdf.py:112), so the escalated rays' d_fine / beta_map / iter_usage are bit-identical to a run of all rays on esc_blob; the
+ * others made every decision with a margin.  *n_escalated (host int, may be NULL): how many rays ran twice.  guard <= 0 or esc_blob NULL:
+ * nerfart_volsdf_fine_sample.  Same workspace (nerfart_volsdf_sampler_workspace_bytes). */
+int nerfart_volsdf_fine_sample_guarded(const float* surf_blob, int precision, const float* esc_blob, int esc_precision, float guard,
+                                       const float* rays_o, const float* rays_dn, int n_rays,
+                                       const float* near, const float* far, float near_s, float far_s, float R_bg,
+                                       float alpha_net, float beta_net, float eps, int n_init, int n_up, int n_final,
+                                       int max_iter, int max_bisect, const float* t_init_dev, const float* u_up_dev,
+                                       const float* u_final_dev, int u_final_per_ray, float* d_fine, float* beta_map,
+                                       float* iter_usage, int* n_escalated, void* workspace, long long workspace_bytes, void* stream);
+
 /* out[r] = sort(cat(a[r, :na], b[r, :nb]))  (volsdf.py:501-502) */
 int nerfart_sort_concat(int n_rays, const float* a, int na, int a_stride, const float* b, int nb, int b_stride,
                         float* out, int out_stride, void* stream);
@@ -207,6 +226,19 @@ int nerfart_volsdf_render_mixed_fwd(const float* surf_blob, const float* rad_blo
                                     float* rgb, float* depth, float* acc, float* normals, float* d_all_out, float* sdf_out, float* nabla_out,
                                     float* radiance_out, float* sigma_out, float* p_out, float* tau_out, float* beta_map_out,
                                     float* iter_usage_out, void* workspace, long long workspace_bytes, void* stream);
+
+/* Every stage on its own blob / precision (ABI 4; what the shipped `mixed` mode calls): Algorithm 1 on (sampler_blob, sampler_precision), GUARDED by
+ * sampler_guard (> 0: nerfart_volsdf_fine_sample_guarded with (surf_blob, precision) as the escalation arithmetic; <= 0: off); sdf + nabla of the 192 final
+ * samples on (surf_blob, precision); the radiance net there on (rad_blob, rad_precision); compositing in fp32.  *n_escalated: host int or NULL.
+ * nerfart_volsdf_render_mixed_fwd = this with rad_precision = precision and sampler_guard = 0. */
+int nerfart_volsdf_render_staged_fwd(const float* surf_blob, int precision, const float* rad_blob, int rad_precision, const float* sampler_blob,
+                                     int sampler_precision, float sampler_guard, int view_tiles, const float* rays_o, const float* rays_d, int n_rays,
+                                     float near_s, float far_s, float R_bg, float alpha, float beta, float eps, int n_samples, int n_importance,
+                                     int max_upsample_steps, int max_bisection_steps, int white_bkgd, int k3_rays_chunk, const float* t_coarse_dev,
+                                     const float* t_init_dev, const float* u_up_dev, const float* u_final_dev, int u_final_per_ray,
+                                     float* rgb, float* depth, float* acc, float* normals, float* d_all_out, float* sdf_out, float* nabla_out,
+                                     float* radiance_out, float* sigma_out, float* p_out, float* tau_out, float* beta_map_out,
+                                     float* iter_usage_out, int* n_escalated, void* workspace, long long workspace_bytes, void* stream);
 
 /* ---- NeuS (models/frameworks/neus.py): up-sampling 'official_solution' :275-303 ('direct_use' / 'direct_more' :242-269 below), helpers :29-78,
  * volume_render :142-424; near_far_from_sphere utils/rend_util.py:168-186. */
@@ -448,6 +480,20 @@ int nerfart_weight_norm_bwd(const float* dW, const float* weight_v, const float*
 long long nerfart_surface_blob_floats(int precision, int multires);
 long long nerfart_radiance_blob_floats(int precision, int view_tiles);
 long long nerfart_pack_workspace_bytes(void);
+/* (ABI 4) The geometry feature of ImplicitSurface.forward(x, return_h=True) / forward_with_nablas (models/base.py:243-282): rows 1..256 of the SDF net's
+ * LAST linear layer on the layer-7 activations, feat = W8[1:] h7 + b8[1:] with W8 = weight_g * weight_v / ||weight_v|| folded on the device (ATen's
+ * summation order) and the product on v_mfma_f32_32x32x2_f32 (exact fp32 products; csrc/geo_feature.hip).  weight_g [257], weight_v [257, 256],
+ * bias [257]: `implicit_surface.surface_fc_layers.8.*`; h7 [M, 256]: nerfart_sdf_nabla_fwd's output; feat_out [M, 256].  The render path never calls
+ * it (the radiance kernels evaluate these rows from their own blob): it serves the reference's other consumers of the callable (boundary B3). */
+long long nerfart_geometry_feature_workspace_bytes(void);
+int nerfart_geometry_feature(const float* weight_g, const float* weight_v, const float* bias, const float* h7, long long M, float* feat_out,
+                             void* workspace, long long workspace_bytes, void* stream);
+
+/* (ABI 4) The architecture the packers index their pointer tables with, as data: radiance == 0 -> the SDF net's 9 layers for embed_multires = arg (6);
+ * != 0 -> the radiance net's 5 layers for view_tiles = arg (1 | 3).  rows[l] x cols[l] = weight_v[l]'s shape (weight_g [rows, 1], bias [rows]); the
+ * return value is the layer count, 0 on a bad argument.  A host checks a checkpoint against it BEFORE calling nerfart_pack_*_blob (any other W / D /
+ * skips / W_geo_feat would be read out of bounds). */
+int nerfart_pack_layer_dims(int radiance, int arg, int* rows, int* cols);
 int nerfart_pack_surface_blob(int precision, int multires, const float* const* weight_g, const float* const* weight_v, const float* const* bias,
                               float* blob_out, long long blob_floats, void* workspace, long long workspace_bytes, void* stream);
 int nerfart_pack_radiance_blob(int precision, int view_tiles, const float* surf8_g, const float* surf8_v, const float* surf8_bias,

@@ -98,3 +98,51 @@ def pass2_sampler_seconds(ctx, reps: int = 2, perturb: bool = True):
                 tr._samples(o[i:i + big], hip.normalize_dirs(d[i:i + big].contiguous()), d[i:i + big], rk, 2, i)
         torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
     return sum(ts[1:]) / reps
+
+
+# ---- the statistics a rendered sample is held to against the CPU oracle (tests/test_gpu_configs.py AND bench.py's parity block: one definition) ----------
+def pixel_stats(rgb, usage, ref_rgb, ref_usage) -> dict:
+    """rgb [n, 3] / usage [n] (iter_usage: rounds of Algorithm 1, -1 = never converged) of a sample of rays against the oracle's, as plain numbers."""
+    err = (rgb - ref_rgb).abs().max(dim=-1).values
+    n = err.numel()
+    same = usage == ref_usage
+    conv = ref_usage >= 0
+    stable = same & conv
+    return {"rays": n, "never_converged_rays_oracle": int((~conv).sum()), "same_upsampling_rounds_frac": round(float(same.float().mean()), 5),
+            "rays_over_1e-3": int((err > 1e-3).sum()), "rays_over_1e-3_among_oracle_converged": int((err[conv] > 1e-3).sum()),
+            "rays_over_1e-3_among_converged_same_rounds": int((err[stable] > 1e-3).sum()),
+            "max_abs_rgb_converged_same_rounds": float(f"{float(err[stable].max()) if bool(stable.any()) else 0.0:.3e}"),
+            "max_abs_rgb_all": float(f"{float(err.max()):.3e}"),
+            "p999_abs": float(f"{float(err.flatten().kthvalue(max(1, int(0.999 * n))).values):.3e}"),
+            "psnr_db": round(float(-10 * torch.log10(((rgb - ref_rgb) ** 2).mean().clamp_min(1e-20))), 1)}
+
+
+def view_budget(st: dict, base: dict = None) -> list:
+    """What a 2,048-ray sample of ANY view of the 480 x 270 benchmark frame has to satisfy (round 6: 8 orbit views measured, profiles/r08_guard_sweep*.json);
+    returns the list of violated statements (empty = inside the budget).
+      * HARD 1e-3 on every ray that converged on the CPU in the same number of rounds as on the GPU (the north-star statement where it can hold);
+      * never-converged / flipped rays: at most max(5, a quarter of the oracle's never-converged rays) past 1e-3 (measured: 1 - 7 of 2,048 with 15 - 40
+        never-converged, pure split-bf16 and mixed alike), none past 4e-3 (measured 2.5e-3), PSNR >= 82 dB (measured 83.9 - 88.4);
+      * identical up-sampling rounds on >= 98.5 % of the sample (measured: split-bf16 99.37 - 99.8 %, mixed 98.78 - 99.46 %);
+      * base (the PURE split-bf16 mode's stats on the same rays) given: the mode under test puts at most ONE ray more past 1e-3, no more oracle-converged
+        rays past 1e-3 than it + 1, and loses at most one percentage point of identical rounds - the shipped mode's contract."""
+    bad = []
+    if st["rays_over_1e-3_among_converged_same_rounds"] != 0:
+        bad.append(f"{st['rays_over_1e-3_among_converged_same_rounds']} ray(s) that converged in the same rounds past 1e-3 (max {st['max_abs_rgb_converged_same_rounds']})")
+    allowed = max(5, -(-st["never_converged_rays_oracle"] // 4))
+    if st["rays_over_1e-3"] > allowed:
+        bad.append(f"{st['rays_over_1e-3']} rays past 1e-3 (budget {allowed})")
+    if st["max_abs_rgb_all"] > 4e-3:
+        bad.append(f"max {st['max_abs_rgb_all']} > 4e-3")
+    if st["psnr_db"] < 82.0:
+        bad.append(f"PSNR {st['psnr_db']} < 82 dB")
+    if st["same_upsampling_rounds_frac"] < 0.985:
+        bad.append(f"identical rounds on {st['same_upsampling_rounds_frac']} < 0.985")
+    if base is not None:
+        if st["rays_over_1e-3"] > base["rays_over_1e-3"] + 1:
+            bad.append(f"{st['rays_over_1e-3']} rays past 1e-3 against pure split-bf16's {base['rays_over_1e-3']} (+1 allowed)")
+        if st["rays_over_1e-3_among_oracle_converged"] > base["rays_over_1e-3_among_oracle_converged"] + 1:
+            bad.append(f"{st['rays_over_1e-3_among_oracle_converged']} oracle-converged rays past 1e-3 against pure split-bf16's {base['rays_over_1e-3_among_oracle_converged']}")
+        if st["same_upsampling_rounds_frac"] < base["same_upsampling_rounds_frac"] - 0.01:
+            bad.append(f"identical rounds {st['same_upsampling_rounds_frac']} more than a point below pure split-bf16's {base['same_upsampling_rounds_frac']}")
+    return bad

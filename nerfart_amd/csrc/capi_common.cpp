@@ -57,5 +57,5 @@ int nerfart_profile_end(double* ms, long long* launches, long long* units) {
     return 0;
 }
 const char* nerfart_last_error(void) { return nerfart::g_last_error.c_str(); }
-int nerfart_abi_version(void) { return 3; }
+int nerfart_abi_version(void) { return 4; }
 }

@@ -17,7 +17,7 @@ namespace gemm32 {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int LS = 36;                  // LDS row stride of a 32-column fp32 tile, in floats
-enum { EPI_PLAIN = 0, EPI_BIAS_RELU = 1, EPI_RELUMASK = 2 };
+enum { EPI_PLAIN = 0, EPI_BIAS_RELU = 1, EPI_RELUMASK = 2, EPI_BIAS = 3 };      // EPI_BIAS: + bias, no activation (geo_feature.hip)
 enum { A_MAT = 0, A_CONV3 = 1 };
 
 struct Epi {
@@ -57,7 +57,9 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
                 ra1 = *reinterpret_cast<const f32x4*>(p + 4);
             }
         } else {
-            const float* p = A + (size_t)(bm + lr) * lda + k0 + lc;
+            // rows past m_valid are padding (computed, never stored): re-read the last valid row instead of memory past a [m_valid, lda] matrix
+            const int ar = bm + lr < e.m_valid ? bm + lr : e.m_valid - 1;
+            const float* p = A + (size_t)ar * lda + k0 + lc;
             ra0 = *reinterpret_cast<const f32x4*>(p);
             ra1 = *reinterpret_cast<const f32x4*>(p + 4);
         }
@@ -97,14 +99,14 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
     // C layout: lane (col = l & 31, half = l >> 5), reg i -> row (i & 3) + 8 (i >> 2) + 4 half
     const int col = bn + wn + r;
     float bias = 0.f;
-    if constexpr (EPI == EPI_BIAS_RELU) bias = e.bias[col];
+    if constexpr (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS) bias = e.bias[col];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int row = bm + wm + (i & 3) + 8 * (i >> 2) + 4 * (l >> 5);
         if (row >= e.m_valid) continue;
         const size_t o = (size_t)row * e.ldo + col;
         const float v = acc[i] + bias;
-        if constexpr (EPI == EPI_PLAIN) e.out[o] = v;
+        if constexpr (EPI == EPI_PLAIN || EPI == EPI_BIAS) e.out[o] = v;
         else if constexpr (EPI == EPI_BIAS_RELU) e.out[o] = fmaxf(v, 0.f);
         else e.out[o] = (e.aux[o] > 0.f) ? v : 0.f;
     }

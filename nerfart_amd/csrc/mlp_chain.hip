@@ -39,7 +39,7 @@ constexpr size_t GRADF_WS_PER_WG = 8 * (size_t)D_LAYER_STRIDE;                 /
 // hipcc hoisted the 128 (layer, tile) addresses out of the tile loop and spilled them (113 VGPR spills, now 3).
 // The layer / tile offset is NOT passed as the instruction's scalar soffset: that form (hipcc re-materialises the SGPR between
 // back-to-back accesses) returned wrong data on the MI355X for the lanes of waves 4..7 with lane % 16 >= 12, run-dependent
-// (tools/dbg_fp32_scratch.py: 12.5 % of the points of every tile, sdf and h7 exact, nabla off by up to 0.17); the same accesses with
+// (tools/archive/dbg_fp32_scratch.py: 12.5 % of the points of every tile, sdf and h7 exact, nabla off by up to 0.17); the same accesses with
 // the offset in the vector register, or through plain pointers, are exact.  Cause not established - avoided.
 typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
 struct Scratch {

@@ -34,7 +34,7 @@ struct Frag { u32x4 h, l; };              // A fragment of one item (32 rows x 1
 // (32 cycles) with nothing else issued: every MFMA is therefore followed by its own share of fillers (measured: pairs of MFMAs
 // with the fillers behind the pair ran 335 cycles per 6 MFMAs, i.e. nothing overlapped).
 __device__ __forceinline__ void mfma1(const u32x4 a, const u32x4 b, f32x16& q) {
-#ifdef W32_NO_MFMA           // timing experiments only (tools/ablate_w32.py): operands kept live, no matrix work - results are wrong
+#ifdef W32_NO_MFMA           // timing experiments only (tools/archive/ablate_w32.py): operands kept live, no matrix work - results are wrong
     asm volatile("" : "+a"(q) : "v"(a), "v"(b));
     return;
 #endif
@@ -212,7 +212,7 @@ struct Items32 {
             else { bh = xs[ks - L::NH].h; bl = xs[ks - L::NH].l; }
             constexpr int HU = L::hosted(ks);
 #ifndef W32_DMA_AT          // where the double item's LDS-DMA pieces go: gap * 2 + (0: right behind the gap's MFMA / read, 1: behind its stages).
-#define W32_DMA_AT 0        // Swept on MI355X (tools/sweep_w32.py, profiles/r02s_sweep_w32.log): 9.47 ms (gap 0) .. 9.57 ms (gap 5), same bits.
+#define W32_DMA_AT 0        // Swept on MI355X (tools/archive/sweep_w32.py, profiles/r02s_sweep_w32.log): 9.47 ms (gap 0) .. 9.57 ms (gap 5), same bits.
 #endif
 #define W32_PIECES(G, POS) if constexpr (W32_DMA_AT == 2 * (G) + (POS)) w_pieces<(DI * 16) / ND, ((DI + 1) * 16) / ND>(s)
             mfma1(r[S][0].h, bh, Q.t[T]);
@@ -396,8 +396,8 @@ k_sdf_only_w32(const float* __restrict__ blob, PointSrc src, float R_bg, float* 
 }  // namespace w32
 
 // precision 1 entry used by the dispatchers of mlp_chain.hip.  The 8-wave kernel of mlp_chain_bf16.hip (k_sdf_only_bf16) stays the
-// default: measured on MI355X (round 2, tools/k2_ab.py, 4 M points) 9.45 ms against 9.56 .. 9.95 ms for every scheduling variant of
-// this kernel - the ablation (tools/ablate_w32.py, profiles/r02k_ablate_w32.log) puts the matrix work alone at 6.1 ms and prices
+// default: measured on MI355X (round 2, tools/archive/k2_ab.py, 4 M points) 9.45 ms against 9.56 .. 9.95 ms for every scheduling variant of
+// this kernel - the ablation (tools/archive/ablate_w32.py, profiles/r02k_ablate_w32.log) puts the matrix work alone at 6.1 ms and prices
 // the three filler classes at +2.3 ms (LDS-DMA issue, ~78 cycles per 1 KiB piece), +1.8 ms (fragment reads, ~16 cycles per
 // ds_read_b128) and +1.7 ms (epilogue), of which a lone in-order wave hides only 2.3 ms: both designs are bound by weight bytes moved
 // per column (L2 -> LDS -> registers), which only more columns per fragment would lower and the register file does not allow.

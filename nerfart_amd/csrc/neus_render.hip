@@ -320,6 +320,13 @@ int nerfart_neus_render_algo_fwd(const float* surf_blob, const float* rad_blob, 
         set_last_error("neus render: bad sample counts"); return 2;
     }
     if (upsample_algo == 2 && n_nograd_samples < 2) { set_last_error("neus render: direct_more needs n_nograd_samples >= 2"); return 2; }
+    // direct_more holds a ray's n_nograd_samples bins in LDS (4 rows + the new depths): refuse up front, with the number that fits, what would only fail
+    // as a generic LDS error from inside the render (the reference takes any N_nograd_samples, the shipped configs use 2048)
+    if (upsample_algo == 2 && ((size_t)4 * n_nograd_samples + (n_importance < 64 ? 64 : n_importance)) * sizeof(float) > 160 * 1024) {
+        set_last_error("neus render: upsample_algo 'direct_more' keeps 4 x N_nograd_samples floats per ray in the 160 KiB LDS: N_nograd_samples must be <= 10,200 "
+                       "(the reference configs use 2048)");
+        return 2;
+    }
     if (upsample_algo != 0 && !(fixed_s_recp > 0.f)) { set_last_error("neus render: fixed_s_recp must be positive"); return 2; }
     const int P = n_samples + n_importance, n_new = n_importance / n_upsample_iters;
     const int n_more = upsample_algo == 2 ? n_nograd_samples : 0;

@@ -476,6 +476,21 @@ long long nerfart_radiance_blob_floats(int precision, int view_tiles) {
 }
 long long nerfart_pack_workspace_bytes(void) { return 4096 * 4; }
 
+// The architecture the packers (and every kernel) are written for, as data a caller can check its tensors against BEFORE handing over pointer
+// tables the library indexes with fixed dims: radiance == 0: the SDF net's 9 layers for embed_multires = arg; != 0: the radiance net's 5 layers for
+// view_tiles = arg.  rows[l] / cols[l] = weight_v[l].shape (weight_g [rows, 1], bias [rows]).  Returns the layer count; 0 on a bad argument.
+int nerfart_pack_layer_dims(int radiance, int arg, int* rows, int* cols) {
+    if (!radiance) {
+        if (arg != 6) { set_last_error("pack_layer_dims: the SDF kernels are written for embed_multires 6"); return 0; }
+        for (int l = 0; l < 9; ++l) { const Dims d = surf_dims(l); if (rows) rows[l] = d.rows; if (cols) cols[l] = d.cols; }
+        return 9;
+    }
+    if (arg != 1 && arg != 3) { set_last_error("pack_layer_dims: view_tiles must be 1 (raw view directions) or 3 (embed_multires_view 4)"); return 0; }
+    const int n_extra = make_prog(2, arg, 0).n_extra;
+    for (int l = 0; l < 5; ++l) { const Dims d = rad_dims(l, n_extra); if (rows) rows[l] = d.rows; if (cols) cols[l] = d.cols; }
+    return 5;
+}
+
 // weight_g[l] [out_l] (or [out_l, 1]), weight_v[l] [out_l, in_l], bias[l] [out_l]: HOST arrays of 9 DEVICE pointers, the state-dict tensors
 // `implicit_surface.surface_fc_layers.{l}.weight_g / weight_v / bias` (W = 256, D = 8, skips = [4], embed_multires = 6, W_geo_feat = 256).
 int nerfart_pack_surface_blob(int precision, int multires, const float* const* weight_g, const float* const* weight_v, const float* const* bias,

@@ -25,7 +25,20 @@ struct SamplerParams {
     float eps;
     float alpha_net, beta_net;
     int u_final_stride;   // 0: one shared table u_final[n_final] (det = True: linspace); n_final: a row per ray (perturb: rand)
+    // guard band of the convergence decision `max B > eps` (volsdf.py:162-163, :240-242): a ray whose max B lies within guard * eps of eps is
+    // neither sampled nor re-queued here - it is appended to esc_list and Algorithm 1 runs again for it on the escalation blob (fine_sample_run)
+    float guard;          // <= 0: off
+    int* esc_list;
+    int* esc_count;
 };
+
+// wave-uniform: is the decision `mx > eps` inside the guard band?  (mx = +inf - a NaN bound - is a clear "not converged")
+__device__ __forceinline__ bool in_guard_band(const SamplerParams& P, float mx) {
+    return P.guard > 0.f && fabsf(mx - P.eps) <= P.guard * P.eps;
+}
+__device__ __forceinline__ void escalate(const SamplerParams& P, int ray) {
+    if (threadIdx.x == 0) P.esc_list[atomicAdd(P.esc_count, 1)] = ray;
+}
 
 // d = near * (1 - t) + far * t with the reference's three roundings (volsdf.py:474, :484)
 __global__ void k_linspace_depths(const float* __restrict__ t, int n, const float* __restrict__ near,
@@ -72,6 +85,7 @@ k_first_check(SamplerParams P, const float* __restrict__ dA, const float* __rest
     __syncthreads();
     const float mx = error_bound_scan(d, s, P.n, P.alpha_net, P.beta_net, nullptr, false);
     const float fr = far ? far[ray] : far_s;
+    if (in_guard_band(P, mx)) { escalate(P, ray); return; }
     if (!(mx > P.eps)) {
         opacity_cdf(d, s, P.n, P.alpha_net, P.beta_net, cdf);
         __syncthreads();
@@ -151,6 +165,7 @@ k_merge_check(SamplerParams P, const float* __restrict__ dA, const float* __rest
         sB[(size_t)ray * P.cap + i] = s[i];
     }
     const float mx = error_bound_scan(d, s, nm, P.alpha_net, P.beta_net, nullptr, false);
+    if (in_guard_band(P, mx)) { escalate(P, ray); return; }
     if (!(mx > P.eps)) {
         float* cdf = d_old;                      // the two depth rows are dead: exactly n + nu = nm floats
         opacity_cdf(d, s, nm, P.alpha_net, P.beta_net, cdf);
@@ -268,6 +283,28 @@ k_composite_volsdf(int P, const float* __restrict__ d_all, const float* __restri
     }
 }
 
+// ---- escalation of guard-band / never-converged rays (fine_sample_run): compact the listed rays, run Algorithm 1 on them again, scatter --------
+__global__ void k_gather_rays(const int* __restrict__ list, int n, const float* __restrict__ rays_o, const float* __restrict__ rays_dn,
+                              const float* __restrict__ near, const float* __restrict__ far, const float* __restrict__ u_final, int n_final,
+                              float* __restrict__ c_o, float* __restrict__ c_dn, float* __restrict__ c_near, float* __restrict__ c_far,
+                              float* __restrict__ c_u) {
+    const int slot = blockIdx.x, ray = list[slot], t = threadIdx.x;
+    if (slot >= n) return;
+    if (t < 3) { c_o[3 * slot + t] = rays_o[3 * (size_t)ray + t]; c_dn[3 * slot + t] = rays_dn[3 * (size_t)ray + t]; }
+    if (t == 0 && near) c_near[slot] = near[ray];
+    if (t == 0 && far) c_far[slot] = far[ray];
+    if (u_final) for (int j = t; j < n_final; j += 64) c_u[(size_t)slot * n_final + j] = u_final[(size_t)ray * n_final + j];
+}
+
+__global__ void k_scatter_samples(const int* __restrict__ list, int n, int n_final, const float* __restrict__ c_d_fine,
+                                  const float* __restrict__ c_beta, const float* __restrict__ c_iter, float* __restrict__ d_fine,
+                                  float* __restrict__ beta_map, float* __restrict__ iter_usage) {
+    const int slot = blockIdx.x, ray = list[slot], t = threadIdx.x;
+    if (slot >= n) return;
+    for (int j = t; j < n_final; j += 64) d_fine[(size_t)ray * n_final + j] = c_d_fine[(size_t)slot * n_final + j];
+    if (t == 0) { beta_map[ray] = c_beta[slot]; iter_usage[ray] = c_iter[slot]; }
+}
+
 static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
@@ -317,18 +354,28 @@ static int set_lds(const void* k, size_t bytes) {
     return 0;
 }
 
-int nerfart_volsdf_first_check(int n_rays, int n, int cap, int n_final, float eps, float alpha_net, float beta_net,
-                               const float* dA, const float* sA, const float* u_final, int u_final_stride,
-                               float beta_plus0_denom, const float* far, float far_s, float* d_fine, float* beta_plus,
-                               float* beta_map, float* iter_usage, int* act_out, int* act_count, void* stream) {
+// guard / esc_list / esc_count: see SamplerParams (the exported stage entry point runs with the guard off)
+static int first_check_launch(int n_rays, int n, int cap, int n_final, float eps, float alpha_net, float beta_net,
+                              const float* dA, const float* sA, const float* u_final, int u_final_stride,
+                              float beta_plus0_denom, const float* far, float far_s, float* d_fine, float* beta_plus,
+                              float* beta_map, float* iter_usage, int* act_out, int* act_count, float guard, int* esc_list, int* esc_count,
+                              void* stream) {
     if (n_rays <= 0) return 0;
-    SamplerParams P{n, cap, 0, n_final, 0, 0, eps, alpha_net, beta_net, u_final_stride};
+    SamplerParams P{n, cap, 0, n_final, 0, 0, eps, alpha_net, beta_net, u_final_stride, guard, esc_list, esc_count};
     const size_t lds = (size_t)3 * n * sizeof(float);
     if (int rc = set_lds((const void*)k_first_check, lds)) return rc;
     hipLaunchKernelGGL(k_first_check, dim3(n_rays), dim3(64), lds, (hipStream_t)stream, P, dA, sA, u_final,
                        beta_plus0_denom, far, far_s, d_fine, beta_plus, beta_map, iter_usage, act_out, act_count);
     NERFART_HIP(hipGetLastError());
     return 0;
+}
+
+int nerfart_volsdf_first_check(int n_rays, int n, int cap, int n_final, float eps, float alpha_net, float beta_net,
+                               const float* dA, const float* sA, const float* u_final, int u_final_stride,
+                               float beta_plus0_denom, const float* far, float far_s, float* d_fine, float* beta_plus,
+                               float* beta_map, float* iter_usage, int* act_out, int* act_count, void* stream) {
+    return first_check_launch(n_rays, n, cap, n_final, eps, alpha_net, beta_net, dA, sA, u_final, u_final_stride, beta_plus0_denom, far, far_s, d_fine,
+                              beta_plus, beta_map, iter_usage, act_out, act_count, 0.f, nullptr, nullptr, stream);
 }
 
 int nerfart_volsdf_upsample(int n_active, int n, int cap, int n_up, const float* dA, const float* sA, const int* act,
@@ -344,19 +391,28 @@ int nerfart_volsdf_upsample(int n_active, int n, int cap, int n_up, const float*
     return 0;
 }
 
-int nerfart_volsdf_merge_check(int n_active, int n, int cap, int n_up, int n_final, int max_bisect, int it, float eps,
-                               float alpha_net, float beta_net, const float* dA, const float* sA, float* dB, float* sB,
-                               const int* act, const float* d_new, const float* s_new, const float* u_final,
-                               int u_final_stride, float* d_fine, float* beta_plus, float* beta_map, float* iter_usage,
-                               int* act_out, int* act_count, void* stream) {
+static int merge_check_launch(int n_active, int n, int cap, int n_up, int n_final, int max_bisect, int it, float eps,
+                              float alpha_net, float beta_net, const float* dA, const float* sA, float* dB, float* sB,
+                              const int* act, const float* d_new, const float* s_new, const float* u_final,
+                              int u_final_stride, float* d_fine, float* beta_plus, float* beta_map, float* iter_usage,
+                              int* act_out, int* act_count, float guard, int* esc_list, int* esc_count, void* stream) {
     if (n_active <= 0) return 0;
-    SamplerParams P{n, cap, n_up, n_final, max_bisect, it, eps, alpha_net, beta_net, u_final_stride};
+    SamplerParams P{n, cap, n_up, n_final, max_bisect, it, eps, alpha_net, beta_net, u_final_stride, guard, esc_list, esc_count};
     const size_t lds = ((size_t)3 * n + 3 * n_up) * sizeof(float);
     if (int rc = set_lds((const void*)k_merge_check, lds)) return rc;
     hipLaunchKernelGGL(k_merge_check, dim3(n_active), dim3(64), lds, (hipStream_t)stream, P, dA, sA, dB, sB, act, d_new,
                        s_new, u_final, d_fine, beta_plus, beta_map, iter_usage, act_out, act_count);
     NERFART_HIP(hipGetLastError());
     return 0;
+}
+
+int nerfart_volsdf_merge_check(int n_active, int n, int cap, int n_up, int n_final, int max_bisect, int it, float eps,
+                               float alpha_net, float beta_net, const float* dA, const float* sA, float* dB, float* sB,
+                               const int* act, const float* d_new, const float* s_new, const float* u_final,
+                               int u_final_stride, float* d_fine, float* beta_plus, float* beta_map, float* iter_usage,
+                               int* act_out, int* act_count, void* stream) {
+    return merge_check_launch(n_active, n, cap, n_up, n_final, max_bisect, it, eps, alpha_net, beta_net, dA, sA, dB, sB, act, d_new, s_new, u_final,
+                              u_final_stride, d_fine, beta_plus, beta_map, iter_usage, act_out, act_count, 0.f, nullptr, nullptr, stream);
 }
 
 int nerfart_volsdf_finalize(int n_active, int n, int cap, int n_final, const float* dA, const float* sA, const int* act,
@@ -401,7 +457,12 @@ typedef struct {
     float *dA, *sA, *dB, *sB, *d_new, *s_new, *beta_plus;
     int *act0, *act1, *count;
     float *t_init, *u_up, *u_final;
+    // escalation (behind everything a run on <= n_rays rays carves, so the second run may reuse the front of the same workspace)
+    int* esc_list;
+    float *c_o, *c_dn, *c_near, *c_far, *c_u, *c_d_fine, *c_beta, *c_iter;
 } sampler_ws_t;
+
+enum { COUNT_SLOTS = 64, ESC_SLOT = COUNT_SLOTS - 1 };     // w.count: one active-ray counter per round + the escalation list's length
 
 static size_t carve_sampler(char* base, int R, int cap, int n_up, int n0, int n_final, sampler_ws_t* w) {
     size_t o = 0;
@@ -418,10 +479,19 @@ static size_t carve_sampler(char* base, int R, int cap, int n_up, int n0, int n_
     int* q;
     q = (int*)take((size_t)R * sizeof(int)); if (w) w->act0 = q;
     q = (int*)take((size_t)R * sizeof(int)); if (w) w->act1 = q;
-    q = (int*)take(256); if (w) w->count = q;
+    q = (int*)take(COUNT_SLOTS * sizeof(int)); if (w) w->count = q;
     p = (float*)take((size_t)n0 * sizeof(float)); if (w) w->t_init = p;
     p = (float*)take((size_t)(n_up + 2) * sizeof(float)); if (w) w->u_up = p;
     p = (float*)take((size_t)n_final * sizeof(float)); if (w) w->u_final = p;
+    q = (int*)take((size_t)R * sizeof(int)); if (w) w->esc_list = q;
+    p = (float*)take((size_t)R * 3 * sizeof(float)); if (w) w->c_o = p;
+    p = (float*)take((size_t)R * 3 * sizeof(float)); if (w) w->c_dn = p;
+    p = (float*)take((size_t)R * sizeof(float)); if (w) w->c_near = p;
+    p = (float*)take((size_t)R * sizeof(float)); if (w) w->c_far = p;
+    p = (float*)take((size_t)R * n_final * sizeof(float)); if (w) w->c_u = p;
+    p = (float*)take((size_t)R * n_final * sizeof(float)); if (w) w->c_d_fine = p;
+    p = (float*)take((size_t)R * sizeof(float)); if (w) w->c_beta = p;
+    p = (float*)take((size_t)R * sizeof(float)); if (w) w->c_iter = p;
     return o;
 }
 
@@ -432,15 +502,24 @@ long long nerfart_volsdf_sampler_workspace_bytes(int n_rays, int n_init, int n_u
 // fine_sample (volsdf.py:97-302) for n_rays rays with already normalised directions.
 //   near/far: per-ray device arrays or nullptr + scalars.  Outputs: d_fine [R, n_final],
 //   beta_map [R], iter_usage [R] (float: 0..max_iter, -1 = never converged).
-int nerfart_volsdf_fine_sample(const float* surf_blob, int precision, const float* rays_o, const float* rays_dn, int n_rays,
-                               const float* near, const float* far, float near_s, float far_s, float R_bg,
-                               float alpha_net, float beta_net, float eps, int n_init, int n_up, int n_final,
-                               int max_iter, int max_bisect, const float* t_init_dev, const float* u_up_dev,
-                               const float* u_final_dev, int u_final_per_ray, float* d_fine, float* beta_map,
-                               float* iter_usage, void* workspace, long long workspace_bytes, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+// GUARDED form (esc_blob != nullptr && guard > 0; nerfart_volsdf_fine_sample_guarded): the SDF queries run on (surf_blob, precision) - the cheap
+// arithmetic - but every ray whose outcome hangs on a marginal threshold decision is sampled AGAIN, from its first query on, on (esc_blob,
+// esc_precision):  (i) a ray whose max B lies within guard * eps of eps at a convergence check (volsdf.py:162-163, :240-242) stops there;
+// (ii) a ray still active after the last round (volsdf.py:294-300: sampled with its last bisected beta+, the rays any change of rounding moves).
+// Rays are independent, so the escalated rays' samples are bit-identical to a run of the whole batch on esc_blob.
+static int fine_sample_run(const float* surf_blob, int precision, const float* esc_blob, int esc_precision, float guard,
+                           const float* rays_o, const float* rays_dn, int n_rays,
+                           const float* near, const float* far, float near_s, float far_s, float R_bg,
+                           float alpha_net, float beta_net, float eps, int n_init, int n_up, int n_final,
+                           int max_iter, int max_bisect, const float* t_init_dev, const float* u_up_dev,
+                           const float* u_final_dev, int u_final_per_ray, float* d_fine, float* beta_map,
+                           float* iter_usage, void* workspace, long long workspace_bytes, int* n_escalated, hipStream_t stream) {
+    if (n_escalated) *n_escalated = 0;
     if (n_rays <= 0) return 0;
     if (u_final_per_ray && !u_final_dev) { set_last_error("fine_sample: u_final_per_ray needs u_final_dev [n_rays, n_final]"); return 2; }
+    if (max_iter < 0 || max_iter >= ESC_SLOT) { set_last_error("fine_sample: max_iter must be in [0, 62]"); return 2; }
+    const bool guarded = esc_blob != nullptr && guard > 0.f;
+    if (!guarded) guard = 0.f;
     const int u_stride = u_final_per_ray ? n_final : 0;
     const int cap = n_init + max_iter * n_up;
     sampler_ws_t w;
@@ -449,7 +528,8 @@ int nerfart_volsdf_fine_sample(const float* surf_blob, int precision, const floa
     // linspace tables: torch.linspace(0, 1, n) for n = n_init, n_up + 2, n_final.  Callers that hold the
     // host framework's own tables pass them (torch's CPU kernel is vectorised and differs from the scalar
     // formula by an ulp on some entries); otherwise the library's nerfart_linspace is used.
-    if (t_init_dev && u_up_dev && u_final_dev) {
+    const bool own_tables = !(t_init_dev && u_up_dev && u_final_dev);
+    if (!own_tables) {
         w.t_init = const_cast<float*>(t_init_dev); w.u_up = const_cast<float*>(u_up_dev); w.u_final = const_cast<float*>(u_final_dev);
     } else {
         float* h = (float*)malloc(sizeof(float) * (size_t)(n_init + n_up + 2 + n_final));
@@ -467,36 +547,87 @@ int nerfart_volsdf_fine_sample(const float* surf_blob, int precision, const floa
     }
     if (int rc = nerfart_linspace_depths(w.t_init, n_init, near, far, near_s, far_s, n_rays, w.dA, cap, stream)) return rc;
     if (int rc = nerfart_sdf_fwd_rays(surf_blob, precision, rays_o, rays_dn, nullptr, w.dA, n_rays, n_init, cap, R_bg, w.sA, cap, stream)) return rc;
-    NERFART_HIP(hipMemsetAsync(w.count, 0, 256, stream));
+    NERFART_HIP(hipMemsetAsync(w.count, 0, COUNT_SLOTS * sizeof(int), stream));
     const float denom = (float)(4.0 * (double)(n_init - 1) * log(1.0 + (double)eps));     // volsdf.py:149
-    if (int rc = nerfart_volsdf_first_check(n_rays, n_init, cap, n_final, eps, alpha_net, beta_net, w.dA, w.sA, w.u_final,
-                                            u_stride, denom, far, far_s, d_fine, w.beta_plus, beta_map, iter_usage, w.act0,
-                                            w.count, stream)) return rc;
-    int n_act = 0;
-    NERFART_HIP(hipMemcpyAsync(&n_act, w.count, sizeof(int), hipMemcpyDeviceToHost, stream));
+    if (int rc = first_check_launch(n_rays, n_init, cap, n_final, eps, alpha_net, beta_net, w.dA, w.sA, w.u_final,
+                                    u_stride, denom, far, far_s, d_fine, w.beta_plus, beta_map, iter_usage, w.act0,
+                                    w.count, guard, w.esc_list, w.count + ESC_SLOT, stream)) return rc;
+    // one read of the counter block per round (the active count of the round + the escalation list's length so far): the only host synchronisation
+    int h_count[COUNT_SLOTS];
+    NERFART_HIP(hipMemcpyAsync(h_count, w.count, sizeof(h_count), hipMemcpyDeviceToHost, stream));
     NERFART_HIP(hipStreamSynchronize(stream));
+    int n_act = h_count[0];
     float *dA = w.dA, *sA = w.sA, *dB = w.dB, *sB = w.sB;
     int *act = w.act0, *act_next = w.act1;
     int n = n_init;
     for (int it = 1; it <= max_iter && n_act > 0; ++it) {
         if (int rc = nerfart_volsdf_upsample(n_act, n, cap, n_up, dA, sA, act, w.beta_plus, w.u_up, it > 1, w.d_new, stream)) return rc;
         if (int rc = nerfart_sdf_fwd_rays(surf_blob, precision, rays_o, rays_dn, act, w.d_new, n_act, n_up, n_up, R_bg, w.s_new, n_up, stream)) return rc;
-        NERFART_HIP(hipMemsetAsync(w.count + it, 0, sizeof(int), stream));
-        if (int rc = nerfart_volsdf_merge_check(n_act, n, cap, n_up, n_final, max_bisect, it, eps, alpha_net, beta_net, dA, sA,
-                                                dB, sB, act, w.d_new, w.s_new, w.u_final, u_stride, d_fine, w.beta_plus,
-                                                beta_map, iter_usage, act_next, w.count + it, stream)) return rc;
-        NERFART_HIP(hipMemcpyAsync(&n_act, w.count + it, sizeof(int), hipMemcpyDeviceToHost, stream));
+        if (int rc = merge_check_launch(n_act, n, cap, n_up, n_final, max_bisect, it, eps, alpha_net, beta_net, dA, sA,
+                                        dB, sB, act, w.d_new, w.s_new, w.u_final, u_stride, d_fine, w.beta_plus,
+                                        beta_map, iter_usage, act_next, w.count + it, guard, w.esc_list, w.count + ESC_SLOT, stream)) return rc;
+        NERFART_HIP(hipMemcpyAsync(h_count, w.count, sizeof(h_count), hipMemcpyDeviceToHost, stream));
         NERFART_HIP(hipStreamSynchronize(stream));
+        n_act = h_count[it];
         float* t;
         t = dA; dA = dB; dB = t;
         t = sA; sA = sB; sB = t;
         int* ti = act; act = act_next; act_next = ti;
         n += n_up;
     }
-    if (n_act > 0)
-        if (int rc = nerfart_volsdf_finalize(n_act, n, cap, n_final, dA, sA, act, w.u_final, u_stride, w.beta_plus, d_fine,
-                                             beta_map, iter_usage, stream)) return rc;
+    if (!guarded) {
+        if (n_act > 0)
+            if (int rc = nerfart_volsdf_finalize(n_act, n, cap, n_final, dA, sA, act, w.u_final, u_stride, w.beta_plus, d_fine,
+                                                 beta_map, iter_usage, stream)) return rc;
+        return 0;
+    }
+    // ---- escalation: the guard-band rays listed so far + the rays that never converged -> Algorithm 1 again, on the escalation blob ----
+    int n_esc = h_count[ESC_SLOT];
+    if (n_act > 0) {
+        NERFART_HIP(hipMemcpyAsync(w.esc_list + n_esc, act, sizeof(int) * (size_t)n_act, hipMemcpyDeviceToDevice, stream));
+        n_esc += n_act;
+    }
+    if (n_escalated) *n_escalated = n_esc;
+    if (n_esc == 0) return 0;
+    hipLaunchKernelGGL(k_gather_rays, dim3(n_esc), dim3(64), 0, stream, w.esc_list, n_esc, rays_o, rays_dn, near, far,
+                       u_final_per_ray ? u_final_dev : (const float*)nullptr, n_final, w.c_o, w.c_dn, w.c_near, w.c_far, w.c_u);
+    NERFART_HIP(hipGetLastError());
+    // the second run carves the FRONT of this workspace (its n_esc <= n_rays rays need no more than this run's, whose contents are dead); the
+    // compacted rays, their outputs and the list sit behind it.  Tables the library built itself sit in the front too: the second run rebuilds them.
+    const float* u2 = u_final_per_ray ? w.c_u : (own_tables ? nullptr : u_final_dev);
+    const int* esc_list = w.esc_list;
+    float *c_d_fine = w.c_d_fine, *c_beta = w.c_beta, *c_iter = w.c_iter;
+    if (int rc = fine_sample_run(esc_blob, esc_precision, nullptr, 0, 0.f, w.c_o, w.c_dn, n_esc, near ? w.c_near : nullptr, far ? w.c_far : nullptr,
+                                 near_s, far_s, R_bg, alpha_net, beta_net, eps, n_init, n_up, n_final, max_iter, max_bisect,
+                                 own_tables ? nullptr : t_init_dev, own_tables ? nullptr : u_up_dev, u2, u_final_per_ray, c_d_fine, c_beta, c_iter,
+                                 workspace, workspace_bytes, nullptr, stream)) return rc;
+    hipLaunchKernelGGL(k_scatter_samples, dim3(n_esc), dim3(64), 0, stream, esc_list, n_esc, n_final, c_d_fine, c_beta, c_iter, d_fine, beta_map,
+                       iter_usage);
+    NERFART_HIP(hipGetLastError());
     return 0;
+}
+
+int nerfart_volsdf_fine_sample(const float* surf_blob, int precision, const float* rays_o, const float* rays_dn, int n_rays,
+                               const float* near, const float* far, float near_s, float far_s, float R_bg,
+                               float alpha_net, float beta_net, float eps, int n_init, int n_up, int n_final,
+                               int max_iter, int max_bisect, const float* t_init_dev, const float* u_up_dev,
+                               const float* u_final_dev, int u_final_per_ray, float* d_fine, float* beta_map,
+                               float* iter_usage, void* workspace, long long workspace_bytes, void* stream) {
+    return fine_sample_run(surf_blob, precision, nullptr, 0, 0.f, rays_o, rays_dn, n_rays, near, far, near_s, far_s, R_bg, alpha_net, beta_net, eps, n_init,
+                           n_up, n_final, max_iter, max_bisect, t_init_dev, u_up_dev, u_final_dev, u_final_per_ray, d_fine, beta_map, iter_usage, workspace,
+                           workspace_bytes, nullptr, (hipStream_t)stream);
+}
+
+int nerfart_volsdf_fine_sample_guarded(const float* surf_blob, int precision, const float* esc_blob, int esc_precision, float guard,
+                                       const float* rays_o, const float* rays_dn, int n_rays,
+                                       const float* near, const float* far, float near_s, float far_s, float R_bg,
+                                       float alpha_net, float beta_net, float eps, int n_init, int n_up, int n_final,
+                                       int max_iter, int max_bisect, const float* t_init_dev, const float* u_up_dev,
+                                       const float* u_final_dev, int u_final_per_ray, float* d_fine, float* beta_map,
+                                       float* iter_usage, int* n_escalated, void* workspace, long long workspace_bytes, void* stream) {
+    return fine_sample_run(surf_blob, precision, esc_blob, esc_precision, guard, rays_o, rays_dn, n_rays, near, far, near_s, far_s, R_bg, alpha_net, beta_net, eps,
+                           n_init, n_up, n_final, max_iter, max_bisect, t_init_dev, u_up_dev, u_final_dev, u_final_per_ray, d_fine, beta_map, iter_usage,
+                           workspace, workspace_bytes, n_escalated, (hipStream_t)stream);
 }
 
 // ---- whole-chunk VolSDF render (boundary B1: render_fn / volume_render, volsdf.py:389-615) ----
@@ -544,18 +675,21 @@ long long nerfart_volsdf_render_workspace_bytes(int n_rays, int n_samples, int n
 // Renders n_rays rays (rays_d un-normalised, as get_rays returns them).  Outputs rgb [R,3], depth [R],
 // acc [R] always; every other output pointer may be null:  normals [R,3]; detailed per-sample
 // arrays d_all/sdf/sigma [R,P], nabla/radiance [R,P,3], p_i/tau [R,P-1]; beta_map/iter_usage [R].
-// sampler_blob / sampler_precision: the surface blob and precision Algorithm 1's SDF queries run on (the no-gradient sampling stage,
-// volsdf.py:479); the 192 final samples - sdf, nabla, radiance, compositing: every number that reaches a pixel - run on surf_blob /
-// rad_blob at `precision`.  nerfart_volsdf_render_fwd passes the same blob and precision for both.
-int nerfart_volsdf_render_mixed_fwd(const float* surf_blob, const float* rad_blob, int precision, const float* sampler_blob, int sampler_precision,
-                                    int view_tiles, const float* rays_o,
+// Every stage on its own blob / precision (nerfart_volsdf_render_staged_fwd):
+//   sampler_blob / sampler_precision: Algorithm 1's SDF queries (the no-gradient sampling stage, volsdf.py:479), with sampler_guard > 0: guarded -
+//     rays whose convergence decision is marginal or that never converge are sampled again on (surf_blob, precision) (fine_sample_run);
+//   surf_blob / precision: sdf + nabla of the 192 final samples;   rad_blob / rad_precision: the radiance net there;   compositing: fp32.
+// nerfart_volsdf_render_mixed_fwd = this with rad_precision = precision and the guard off; nerfart_volsdf_render_fwd passes the same blob and
+// precision everywhere.
+int nerfart_volsdf_render_staged_fwd(const float* surf_blob, int precision, const float* rad_blob, int rad_precision, const float* sampler_blob,
+                                     int sampler_precision, float sampler_guard, int view_tiles, const float* rays_o,
                               const float* rays_d, int n_rays, float near_s, float far_s, float R_bg, float alpha,
                               float beta, float eps, int n_samples, int n_importance, int max_upsample_steps,
                               int max_bisection_steps, int white_bkgd, int k3_rays_chunk, const float* t_coarse_dev,
                               const float* t_init_dev, const float* u_up_dev, const float* u_final_dev, int u_final_per_ray,
                               float* rgb, float* depth, float* acc, float* normals, float* d_all_out, float* sdf_out, float* nabla_out,
                               float* radiance_out, float* sigma_out, float* p_out, float* tau_out, float* beta_map_out,
-                              float* iter_usage_out, void* workspace, long long workspace_bytes, void* stream_) {
+                              float* iter_usage_out, int* n_escalated, void* workspace, long long workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_rays <= 0) return 0;
     if (!sampler_blob) { set_last_error("render: sampler_blob is NULL"); return 2; }
@@ -572,10 +706,11 @@ int nerfart_volsdf_render_mixed_fwd(const float* surf_blob, const float* rad_blo
     float* iter_usage = iter_usage_out ? iter_usage_out : w.iter_usage;
 
     if (int rc = nerfart_normalize_dirs(rays_d, w.rays_dn, n_rays, stream)) return rc;
-    if (int rc = nerfart_volsdf_fine_sample(sampler_blob, sampler_precision, rays_o, w.rays_dn, n_rays, nullptr, nullptr, near_s, far_s, R_bg,
-                                            alpha, beta, eps, 4 * n_samples, 4 * n_samples, n_importance,
-                                            max_upsample_steps, max_bisection_steps, t_init_dev, u_up_dev, u_final_dev,
-                                            u_final_per_ray, w.d_fine, beta_map, iter_usage, w.sampler, (long long)w.sampler_bytes, stream)) return rc;
+    const bool guarded = sampler_guard > 0.f && (sampler_blob != surf_blob || sampler_precision != precision);
+    if (int rc = fine_sample_run(sampler_blob, sampler_precision, guarded ? surf_blob : nullptr, precision, sampler_guard, rays_o, w.rays_dn, n_rays,
+                                 nullptr, nullptr, near_s, far_s, R_bg, alpha, beta, eps, 4 * n_samples, 4 * n_samples, n_importance,
+                                 max_upsample_steps, max_bisection_steps, t_init_dev, u_up_dev, u_final_dev,
+                                 u_final_per_ray, w.d_fine, beta_map, iter_usage, w.sampler, (long long)w.sampler_bytes, n_escalated, stream)) return rc;
     if (t_coarse_dev) {
         w.t_coarse = const_cast<float*>(t_coarse_dev);
     } else {
@@ -594,11 +729,27 @@ int nerfart_volsdf_render_mixed_fwd(const float* surf_blob, const float* rad_blo
         const size_t po = (size_t)c0 * P;
         if (int rc = nerfart_sdf_nabla_fwd_rays(surf_blob, precision, rays_o + 3 * (size_t)c0, w.rays_dn + 3 * (size_t)c0, nullptr,
                                                 d_all + po, rk, P, P, R_bg, sdf + po, nabla + 3 * po, w.h7, w.nabla_ws, (long long)w.nabla_ws_bytes, stream)) return rc;
-        if (int rc = nerfart_radiance_fwd_rays(rad_blob, precision, view_tiles, rays_o + 3 * (size_t)c0, w.rays_dn + 3 * (size_t)c0,
+        if (int rc = nerfart_radiance_fwd_rays(rad_blob, rad_precision, view_tiles, rays_o + 3 * (size_t)c0, w.rays_dn + 3 * (size_t)c0,
                                                nullptr, d_all + po, rk, P, P, nabla + 3 * po, w.h7, rad + 3 * po, stream)) return rc;
     }
     return nerfart_volsdf_composite(n_rays, P, d_all, sdf, rad, nabla, alpha, beta, white_bkgd, rgb, depth, acc, normals,
                                     sigma_out, p_out, tau_out, stream);
+}
+
+int nerfart_volsdf_render_mixed_fwd(const float* surf_blob, const float* rad_blob, int precision, const float* sampler_blob, int sampler_precision,
+                                    int view_tiles, const float* rays_o,
+                              const float* rays_d, int n_rays, float near_s, float far_s, float R_bg, float alpha,
+                              float beta, float eps, int n_samples, int n_importance, int max_upsample_steps,
+                              int max_bisection_steps, int white_bkgd, int k3_rays_chunk, const float* t_coarse_dev,
+                              const float* t_init_dev, const float* u_up_dev, const float* u_final_dev, int u_final_per_ray,
+                              float* rgb, float* depth, float* acc, float* normals, float* d_all_out, float* sdf_out, float* nabla_out,
+                              float* radiance_out, float* sigma_out, float* p_out, float* tau_out, float* beta_map_out,
+                              float* iter_usage_out, void* workspace, long long workspace_bytes, void* stream_) {
+    return nerfart_volsdf_render_staged_fwd(surf_blob, precision, rad_blob, precision, sampler_blob, sampler_precision, 0.f, view_tiles, rays_o, rays_d, n_rays,
+                                            near_s, far_s, R_bg, alpha, beta, eps, n_samples, n_importance, max_upsample_steps, max_bisection_steps, white_bkgd,
+                                            k3_rays_chunk, t_coarse_dev, t_init_dev, u_up_dev, u_final_dev, u_final_per_ray, rgb, depth, acc, normals, d_all_out,
+                                            sdf_out, nabla_out, radiance_out, sigma_out, p_out, tau_out, beta_map_out, iter_usage_out, nullptr, workspace,
+                                            workspace_bytes, stream_);
 }
 
 int nerfart_volsdf_render_fwd(const float* surf_blob, const float* rad_blob, int precision, int view_tiles, const float* rays_o,

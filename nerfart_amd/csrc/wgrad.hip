@@ -42,34 +42,55 @@ struct Args {
     float* part;                                // [n_mats][n_split][256 * NA + 256]
 };
 
-// two transposing reads = one MFMA operand (8 bf16: rows 4 kg .. 4 kg + 7 of this lane's column), waited for in the statement
+// two transposing reads = one MFMA operand (8 bf16: rows 4 kg .. 4 kg + 7 of this lane's column).  ISSUED only: the caller waits once for a whole
+// k-step's operands (frags_wait) - round 6: the per-fragment `s_waitcnt lgkmcnt(0)` of rounds 3-5 serialised 12 LDS latencies per stage in front of
+// the MFMAs (mfma_util 0.31); now a k-step's 12 reads are in flight together and the NEXT k-step's are issued under this one's 8 MFMAs
+struct Frag { u32x2 a, b; };
 template <int O0, int O1>
-__device__ __forceinline__ bf16x8 frag(unsigned addr) {
-    u32x2 a, b;
-    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(a), "=&v"(b) : "v"(addr), "i"(O0), "i"(O1) : "memory");
-    u32x4 r = {a[0], a[1], b[0], b[1]};
+__device__ __forceinline__ void frag_issue(Frag& f, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+                 : "=&v"(f.a), "=&v"(f.b) : "v"(addr), "i"(O0), "i"(O1) : "memory");
+}
+__device__ __forceinline__ bf16x8 frag_value(const Frag& f) {
+    u32x4 r = {f.a[0], f.a[1], f.b[0], f.b[1]};
     return __builtin_bit_cast(bf16x8, r);
 }
+
+template <int NA> struct Frags { Frag z[Shape<NA>::MB], a[Shape<NA>::NB]; };
 
 // k-step S (16 rows) of a staged tile: fragment of column-block pair mb = subtile rows 4 S + {0, 1} (+ 2 for the upper lane half,
 // which sits in the lane's base address), column blocks 2 mb + {0, 1} (the odd one for lanes 16..31 / 48..63, in the base too)
 template <int NA, int S>
-__device__ __forceinline__ void kstep(unsigned za, unsigned aa, f32x16 (&acc)[Shape<NA>::MB][Shape<NA>::NB]) {
-    constexpr int MB = Shape<NA>::MB, NB = Shape<NA>::NB, NZ = 16, NAB = NA / 16;
-    bf16x8 fz[MB], fa[NB];
-    fz[0] = frag<(0 + (4 * S) * NZ) * 128, (0 + (4 * S + 1) * NZ) * 128>(za);
+__device__ __forceinline__ void frags_issue(Frags<NA>& f, unsigned za, unsigned aa) {
+    constexpr int MB = Shape<NA>::MB, NZ = 16, NAB = NA / 16;
+    frag_issue<(0 + (4 * S) * NZ) * 128, (0 + (4 * S + 1) * NZ) * 128>(f.z[0], za);
     if constexpr (MB > 1) {
-        fz[1] = frag<(2 + (4 * S) * NZ) * 128, (2 + (4 * S + 1) * NZ) * 128>(za);
-        fz[2] = frag<(4 + (4 * S) * NZ) * 128, (4 + (4 * S + 1) * NZ) * 128>(za);
-        fz[3] = frag<(6 + (4 * S) * NZ) * 128, (6 + (4 * S + 1) * NZ) * 128>(za);
+        frag_issue<(2 + (4 * S) * NZ) * 128, (2 + (4 * S + 1) * NZ) * 128>(f.z[1], za);
+        frag_issue<(4 + (4 * S) * NZ) * 128, (4 + (4 * S + 1) * NZ) * 128>(f.z[2], za);
+        frag_issue<(6 + (4 * S) * NZ) * 128, (6 + (4 * S + 1) * NZ) * 128>(f.z[3], za);
     }
-    fa[0] = frag<(0 + (4 * S) * NAB) * 128, (0 + (4 * S + 1) * NAB) * 128>(aa);
-    fa[1] = frag<(2 + (4 * S) * NAB) * 128, (2 + (4 * S + 1) * NAB) * 128>(aa);
+    frag_issue<(0 + (4 * S) * NAB) * 128, (0 + (4 * S + 1) * NAB) * 128>(f.a[0], aa);
+    frag_issue<(2 + (4 * S) * NAB) * 128, (2 + (4 * S + 1) * NAB) * 128>(f.a[1], aa);
+}
+// every LDS read issued so far has landed; the registers of `f` are named as in-outs so that no use of them is scheduled above the wait
+template <int NA>
+__device__ __forceinline__ void frags_wait(Frags<NA>& f) {
+    constexpr int MB = Shape<NA>::MB;
+    if constexpr (MB > 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.z[0].a), "+v"(f.z[0].b), "+v"(f.z[1].a), "+v"(f.z[1].b), "+v"(f.z[2].a), "+v"(f.z[2].b), "+v"(f.z[3].a),
+                     "+v"(f.z[3].b), "+v"(f.a[0].a), "+v"(f.a[0].b), "+v"(f.a[1].a), "+v"(f.a[1].b) :: "memory");
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.z[0].a), "+v"(f.z[0].b), "+v"(f.a[0].a), "+v"(f.a[0].b), "+v"(f.a[1].a), "+v"(f.a[1].b) :: "memory");
+    }
+}
+template <int NA>
+__device__ __forceinline__ void frags_mma(const Frags<NA>& f, f32x16 (&acc)[Shape<NA>::MB][Shape<NA>::NB]) {
+    constexpr int MB = Shape<NA>::MB, NB = Shape<NA>::NB;
 #pragma unroll
     for (int a = 0; a < MB; ++a)
 #pragma unroll
-        for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz[a], fa[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < NB; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_value(f.z[a]), frag_value(f.a[b]), acc[a][b], 0, 0, 0);
 }
 
 template <int NA>
@@ -99,40 +120,46 @@ __global__ __launch_bounds__(THREADS) void k_wgrad(Args g) {
     float cs[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) cs[i] = 0.f;
+    // Loads are UNCONDITIONAL (rows past the slice re-read its last row and are zeroed when staged, a stage past the end re-reads the last stage):
+    // with predicated loads or a branch around a fetch the compiler cannot count what is in flight and falls back to `s_waitcnt vmcnt(0)` in front
+    // of every stage() - which also waits for the fetch issued just before the MFMAs, i.e. one stage of prefetch instead of two (round 6: the
+    // reason k_wgrad<256> sat at 4.98 TB/s, 0.62 of the HBM peak, since round 3).
+    const long long r_last = r_end - 1;
     auto fetch = [&](int kt, int set) {
-        const long long r0 = r_begin + (long long)kt * KT;
+        const long long r0 = r_begin + (long long)(kt < nk ? kt : nk - 1) * KT;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const long long r = r0 + zr + 16 * i;
-            rz[set][i] = u32x4{0u, 0u, 0u, 0u};
-            if (r < r_end) rz[set][i] = *reinterpret_cast<const u32x4*>(Z + (size_t)r * 512 + zq * 16);
-            if constexpr (NA == 256) {
-                ra[set][i] = u32x4{0u, 0u, 0u, 0u};
-                if (r < r_end) ra[set][i] = *reinterpret_cast<const u32x4*>(A + (size_t)r * 512 + zq * 16);
-            }
+            long long r = r0 + zr + 16 * i;
+            r = r < r_last ? r : r_last;
+            rz[set][i] = *reinterpret_cast<const u32x4*>(Z + (size_t)r * 512 + zq * 16);
+            if constexpr (NA == 256) ra[set][i] = *reinterpret_cast<const u32x4*>(A + (size_t)r * 512 + zq * 16);
         }
         if constexpr (NA == 64) {
-            const long long r = r0 + (tid >> 3);
-            ra[set][0] = u32x4{0u, 0u, 0u, 0u};
-            if (tid < 256 && r < r_end) ra[set][0] = *reinterpret_cast<const u32x4*>(A + (size_t)r * 128 + (tid & 7) * 16);
+            long long r = r0 + (tid >> 3);
+            r = r < r_last ? r : r_last;
+            if (tid < 256) ra[set][0] = *reinterpret_cast<const u32x4*>(A + (size_t)r * 128 + (tid & 7) * 16);
         }
     };
     auto stage = [&](int kt, int set, int buf) {
         const long long r0 = r_begin + (long long)kt * KT;
+        const u32x4 zero = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<u32x4*>(Zs + buf * ZT + lds_off(zr + 16 * i, zq, NCB_Z)) = rz[set][i];
-            if constexpr (NA == 256) *reinterpret_cast<u32x4*>(As + buf * AT + lds_off(zr + 16 * i, zq, NCB_A)) = ra[set][i];
-            if (r0 + zr + 16 * i < g.cs_rows) {                  // rows past r_end were fetched as zeros
+            const bool live = r0 + zr + 16 * i < r_end;
+            const u32x4 vz = live ? rz[set][i] : zero;
+            *reinterpret_cast<u32x4*>(Zs + buf * ZT + lds_off(zr + 16 * i, zq, NCB_Z)) = vz;
+            if constexpr (NA == 256) *reinterpret_cast<u32x4*>(As + buf * AT + lds_off(zr + 16 * i, zq, NCB_A)) = live ? ra[set][i] : zero;
+            if (r0 + zr + 16 * i < g.cs_rows) {                  // rows past r_end were staged as zeros
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    cs[2 * e] += __uint_as_float(rz[set][i][e] << 16);
-                    cs[2 * e + 1] += __uint_as_float(rz[set][i][e] & 0xffff0000u);
+                    cs[2 * e] += __uint_as_float(vz[e] << 16);
+                    cs[2 * e + 1] += __uint_as_float(vz[e] & 0xffff0000u);
                 }
             }
         }
         if constexpr (NA == 64) {
-            if (tid < 256) *reinterpret_cast<u32x4*>(As + buf * AT + lds_off(tid >> 3, tid & 7, NCB_A)) = ra[set][0];
+            const bool live = r0 + (tid >> 3) < r_end;
+            if (tid < 256) *reinterpret_cast<u32x4*>(As + buf * AT + lds_off(tid >> 3, tid & 7, NCB_A)) = live ? ra[set][0] : zero;
         }
     };
 
@@ -151,27 +178,35 @@ __global__ __launch_bounds__(THREADS) void k_wgrad(Args g) {
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
     auto compute = [&](int buf) {
         const unsigned za = zs0 + buf * ZT + lane_z, aa = as0 + buf * AT + lane_a;
-        kstep<NA, 0>(za, aa, acc);
-        kstep<NA, 1>(za, aa, acc);
+        Frags<NA> f0, f1;
+        frags_issue<NA, 0>(f0, za, aa);
+        frags_wait<NA>(f0);
+        frags_issue<NA, 1>(f1, za, aa);          // in flight under k-step 0's MFMAs
+        frags_mma<NA>(f0, acc);
+        frags_wait<NA>(f1);
+        frags_mma<NA>(f1, acc);
     };
 
+    // Two stages per iteration, branch-free between a fetch and the stage() that consumes it (a stage past the end stages zeros into a buffer
+    // nobody reads): every path into the loop header carries exactly set 1's four loads, so the compiler's waits are counted (`vmcnt(4)`), never
+    // `vmcnt(0)` - each load is in flight across two compute phases.
     if (nk > 0) {
         fetch(0, 0);
-        if (nk > 1) fetch(1, 1);
+        fetch(1, 1);
         stage(0, 0, 0);
         __syncthreads();
-        for (int kt = 0; kt < nk; kt += 2) {
-            if (kt + 2 < nk) fetch(kt + 2, 0);
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            fetch(kt + 2, 0);
             compute(0);
-            if (kt + 1 < nk) stage(kt + 1, 1, 1);
+            stage(kt + 1, 1, 1);
             __syncthreads();
-            if (kt + 1 < nk) {
-                if (kt + 3 < nk) fetch(kt + 3, 1);
-                compute(1);
-                if (kt + 2 < nk) stage(kt + 2, 0, 0);
-                __syncthreads();
-            }
+            fetch(kt + 3, 1);
+            compute(1);
+            stage(kt + 2, 0, 0);
+            __syncthreads();
         }
+        if (kt < nk) compute(0);                  // odd stage count: the last stage sits in buffer 0
     }
     // ---- partial results: part[mat][sp][p * NA + q], then 256 column sums
     float* out = g.part + ((size_t)mat * g.n_split + sp) * (size_t)(256 * NA + 256);

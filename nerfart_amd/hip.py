@@ -66,6 +66,7 @@ _SIGS = {
     "nerfart_volsdf_finalize": (_i, [_i, _i, _i, _i] + [_p] * 4 + [_i] + [_p] * 5),
     "nerfart_volsdf_sampler_workspace_bytes": (_ll, [_i, _i, _i, _i, _i]),
     "nerfart_volsdf_fine_sample": (_i, [_p, _i, _p, _p, _i, _p, _p, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _ll, _p]),
+    "nerfart_volsdf_fine_sample_guarded": (_i, [_p, _i, _p, _i, _f, _p, _p, _i, _p, _p, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _ll, _p]),
     "nerfart_sort_concat": (_i, [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p]),
     "nerfart_volsdf_composite": (_i, [_i, _i, _p, _p, _p, _p, _f, _f, _i] + [_p] * 8),
     "nerfart_volsdf_composite_bwd": (_i, [_i, _i, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p]),
@@ -80,6 +81,7 @@ _SIGS = {
     "nerfart_volsdf_render_workspace_bytes": (_ll, [_i, _i, _i, _i, _i]),
     "nerfart_volsdf_render_fwd": (_i, [_p, _p, _i, _i, _p, _p, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i] + [_p] * 4 + [_i] + [_p] * 13 + [_p, _ll, _p]),
     "nerfart_volsdf_render_mixed_fwd": (_i, [_p, _p, _i, _p, _i, _i, _p, _p, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i] + [_p] * 4 + [_i] + [_p] * 13 + [_p, _ll, _p]),
+    "nerfart_volsdf_render_staged_fwd": (_i, [_p, _i, _p, _i, _p, _i, _f, _i, _p, _p, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i] + [_p] * 4 + [_i] + [_p] * 13 + [_p, _p, _ll, _p]),
     "nerfart_near_far_from_sphere": (_i, [_p, _p, _i, _f, _p, _p, _p]),
     "nerfart_neus_upsample_step": (_i, [_i, _i, _i, _i, _f, _p, _p, _p, _i, _p, _p]),
     "nerfart_merge_sorted_pairs": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p]),
@@ -121,6 +123,9 @@ _SIGS = {
     "nerfart_surface_blob_floats": (_ll, [_i, _i]),
     "nerfart_radiance_blob_floats": (_ll, [_i, _i]),
     "nerfart_pack_workspace_bytes": (_ll, []),
+    "nerfart_pack_layer_dims": (_i, [_i, _i, _p, _p]),
+    "nerfart_geometry_feature_workspace_bytes": (_ll, []),
+    "nerfart_geometry_feature": (_i, [_p, _p, _p, _p, _ll, _p, _p, _ll, _p]),
     "nerfart_pack_surface_blob": (_i, [_i, _i, _p, _p, _p, _p, _ll, _p, _ll, _p]),
     "nerfart_pack_radiance_blob": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p, _ll, _p, _ll, _p]),
     "nerfart_pack_plan_debug": (_i, [_i, _i, _i] + [_p] * 6),
@@ -166,10 +171,34 @@ def _ptr_table(tensors, name):
     return (C.c_void_p * len(tensors))(*[_dev(t, name=f"{name}[{i}]") for i, t in enumerate(tensors)])
 
 
+def pack_layer_dims(radiance: bool, arg: int):
+    """[(rows, cols)] of the weight_v tensors the packers expect (nerfart_pack_layer_dims): the SDF net for embed_multires = arg, or the
+    radiance net for view_tiles = arg."""
+    rows, cols = (C.c_int * 9)(), (C.c_int * 9)()
+    n = int(lib.nerfart_pack_layer_dims(int(bool(radiance)), int(arg), rows, cols))
+    if n <= 0:
+        raise NotImplementedError(f"nerfart_pack_layer_dims: {lib.nerfart_last_error().decode(errors='replace')}")
+    return [(int(rows[l]), int(cols[l])) for l in range(n)]
+
+
+def check_layers(what: str, dims, weight_g, weight_v, bias):
+    """The pack entry points index HOST pointer tables and DEVICE tensors with the fixed dims of the architecture the kernels are written for:
+    refuse anything else here (NotImplementedError, as the reference-config guard of the packing plans did) instead of reading out of bounds."""
+    if not (len(weight_g) == len(weight_v) == len(bias) == len(dims)):
+        raise NotImplementedError(f"{what}: the kernels are written for {len(dims)} layers (got {len(weight_g)} / {len(weight_v)} / {len(bias)} "
+                                  f"weight_g / weight_v / bias tensors) - SURVEY.md 2: the four shipped configs")
+    for l, (r, c) in enumerate(dims):
+        if tuple(weight_v[l].shape) != (r, c) or weight_g[l].numel() != r or tuple(bias[l].shape) != (r,):
+            raise NotImplementedError(f"{what}: layer {l} must be weight_v [{r}, {c}], weight_g [{r}, 1], bias [{r}] (got {tuple(weight_v[l].shape)}, "
+                                      f"{tuple(weight_g[l].shape)}, {tuple(bias[l].shape)}): W 256, D 8, skips [4], embed_multires 6, W_geo_feat 256 / "
+                                      f"radiance W 256, D 4 are the architectures the kernels are written for")
+
+
 def pack_surface_blob(precision: int, multires: int, weight_g, weight_v, bias) -> torch.Tensor:
     """nerfart_pack_surface_blob: the SDF net's blob for C-ABI `precision` (0 fp32, 1 split bf16, 4 fp16 hi + lo) from the state dict's
     per-layer weight_g [out, 1] / weight_v [out, in] / bias [out] (9 layers) - weight_norm fold, unit-order permutation and hi / lo split on
     the device.  The returned tensor carries `.nerfart_term` ('fp32' | 'bf16' | 'fp16') for the wrappers of entry points that read one encoding only."""
+    check_layers("pack_surface_blob", pack_layer_dims(False, multires), weight_g, weight_v, bias)
     dev = weight_v[0].device
     n = int(lib.nerfart_surface_blob_floats(int(precision), int(multires)))
     if n <= 0:
@@ -188,6 +217,8 @@ def pack_surface_blob(precision: int, multires: int, weight_g, weight_v, bias) -
 def pack_radiance_blob(precision: int, view_tiles: int, surf8, weight_g, weight_v, bias) -> torch.Tensor:
     """nerfart_pack_radiance_blob: surf8 = (weight_g, weight_v, bias) of the SDF net's last layer (its rows 1.. make the geometry feature),
     then the 5 radiance layers' tensors."""
+    check_layers("pack_radiance_blob", pack_layer_dims(True, view_tiles), weight_g, weight_v, bias)
+    check_layers("pack_radiance_blob (the SDF net's last layer)", pack_layer_dims(False, 6)[8:], [surf8[0]], [surf8[1]], [surf8[2]])
     dev = weight_v[0].device
     n = int(lib.nerfart_radiance_blob_floats(int(precision), int(view_tiles)))
     if n <= 0:
@@ -253,6 +284,17 @@ def sdf_nabla_fwd(surf_blob, pts, R_bg: float, want_h7: bool = True, precision: 
     _check(lib.nerfart_sdf_nabla_fwd(_dev(surf_blob), int(precision), _dev(pts, name="pts"), M, float(R_bg), _dev(sdf), _dev(nab),
                                      _dev(h7), _dev(ws, torch.uint8), nb, _stream()), "nerfart_sdf_nabla_fwd")
     return sdf, nab, h7
+
+
+def geometry_feature(weight_g, weight_v, bias, h7):
+    """feat [M, 256] = W8[1:] h7 + b8[1:] (nerfart_geometry_feature: the SDF net's last layer's feature rows, weight_norm folded on the device)."""
+    M = h7.shape[0]
+    out = torch.empty(M, 256, dtype=torch.float32, device=h7.device)
+    ws = _workspace(int(lib.nerfart_geometry_feature_workspace_bytes()), h7.device)
+    _check(lib.nerfart_geometry_feature(_dev(weight_g.detach().reshape(-1).contiguous(), name="weight_g"), _dev(weight_v.detach().contiguous(), name="weight_v"),
+                                        _dev(bias.detach().contiguous(), name="bias"), _dev(h7, name="h7"), M, _dev(out), ws.data_ptr(), ws.numel(), _stream()),
+           "nerfart_geometry_feature")
+    return out
 
 
 def nabla_workspace(precision: int, device):
@@ -405,9 +447,11 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 def volsdf_fine_sample(surf_blob, rays_o, rays_dn, near: float, far: float, R_bg: float, alpha: float, beta: float,
                        eps: float, n_init: int, n_up: int, n_final: int, max_iter: int, max_bisect: int, precision: int = 0,
-                       u_final=None):
+                       u_final=None, escalate=None, guard: float = 0.0, stats=None):
     """u_final [R, n_final]: the caller's uniform random numbers for the final inverse-CDF samples (perturb=True:
-    sample_cdf(det=False), rend_util.py:306-307); None: the deterministic linspace table."""
+    sample_cdf(det=False), rend_util.py:306-307); None: the deterministic linspace table.
+    escalate = (surface blob, precision id) + guard > 0: the GUARDED sampler (nerfart_volsdf_fine_sample_guarded): rays whose convergence decision
+    lies within guard * eps of eps, and rays that never converge, are sampled again on that blob.  stats (dict): 'escalated' += rays that ran twice."""
     R = rays_o.shape[0]
     dev = rays_o.device
     if u_final is not None and tuple(u_final.shape) != (R, n_final):
@@ -417,12 +461,18 @@ def volsdf_fine_sample(surf_blob, rays_o, rays_dn, near: float, far: float, R_bg
     usage = torch.empty(R, dtype=torch.float32, device=dev)
     nb = lib.nerfart_volsdf_sampler_workspace_bytes(R, n_init, n_up, n_final, max_iter)
     ws = _workspace(nb, dev)
-    _check(lib.nerfart_volsdf_fine_sample(_dev(surf_blob), int(precision), _dev(rays_o), _dev(rays_dn), R, None, None, float(near), float(far),
-                                          float(R_bg), float(alpha), float(beta), float(eps), n_init, n_up, n_final, max_iter,
-                                          max_bisect, _dev(lin_table(n_init, dev)), _dev(lin_table(n_up + 2, dev)),
-                                          _dev(lin_table(n_final, dev) if u_final is None else u_final, name="u_final"),
-                                          int(u_final is not None), _dev(d_fine), _dev(beta_map), _dev(usage), ws.data_ptr(), ws.numel(),
-                                          _stream()), "nerfart_volsdf_fine_sample")
+    esc_blob, esc_prec = escalate if (escalate is not None and guard > 0) else (None, 0)
+    n_esc = C.c_int(0)
+    _check(lib.nerfart_volsdf_fine_sample_guarded(_dev(surf_blob), int(precision), _dev(esc_blob, name="esc_blob"), int(esc_prec), float(guard),
+                                                  _dev(rays_o), _dev(rays_dn), R, None, None, float(near), float(far),
+                                                  float(R_bg), float(alpha), float(beta), float(eps), n_init, n_up, n_final, max_iter,
+                                                  max_bisect, _dev(lin_table(n_init, dev)), _dev(lin_table(n_up + 2, dev)),
+                                                  _dev(lin_table(n_final, dev) if u_final is None else u_final, name="u_final"),
+                                                  int(u_final is not None), _dev(d_fine), _dev(beta_map), _dev(usage), C.byref(n_esc), ws.data_ptr(),
+                                                  ws.numel(), _stream()), "nerfart_volsdf_fine_sample_guarded")
+    if stats is not None:
+        stats["escalated"] = stats.get("escalated", 0) + n_esc.value
+        stats["rays"] = stats.get("rays", 0) + R
     return d_fine, beta_map, usage
 
 
@@ -610,10 +660,13 @@ def weight_norm_bwd(dW, weight_v, weight_g):
 
 def volsdf_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, near, far, R_bg, alpha, beta, eps=0.1,
                   n_samples=128, n_importance=64, max_upsample_steps=5, max_bisection_steps=10, white_bkgd=False,
-                  calc_normal=True, detailed=False, k3_rays_chunk=8192, precision=0, u_final=None, sampler=None):
-    """One chunk of rays through nerfart_volsdf_render_fwd.  Returns a dict of flat [R, ...] tensors.
+                  calc_normal=True, detailed=False, k3_rays_chunk=8192, precision=0, u_final=None, sampler=None, guard: float = 0.0,
+                  radiance=None, stats=None):
+    """One chunk of rays through nerfart_volsdf_render_staged_fwd.  Returns a dict of flat [R, ...] tensors.
     u_final [R, n_importance]: uniform random numbers of the final samples (perturb=True); None: deterministic.
-    sampler = (surface blob, precision id): Algorithm 1 on its own blob / precision (nerfart_volsdf_render_mixed_fwd); None: the model's."""
+    sampler = (surface blob, precision id): Algorithm 1 on its own blob / precision; None: the model's.  guard > 0: the guarded sampler (marginal
+    and never-converged rays sampled again on (surf_blob, precision)).  radiance = (radiance blob, precision id): the radiance net of the final
+    samples on its own blob / precision; None: (rad_blob, precision).  stats (dict): 'escalated' / 'rays' accumulated."""
     R = rays_o.shape[0]
     dev = rays_o.device
     P = n_samples + n_importance
@@ -631,25 +684,30 @@ def volsdf_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, near, far,
     ws = _workspace(nb, dev)
     g = lambda k: _dev(det.get(k))
     samp_blob, samp_prec = sampler if sampler is not None else (surf_blob, precision)
-    _check(lib.nerfart_volsdf_render_mixed_fwd(
-        _dev(surf_blob), _dev(rad_blob), int(precision), _dev(samp_blob, name="sampler_blob"), int(samp_prec), int(view_tiles),
-        _dev(rays_o, name="rays_o"), _dev(rays_d, name="rays_d"), R,
+    rblob, rprec = radiance if radiance is not None else (rad_blob, precision)
+    n_esc = C.c_int(0)
+    _check(lib.nerfart_volsdf_render_staged_fwd(
+        _dev(surf_blob), int(precision), _dev(rblob, name="rad_blob"), int(rprec), _dev(samp_blob, name="sampler_blob"), int(samp_prec), float(guard),
+        int(view_tiles), _dev(rays_o, name="rays_o"), _dev(rays_d, name="rays_d"), R,
         float(near), float(far), float(R_bg), float(alpha), float(beta), float(eps), n_samples, n_importance,
         max_upsample_steps, max_bisection_steps, int(bool(white_bkgd)), k3_rays_chunk,
         _dev(lin_table(n_samples, dev)), _dev(lin_table(4 * n_samples, dev)), _dev(lin_table(4 * n_samples + 2, dev)),
         _dev(lin_table(n_importance, dev) if u_final is None else u_final, name="u_final"), int(u_final is not None),
         _dev(out["rgb"]), _dev(out["depth_volume"]), _dev(out["mask_volume"]), _dev(out.get("normals_volume")),
         g("d_vals"), g("implicit_surface"), g("implicit_nablas"), g("radiance"), g("sigma"), g("p_i"),
-        g("visibility_weights"), g("beta_map"), g("iter_usage"), ws.data_ptr(), ws.numel(), _stream()),
-        "nerfart_volsdf_render_mixed_fwd")
+        g("visibility_weights"), g("beta_map"), g("iter_usage"), C.byref(n_esc), ws.data_ptr(), ws.numel(), _stream()),
+        "nerfart_volsdf_render_staged_fwd")
+    if stats is not None:
+        stats["escalated"] = stats.get("escalated", 0) + n_esc.value
+        stats["rays"] = stats.get("rays", 0) + R
     out.update(det)
     return out
 
 
 def volsdf_render_mixed(surf_blob, rad_blob, sampler_blob, sampler_precision: int, view_tiles, rays_o, rays_d, *, near, far, R_bg, alpha, beta, eps=0.1,
                         n_samples=128, n_importance=64, max_upsample_steps=5, max_bisection_steps=10, white_bkgd=False, calc_normal=True,
-                        detailed=False, k3_rays_chunk=8192, precision=1, u_final=None):
-    """volsdf_render(..., sampler=(sampler_blob, sampler_precision)) restated on the PER-STAGE entry points, in the fused renderer's own order
+                        detailed=False, k3_rays_chunk=8192, precision=1, u_final=None, guard: float = 0.0):
+    """volsdf_render(..., sampler=(sampler_blob, sampler_precision), guard=guard) restated on the PER-STAGE entry points, in the fused renderer's own order
     (tests: the two must agree bit for bit, every output): the SAMPLER (Algorithm 1: 512 (1 + rounds) SDF queries per ray, no gradient,
     volsdf.py:479) on another blob / precision than the 192 final samples.  The final samples -
     sdf, nabla, radiance, compositing, i.e. every number that reaches a pixel - run at `precision` on (surf_blob, rad_blob); only WHERE the
@@ -660,7 +718,8 @@ def volsdf_render_mixed(surf_blob, rad_blob, sampler_blob, sampler_precision: in
     f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
     dn = normalize_dirs(rays_d)
     d_fine, beta_map, usage = volsdf_fine_sample(sampler_blob, rays_o, dn, near, far, R_bg, alpha, beta, eps, 4 * n_samples, 4 * n_samples, n_importance,
-                                                 max_upsample_steps, max_bisection_steps, precision=sampler_precision, u_final=u_final)
+                                                 max_upsample_steps, max_bisection_steps, precision=sampler_precision, u_final=u_final,
+                                                 escalate=(surf_blob, precision), guard=guard)
     d_coarse = f(R, n_samples)
     _check(lib.nerfart_linspace_depths(_dev(lin_table(n_samples, dev)), n_samples, None, None, float(near), float(far), R, _dev(d_coarse), n_samples,
                                        _stream()), "nerfart_linspace_depths")
@@ -703,6 +762,8 @@ def neus_sample(surf_blob, rays_o, rays_d, *, obj_bounding_radius, n_samples=64,
     if upsample_algo not in NEUS_UPSAMPLE_ALGOS:
         raise ValueError(f"upsample_algo must be one of {list(NEUS_UPSAMPLE_ALGOS)}")
     algo = NEUS_UPSAMPLE_ALGOS[upsample_algo]
+    if algo == 2 and (4 * int(n_nograd_samples) + max(64, n_importance)) * 4 > 160 * 1024:
+        raise NerfartHipError("upsample_algo 'direct_more' keeps 4 x N_nograd_samples floats per ray in the 160 KiB LDS: N_nograd_samples must be <= 10,200")
     R, dev = rays_o.shape[0], rays_o.device
     P = n_samples + n_importance
     if u_new is not None and tuple(u_new.shape) != (R, n_importance):

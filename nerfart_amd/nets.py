@@ -20,6 +20,14 @@ import torch.nn as nn
 from . import hip
 
 
+# Guard band of the `mixed` mode's sampler (hip.volsdf_fine_sample / nerfart_volsdf_fine_sample_guarded): a ray whose maximum error bound lies within
+# DEFAULT_SAMPLER_GUARD * eps of eps at a convergence check of Algorithm 1 (volsdf.py:162-163, :240-242), or that never converges (:294-300), is
+# sampled again on the split-bf16 kernels.  0.005 is the smallest guard at which the mode reproduces pure split-bf16's outlier statistics against the
+# CPU oracle on all 8 measured views (profiles/r08_guard_sweep*.json, tools/guard_sweep.py: rays past 1e-3 <= bf16x3's + 1 per view, identical counts
+# among the oracle-converged rays; 1.5 - 2.3 % of the rays run twice, + 2 % of a frame); the never-converged rays carry most of it (guard -> 0: 1.1 %).
+DEFAULT_SAMPLER_GUARD = 0.005
+
+
 def embed_dim(multires: int, c: int = 3) -> int:
     return c if multires < 0 else c * (1 + 2 * multires)
 
@@ -96,24 +104,24 @@ class ImplicitSurface(nn.Module):
 
     def forward(self, x: torch.Tensor, return_h: bool = False):
         """ImplicitSurface.forward (models/base.py:243-263): sdf [...] (no sphere clamp) and, with return_h, the geometry
-        feature [..., W_geo_feat].  HIP kernels (K2 / K3a); the feature rows of the last linear layer are one GEMM on h7."""
+        feature [..., W_geo_feat].  HIP kernels (K2 / K3a + nerfart_geometry_feature for the feature rows of the last linear layer)."""
         m = self._model()
         if not return_h:
             return m._surface_query(x, 0.0, False, False)
         sdf, _, h7 = m._surface_query(x, 0.0, True, True)
-        last = self.surface_fc_layers[self.D]
-        w = torch._weight_norm(last.weight_v, last.weight_g, 0)
-        feat = torch.nn.functional.linear(h7, w[1:], last.bias[1:])
-        return sdf, feat.reshape(*x.shape[:-1], -1)
+        return sdf, self._geometry_feature(h7).reshape(*x.shape[:-1], -1)
 
     def forward_with_nablas(self, x: torch.Tensor, has_grad_bak=None):
         """ImplicitSurface.forward_with_nablas (base.py:265-282) under no_grad: (sdf, nablas, geometry feature)."""
         m = self._model()
         sdf, nab, h7 = m._surface_query(x, 0.0, True, True)
+        return sdf, nab, self._geometry_feature(h7).reshape(*x.shape[:-1], -1)
+
+    def _geometry_feature(self, h7):
+        """Rows 1.. of the last linear layer on h7 (models/base.py:258-262): nerfart_geometry_feature - weight_norm fold + fp32 MFMA GEMM in the HIP
+        library (round 6; rounds 1-5 called F.linear here, a rocBLAS GEMM off the frame path)."""
         last = self.surface_fc_layers[self.D]
-        w = torch._weight_norm(last.weight_v, last.weight_g, 0)
-        feat = torch.nn.functional.linear(h7, w[1:], last.bias[1:])
-        return sdf, nab, feat.reshape(*x.shape[:-1], -1)
+        return hip.geometry_feature(last.weight_g, last.weight_v, last.bias, h7)
 
 
 class RadianceNet(nn.Module):
@@ -142,12 +150,22 @@ class _PackedModel(nn.Module):
         if r.embed_multires != -1 or r.embed_multires_view not in (-1, 4):
             raise NotImplementedError("radiance embed_multires must be -1 and embed_multires_view in (-1, 4)")
         self.view_tiles = 1 if r.embed_multires_view == -1 else 3
+        # the kernels and the blob packers are written for ONE architecture per net (the four shipped configs): refuse any other at construction,
+        # not with a fault inside nerfart_pack_*_blob (hip.check_layers holds the tensors themselves to the library's dims again at pack time)
+        g, v, b = self._surface_layers()
+        hip.check_layers("ImplicitSurface", hip.pack_layer_dims(False, s.embed_multires), g, v, b)
+        R = list(r.layers)
+        hip.check_layers("RadianceNet", hip.pack_layer_dims(True, self.view_tiles), [l.weight_g for l in R], [l.weight_v for l in R], [l.bias for l in R])
         self._bind_owner()
         self._blobs = None
         self._blob_key = None
         self.precision = "fp32"
         self.sampler_precision = None
+        self.sampler_guard = 0.0
         self._sampler_blob = None
+        self.radiance_precision = None
+        self._radiance_blob = None
+        self.render_stats = None        # a dict here collects {'rays', 'escalated'} over volume_render calls (bench.py, tests)
 
     def _bind_owner(self):
         import weakref
@@ -161,7 +179,7 @@ class _PackedModel(nn.Module):
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            new.__dict__[k] = None if k in ("_blobs", "_blob_key") else copy.deepcopy(v, memo)
+            new.__dict__[k] = None if k in ("_blobs", "_blob_key", "_sampler_blob", "_radiance_blob") else copy.deepcopy(v, memo)
         new._bind_owner()
         return new
 
@@ -180,13 +198,17 @@ class _PackedModel(nn.Module):
         if precision == "mixed":
             self.precision = "bf16x3"
             self.sampler_precision = "fp16x2" if hasattr(self, "ln_beta") else None
+            self.sampler_guard = DEFAULT_SAMPLER_GUARD if hasattr(self, "ln_beta") else 0.0
         elif precision in hip.PRECISIONS:
             self.precision = precision
             self.sampler_precision = None
+            self.sampler_guard = 0.0
         else:
             raise ValueError(f"precision must be one of {list(hip.PRECISIONS) + ['mixed']}")
         self._blobs = None
         self._sampler_blob = None
+        self.radiance_precision = None
+        self._radiance_blob = None
         return self
 
     @property
@@ -194,18 +216,52 @@ class _PackedModel(nn.Module):
         """'mixed' | 'fp32' | 'bf16x3' | 'fp16x2' | 'bf16x3+<sampler precision> sampler'."""
         if self.sampler_precision is None or self.sampler_precision == self.precision:
             return self.precision
-        return "mixed" if (self.precision, self.sampler_precision) == ("bf16x3", "fp16x2") else f"{self.precision}+{self.sampler_precision} sampler"
+        if (self.precision, self.sampler_precision) == ("bf16x3", "fp16x2") and self.sampler_guard > 0:
+            return "mixed"
+        return f"{self.precision}+{self.sampler_precision} sampler" + (f" (guard {self.sampler_guard:g})" if self.sampler_guard > 0 else " (unguarded)")
 
-    def set_sampler_precision(self, precision):
-        """VolSDF only, a MEASUREMENT variant: run Algorithm 1's SDF queries (512 (1 + rounds) per ray, no gradient,
-        volsdf.py:479) at another precision than the 192 final samples - e.g. model.set_precision("bf16x3").set_sampler_precision("fp16x2"):
-        every number that reaches a pixel is computed in split-bf16, only WHERE the fine samples sit comes from the 2-MFMA kernels.
-        None: the sampler uses the model's precision (the fused renderer)."""
+    def set_sampler_precision(self, precision, guard: float = None):
+        """VolSDF only: run Algorithm 1's SDF queries (512 (1 + rounds) per ray, no gradient, volsdf.py:479) at another precision than the 192 final
+        samples - e.g. model.set_precision("bf16x3").set_sampler_precision("fp16x2") (= set_precision("mixed")): every number that reaches
+        a pixel is computed in split-bf16, only WHERE the fine samples sit comes from the 2-MFMA kernels - and, with guard > 0, not even that for
+        the rays whose convergence decision is marginal (max B within guard * eps of eps) or that never converge: those are sampled again at the
+        model's precision.  guard None = DEFAULT_SAMPLER_GUARD (the shipped mode's), 0 = the unguarded measurement variant of round 5.
+        precision None: the sampler uses the model's precision."""
         if precision is not None and precision not in hip.PRECISIONS:
             raise ValueError(f"precision must be one of {list(hip.PRECISIONS)} or None")
         self.sampler_precision = precision
+        self.sampler_guard = 0.0 if precision is None else (DEFAULT_SAMPLER_GUARD if guard is None else float(guard))
         self._sampler_blob = None
         return self
+
+    def set_radiance_precision(self, precision):
+        """VolSDF's renderer only (nerfart_volsdf_render_staged_fwd): the radiance net of the final samples at another precision than sdf + nabla
+        there - e.g. "fp16x2" (one fp16 activation term x fp16 hi + lo weights, 2 MFMAs per product; SURVEY.md 7 measured plain bf16 on the
+        radiance net alone at rgb 4e-5 with identical sampling).  Inference only: pass 2 reads the split-bf16 blob.  None: the model's."""
+        if precision is not None and precision not in hip.PRECISIONS:
+            raise ValueError(f"precision must be one of {list(hip.PRECISIONS)} or None")
+        self.radiance_precision = precision
+        self._radiance_blob = None
+        return self
+
+    def packed_radiance(self):
+        """(radiance blob, precision id) when the radiance net renders at its own precision; None otherwise."""
+        if self.radiance_precision is None or self.radiance_precision == self.precision:
+            return None
+        key = (self.radiance_precision,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._radiance_blob is None or self._radiance_blob[0] != key:
+            with torch.no_grad():
+                blob = self._pack_radiance(self.radiance_precision)
+            self._radiance_blob = (key, blob)
+        return self._radiance_blob[1], hip.PRECISIONS[self.radiance_precision]
+
+    def sampler_args(self) -> dict:
+        """Keyword arguments of hip.volsdf_fine_sample for this model's sampler: (blob, precision) + the escalation arithmetic and guard."""
+        surf_blob, _ = self.packed()
+        samp = self.packed_sampler()
+        if samp is None:
+            return dict(blob=surf_blob, precision=self.precision_id, escalate=None, guard=0.0)
+        return dict(blob=samp[0], precision=samp[1], escalate=(surf_blob, self.precision_id), guard=self.sampler_guard)
 
     def _surface_layers(self):
         L = list(self.implicit_surface.surface_fc_layers)

@@ -22,9 +22,10 @@ def volume_render(rays_o, rays_d, model: NeuS, obj_bounding_radius=1.0, batched=
                   calc_normal=False, use_view_dirs=True, rayschunk=None, netchunk=1048576, white_bkgd=False,
                   near_bypass=None, far_bypass=None, detailed_output=True, show_progress=False, perturb=False,
                   fixed_s_recp=1 / 64., N_samples=64, N_importance=64, N_outside=0, upsample_algo="official_solution",
-                  N_nograd_samples=2048, N_upsample_iters=4, k3_rays_chunk=8192, uniforms=None, **dummy_kwargs):
+                  N_nograd_samples=2048, N_upsample_iters=4, k3_rays_chunk=8192, uniforms=None, honor_rayschunk=False, **dummy_kwargs):
     """uniforms [N_rays, N_importance] (not a reference argument): with perturb=True, the uniform numbers of the up-sampling rounds
-    (round k reads columns k * N_importance / N_upsample_iters ...), a row per ray, instead of a fresh torch.rand."""
+    (round k reads columns k * N_importance / N_upsample_iters ...), a row per ray, instead of a fresh torch.rand.
+    rayschunk (512 in the NeuS YAMLs' val_rayschunk, neus.py:747): the reference's memory hint - volsdf.launch_rays."""
     if upsample_algo not in hip.NEUS_UPSAMPLE_ALGOS:
         raise NotImplementedError(f"upsample_algo {upsample_algo!r} (neus.py:303: the reference raises too)")
     if N_outside > 0 or near_bypass is not None or far_bypass is not None:
@@ -39,7 +40,8 @@ def volume_render(rays_o, rays_d, model: NeuS, obj_bounding_radius=1.0, batched=
     if model.packed_sampler() is not None:
         raise NotImplementedError("set_sampler_precision is a VolSDF measurement variant (Algorithm 1); NeuS's up-sampling runs at the model's precision")
     s = float(model.forward_s().detach())
-    chunk = int(rayschunk) if rayschunk else DEFAULT_RAYSCHUNK
+    from .volsdf import launch_rays
+    chunk = launch_rays(rayschunk, DEFAULT_RAYSCHUNK, perturb, uniforms, honor_rayschunk)
     parts = []
     for i in range(0, N, chunk):
         # perturb (neus.py:296, rend_util.py:269-272): every up-sampling round inverts its CDF at uniform random numbers

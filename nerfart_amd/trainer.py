@@ -169,11 +169,11 @@ class Trainer(nn.Module):
         near, far = rk.get("near", 0.0), rk.get("far", 6.0)
         # model.set_sampler_precision(...): Algorithm 1 on its own blob / precision (it carries no gradient, volsdf.py:479; the per-sample
         # state pass 2 differentiates is evaluated at the model's precision at whatever depths it returns)
-        samp_blob, samp_prec = m.packed_sampler() or (surf_blob, m.precision_id)
-        d_fine, _, _ = hip.volsdf_fine_sample(samp_blob, o, dn, near, far, rk.get("obj_bounding_radius", 3.0), float(alpha.detach()),
+        sa = m.sampler_args()
+        d_fine, _, _ = hip.volsdf_fine_sample(sa["blob"], o, dn, near, far, rk.get("obj_bounding_radius", 3.0), float(alpha.detach()),
                                               float(beta.detach()), rk.get("epsilon", 0.1), 4 * ns, 4 * ns, ni,
                                               rk.get("max_upsample_steps", 5), rk.get("max_bisection_steps", 10),
-                                              precision=samp_prec,
+                                              precision=sa["precision"], escalate=sa["escalate"], guard=sa["guard"],
                                               u_final=self._uniform(pass_no, first_ray, o.shape[0], ni, o.device) if perturb else None)
         t = hip.lin_table(ns, o.device)
         d_coarse = (near * (1.0 - t) + far * t)[None, :].expand(o.shape[0], ns)
@@ -196,6 +196,9 @@ class Trainer(nn.Module):
         (1 KiB / point in HBM) for pass 2: the weights do not change between the passes and perturb=False is
         deterministic, so pass 2 would recompute exactly these.  Returns rgb [N, 3]; the state waits in self._kept."""
         m = self.model
+        if not self.is_neus:
+            from .volsdf import check_render_kwargs
+            check_render_kwargs(**rk)                 # the staged pass 1 refuses what volume_render refuses
         if m.precision != "bf16x3":
             raise RuntimeError("render_keep keeps split-bf16 pass-1 state for the native pass 2: set_precision('bf16x3') first")
         o = rays_o.reshape(-1, 3).float().contiguous()
@@ -253,12 +256,14 @@ class Trainer(nn.Module):
         m = self.model
         if self.is_neus:
             raise RuntimeError("render_two_draws: VolSDF only (NeuS draws in every up-sampling round)")
+        from .volsdf import check_render_kwargs
+        check_render_kwargs(**rk)                     # the staged pass 1 refuses what volume_render refuses
         if m.precision != "bf16x3":
             raise RuntimeError("render_two_draws feeds the native pass 2: set_precision('mixed') or ('bf16x3') first")
         o = rays_o.reshape(-1, 3).float().contiguous()
         d_raw = rays_d.reshape(-1, 3).float().contiguous()
         surf_blob, rad_blob = m.packed()
-        samp_blob, samp_prec = m.packed_sampler() or (surf_blob, m.precision_id)
+        sa = m.sampler_args()
         alpha, beta = m.forward_ab()
         ab = (float(alpha.detach()), float(beta.detach()))
         white = rk.get("white_bkgd", False)
@@ -274,9 +279,9 @@ class Trainer(nn.Module):
             n = oi.shape[0]
             dn = hip.normalize_dirs(di)
             u = torch.cat([self._uniform(1, i, n, ni, o.device), self._uniform(2, i, n, ni, o.device)], dim=1).contiguous()
-            d_fine, _, _ = hip.volsdf_fine_sample(samp_blob, oi, dn, near, far, rk.get("obj_bounding_radius", 3.0), ab[0], ab[1], rk.get("epsilon", 0.1),
+            d_fine, _, _ = hip.volsdf_fine_sample(sa["blob"], oi, dn, near, far, rk.get("obj_bounding_radius", 3.0), ab[0], ab[1], rk.get("epsilon", 0.1),
                                                   4 * ns, 4 * ns, 2 * ni, rk.get("max_upsample_steps", 5), rk.get("max_bisection_steps", 10),
-                                                  precision=samp_prec, u_final=u)
+                                                  precision=sa["precision"], escalate=sa["escalate"], guard=sa["guard"], u_final=u)
             d_coarse = (near * (1.0 - t) + far * t)[None, :].expand(n, ns)
             dep1 = torch.sort(torch.cat([d_coarse, d_fine[:, :ni]], dim=-1), dim=-1)[0]
             deps2.append(torch.sort(torch.cat([d_coarse, d_fine[:, ni:]], dim=-1), dim=-1)[0])

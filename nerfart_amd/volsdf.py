@@ -5,10 +5,12 @@ set (:389-424) and returns the reference's ``extras`` keys (:566-594); ``SingleR
 ``get_model`` (:943-994) keep their shapes.  The whole chunk body (:448-596: sampling, network queries,
 integration) is one call into the HIP library; Python only slices rays into chunks and reshapes.
 
-Differences that cannot change results: chunks default to 131,072 rays instead of
-2,048-4,000 (rays are independent; the reference sizes were 24 GB fits; with ``perturb=True`` the uniform random
-numbers of the final samples come from torch's generator, one draw per chunk instead of one per converged subset); the 256-d feature map the reference materialises and drops in ``fine_sample`` never exists;
-weight_norm is folded once per weight update.
+Differences that cannot change results: launches hold up to 131,072 rays instead of
+2,048-4,000 - the reference's ``rayschunk`` (render.py:488,614: 2048; ``val_rayschunk`` 1024, volsdf.py:990; 2000, :720) is a 24 GB
+memory fit, rays are independent (:112) and the results here are chunk-invariant bit for bit (tests), so the argument is read as the
+HINT it is: ``launch_rays`` (``honor_rayschunk=True`` slices exactly as asked; with ``perturb=True`` and no ``uniforms`` the chunking
+decides which torch.rand call a ray's numbers come from, so the caller's value is kept there); the 256-d feature map the reference
+materialises and drops in ``fine_sample`` never exists; weight_norm is folded once per weight update.
 """
 from __future__ import annotations
 
@@ -24,18 +26,39 @@ from .nets import VolSDF
 DEFAULT_RAYSCHUNK = 131072      # a 480 x 270 frame in ONE set of sampler rounds (measured: 522.6 -> 519.7 ms against two 65,536-ray chunks; bit-identical)
 
 
-def volume_render(rays_o, rays_d, model: VolSDF, near=0.0, far=6.0, obj_bounding_radius=3.0, batched=False,
-                  batched_info=None, require_nablas=False, calc_normal=True, use_view_dirs=True, rayschunk=None,
-                  netchunk=1048576, white_bkgd=False, use_nerfplusplus=False, detailed_output=True,
-                  show_progress=False, perturb=False, N_samples=128, N_importance=64, N_outside=32,
-                  max_upsample_steps=5, max_bisection_steps=10, epsilon=0.1, k3_rays_chunk=8192, uniforms=None, **dummy_kwargs):
-    """rays_o / rays_d: [(B,) N_rays, 3], rays_d un-normalised.  See module docstring.
-    uniforms [N_rays, N_importance] (not a reference argument): with perturb=True, the uniform numbers of the final inverse-CDF
-    samples, a row per ray, instead of a fresh torch.rand - how a test feeds the draws the reference made."""
+def launch_rays(rayschunk, default: int, perturb: bool = False, uniforms=None, honor_rayschunk: bool = False) -> int:
+    """Rays per library call for a caller's `rayschunk`.  The reference's values (1024 / 2048 / 2000: render.py:488,614, volsdf.py:720,990,
+    train.py:189) size a chunk's activations for a 24 GB card and carry no semantics - every ray is rendered independently (volsdf.py:112,
+    :599-610 only concatenates) - so a SMALLER value than this library's launch size is a hint that 288 GB of HBM does not need: the launch holds
+    max(rayschunk, default) rays and the result is the same bit for bit (tests/test_gpu_configs.py).  Honoured exactly when the caller says
+    so, and when the chunking is observable: perturb=True without `uniforms` draws one torch.rand block per chunk."""
+    if not rayschunk:
+        return int(default)
+    r = int(rayschunk)
+    if honor_rayschunk or (perturb and uniforms is None):
+        return r
+    return max(r, int(default))
+
+
+def check_render_kwargs(use_nerfplusplus=False, use_view_dirs=True, **_):
+    """The render arguments every VolSDF path of this package refuses (volume_render and the Trainer's staged pass 1 alike - ADVICE r05)."""
     if use_nerfplusplus:
         raise NotImplementedError("outside_scene: nerf++ is outside the hot-path scope (SURVEY.md 2, row 19)")
     if not use_view_dirs:
         raise NotImplementedError("use_view_dirs=False is not used by any reference config")
+
+
+def volume_render(rays_o, rays_d, model: VolSDF, near=0.0, far=6.0, obj_bounding_radius=3.0, batched=False,
+                  batched_info=None, require_nablas=False, calc_normal=True, use_view_dirs=True, rayschunk=None,
+                  netchunk=1048576, white_bkgd=False, use_nerfplusplus=False, detailed_output=True,
+                  show_progress=False, perturb=False, N_samples=128, N_importance=64, N_outside=32,
+                  max_upsample_steps=5, max_bisection_steps=10, epsilon=0.1, k3_rays_chunk=8192, uniforms=None, honor_rayschunk=False,
+                  **dummy_kwargs):
+    """rays_o / rays_d: [(B,) N_rays, 3], rays_d un-normalised.  See module docstring.
+    uniforms [N_rays, N_importance] (not a reference argument): with perturb=True, the uniform numbers of the final inverse-CDF
+    samples, a row per ray, instead of a fresh torch.rand - how a test feeds the draws the reference made.
+    rayschunk: the reference's memory hint - see launch_rays (honor_rayschunk=True: slice exactly as asked)."""
+    check_render_kwargs(use_nerfplusplus=use_nerfplusplus, use_view_dirs=use_view_dirs)
     if torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters()) and rays_o.requires_grad:
         raise NotImplementedError("differentiable rays are not supported")
     lead = rays_o.shape[:-1]
@@ -43,10 +66,11 @@ def volume_render(rays_o, rays_d, model: VolSDF, near=0.0, far=6.0, obj_bounding
     rd = rays_d.reshape(-1, 3).float().contiguous()
     N = ro.shape[0]
     surf_blob, rad_blob = model.packed()
+    radiance = model.packed_radiance()                     # None unless model.set_radiance_precision(...) chose another arithmetic for the radiance net
     sampler = model.packed_sampler()                       # None unless model.set_sampler_precision(...) chose another arithmetic for Algorithm 1
     alpha, beta = model.forward_ab()
     alpha, beta = float(alpha.detach()), float(beta.detach())
-    chunk = int(rayschunk) if rayschunk else DEFAULT_RAYSCHUNK
+    chunk = launch_rays(rayschunk, DEFAULT_RAYSCHUNK, perturb, uniforms, honor_rayschunk)
     want_normal = bool(calc_normal and require_nablas)
     parts = []
     for i in range(0, N, chunk):
@@ -62,7 +86,8 @@ def volume_render(rays_o, rays_d, model: VolSDF, near=0.0, far=6.0, obj_bounding
             R_bg=obj_bounding_radius, alpha=alpha, beta=beta, eps=epsilon, n_samples=N_samples,
             n_importance=N_importance, max_upsample_steps=max_upsample_steps,
             max_bisection_steps=max_bisection_steps, white_bkgd=white_bkgd, calc_normal=want_normal,
-            detailed=detailed_output, k3_rays_chunk=k3_rays_chunk, precision=model.precision_id, u_final=u_final, sampler=sampler))
+            detailed=detailed_output, k3_rays_chunk=k3_rays_chunk, precision=model.precision_id, u_final=u_final, sampler=sampler,
+            guard=model.sampler_guard if sampler is not None else 0.0, radiance=radiance, stats=model.render_stats))
     ret = OrderedDict()
     order = ["rgb", "depth_volume", "mask_volume", "normals_volume", "implicit_surface", "implicit_nablas", "radiance",
              "alpha", "p_i", "visibility_weights", "d_vals", "sigma", "beta_map", "iter_usage"]

@@ -26,9 +26,16 @@ sys.path.insert(0, HERE)
 import make_golden as mg  # noqa: E402
 
 K_STEPS = 5
+SGD_LR_FILE = os.path.join(HERE, "trajectory_sgd_lr.json")        # per case: the SGD learning rate tools/trajectory_sensitivity.py settled on
 
 
-def main():
+def main(opt_kind="adam", H=16, W=12, out_name="trajectory_golden.npz"):
+    """opt_kind 'adam': the reference's own optimiser (get_optimizer) - trajectory_golden.npz.  'sgd' (`--sgd`): the SAME loop with
+    torch.optim.SGD(lr) under the same exponential_step schedule, 24 x 16 rays, lr per case from trajectory_sgd_lr.json - a WELL-CONDITIONED
+    trajectory: Adam's first steps are +-lr per entry whatever the gradient's size, so its 5-step run amplifies one-ulp
+    noise to 0.08 - 0.73 in the image and can hold nothing after step 2; SGD's update is linear in the gradient, the reference's own one-ulp
+    deviation stays below 1e-3 (tools/trajectory_sensitivity.py, profiles/r08_trajectory_sensitivity_sgd.json) and the GPU test holds all 5 steps hard."""
+    sgd_lr = json.load(open(SGD_LR_FILE)) if opt_kind == "sgd" else None
     mg.install_stubs()
     sys.path.insert(0, mg.REF)
     os.chdir(mg.REF)
@@ -39,7 +46,6 @@ def main():
     from nerfart_amd import scene, frameworks
     torch.set_num_threads(8)
     out = {}
-    H, W = 16, 12
     c2w, K = scene.camera(H, W)
     g = torch.Generator().manual_seed(79)
     target = torch.rand(1, H * W, 3, generator=g) * 0.3 + 0.5
@@ -72,7 +78,11 @@ def main():
         tag = f"T_{fw}_{branch}_"
         out[tag + "state_sha256"] = np.array(mg.state_checksum(sd))
         theta0 = {n: p.detach().clone() for n, p in model.named_parameters()}
-        optimizer = get_optimizer(cfg, model)
+        if opt_kind == "sgd":
+            cfg.training.lr = float(sgd_lr[f"{fw}_{branch}"])
+            optimizer = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=cfg.training.lr)
+        else:
+            optimizer = get_optimizer(cfg, model)
         scheduler = get_scheduler(cfg, optimizer)
         rk = dict(rk_train)
         rk["perturb"] = False
@@ -141,9 +151,12 @@ def main():
             rgb, _, _ = ref_render(ro, rd, **({"require_nablas": True} if fw == "VolSDF" else {}), calc_normal=True, detailed_output=False, **rk_test)
         out[tag + "final_rgb"] = rgb[0]
         print(tag, "lr", [f"{x:.3e}" for x in lrs], "loss", [round(x, 6) for x in losses], "tensors that moved:", n)
-    np.savez_compressed(os.path.join(HERE, "trajectory_golden.npz"), **mg.t2n(out))
-    print("wrote trajectory_golden.npz", len(out), "arrays")
+    np.savez_compressed(os.path.join(HERE, out_name), **mg.t2n(out))
+    print("wrote", out_name, len(out), "arrays")
 
 
 if __name__ == "__main__":
-    main()
+    if "--sgd" in sys.argv:
+        main("sgd", 24, 16, "trajectory_sgd_golden.npz")
+    else:
+        main()

@@ -50,3 +50,25 @@ def test_fewer_devices_than_ranks_is_refused_not_asserted():
     assert what == "refuse" and "8 visible devices" in msg and "shows 1" in msg
     what, cmd = b.launch_plan(2, {"NERFART_BENCH_BACKEND": "gloo"}, 1, ["--gpus", "2"])
     assert what == "spawn"                                                      # the functional gloo run shares devices
+
+
+def test_the_multi_gpu_line_explains_itself():
+    """at N > 1 the line carries `strong` (one frame over N GPUs: north_star's ray-parallel scaling) and `weak` at top level
+    whichever is primary, per-rank step times, and an explicit cpu_baseline marker with the cached N = 1 figure; at N = 1 nothing is added."""
+    b = _bench()
+    assert b.scale_fields(1, False, 250000.0, 518.0, {}, [518.0], None, None) == {}
+    n1 = {"value": 250000.0, "n_gpus": 1, "cpu_baseline": {"value": 119.4, "unit": "rays/s", "cores": 32, "kind": "port", "sample": "2048 rays"}}
+    sec = {"strong_tiles": {"value": 1.9e6, "unit": "rays/s", "ms_per_step": 68.2, "scaling": "strong"}}
+    f = b.scale_fields(8, False, 1.99e6, 521.0, sec, [520.0, 515.0, 519.0, 521.0, 500.0, 510.0, 505.0, 518.0], "profiles/r08_bench_line.json", n1)
+    assert f["weak"]["is_primary"] and not f["strong"]["is_primary"]
+    assert f["strong"]["value"] == 1.9e6 and f["strong"]["ms_per_step"] == 68.2 and f["weak"]["value"] == 1.99e6
+    assert f["strong"]["speedup_vs_cached_n1"] == 7.6 and f["strong"]["efficiency_vs_n1_hint"] == 0.95
+    assert f["rank_step_ms"]["max"] == 521.0 and f["rank_step_ms"]["min"] == 500.0 and f["rank_step_ms"]["imbalance_max_over_mean"] > 1.0
+    assert f["cpu_baseline"]["n/a at N>1"] and f["cpu_baseline"]["cached_n1"]["value"] == 119.4 and f["n1_reference"]["from"].startswith("profiles/")
+    g = b.scale_fields(2, True, 4.6e5, 281.0, {"weak_views": {"value": 4.9e5, "unit": "rays/s", "ms_per_step": 529.0}}, [281.0, 279.0], None, None)
+    assert g["strong"]["is_primary"] and g["strong"]["value"] == 4.6e5 and g["weak"]["value"] == 4.9e5
+    assert g["strong"]["speedup_vs_cached_n1"] is None and g["cpu_baseline"]["cached_n1"] is None
+    import json
+    json.dumps(f); json.dumps(g)
+    name, line = b.cached_n1_line()
+    assert name is None or (line["n_gpus"] == 1 and line["value"] > 0)

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(hip.lib, s), f"{s} declared in include/nerfart_hip.h but not exported by {hip.LIB_PATH}"
     assert set(hip._SIGS) == set(syms), "ctypes signature table and header disagree"
-    assert hip.ABI_VERSION == 3
+    assert hip.ABI_VERSION == 4
 
 
 def test_library_is_gfx950_code_object():
@@ -124,3 +124,51 @@ def test_render_bwd_entry_points_validate_their_arguments_without_a_gpu():
     assert lib.nerfart_neus_render_bwd(null, null, 2, 6, null, null, 4, 128, null, null, null, null, null, 20.0, 0, 0.1, 0, 0, null, null, 0, null) != 0
     assert b"view_tiles" in lib.nerfart_last_error()
     assert lib.nerfart_volsdf_render_bwd_workspace_bytes(1200, 192, 1) < lib.nerfart_volsdf_render_bwd_workspace_bytes(1200, 192, 0)
+
+
+def test_an_architecture_the_kernels_are_not_written_for_is_refused_before_packing():
+    """nerfart_pack_*_blob index their pointer tables and the device tensors with the fixed dims of the four shipped configs; a
+    YAML-reachable variant (surface.W 512, D 6, skips [], W_geometry_feature 128, radiance W / D) must be a NotImplementedError at model
+    construction - from the library's own dims (nerfart_pack_layer_dims) - not an out-of-bounds read on the GPU."""
+    import pytest
+    from nerfart_amd import hip, nets
+    assert hip.pack_layer_dims(False, 6) == [(256, 39), (256, 256), (256, 256), (217, 256)] + [(256, 256)] * 4 + [(257, 256)]
+    assert hip.pack_layer_dims(True, 1) == [(256, 265)] + [(256, 256)] * 3 + [(3, 256)]
+    assert hip.pack_layer_dims(True, 3)[0] == (256, 289)
+    with pytest.raises(NotImplementedError):
+        hip.pack_layer_dims(False, 4)
+    nets.VolSDF(W_geo_feat=256)                                                       # the shipped architecture constructs
+    nets.NeuS(W_geo_feat=256, radiance_cfg={"embed_multires_view": 4})
+    for bad in (dict(surface_cfg={"W": 512}), dict(surface_cfg={"D": 6}), dict(surface_cfg={"skips": []}), dict(surface_cfg={"skips": [3]}),
+                dict(W_geo_feat=128), dict(radiance_cfg={"W": 128}), dict(radiance_cfg={"D": 3}), dict(surface_cfg={"embed_multires": 4})):
+        with pytest.raises(NotImplementedError):
+            nets.VolSDF(**dict(dict(W_geo_feat=256), **bad))
+    # the pack wrappers hold the tensors themselves to the same dims (a state dict loaded into a hand-built module list)
+    g = [torch.zeros(256, 1)] * 9; v = [torch.zeros(256, 256)] * 9; b = [torch.zeros(256)] * 9
+    with pytest.raises(NotImplementedError):
+        hip.pack_surface_blob(1, 6, g, v, b)
+    with pytest.raises(NotImplementedError):
+        hip.pack_surface_blob(1, 6, g[:7], v[:7], b[:7])
+
+
+def test_rayschunk_is_read_as_the_memory_hint_it_is():
+    """volsdf.launch_rays: the reference's rayschunk values (1024 / 2048 / 2000: render.py:488,614, volsdf.py:720,990) never shrink a launch below the
+    library's own size unless the caller insists or the chunking is observable (perturb=True drawing from torch's generator per chunk)."""
+    from nerfart_amd.volsdf import launch_rays, DEFAULT_RAYSCHUNK
+    assert launch_rays(None, DEFAULT_RAYSCHUNK) == DEFAULT_RAYSCHUNK
+    assert launch_rays(1024, DEFAULT_RAYSCHUNK) == DEFAULT_RAYSCHUNK and launch_rays(2048, DEFAULT_RAYSCHUNK) == DEFAULT_RAYSCHUNK
+    assert launch_rays(1 << 20, DEFAULT_RAYSCHUNK) == 1 << 20                       # a LARGER request is honoured
+    assert launch_rays(1024, DEFAULT_RAYSCHUNK, honor_rayschunk=True) == 1024
+    assert launch_rays(1024, DEFAULT_RAYSCHUNK, perturb=True) == 1024                # draws per chunk: keep the caller's chunking
+    assert launch_rays(1024, DEFAULT_RAYSCHUNK, perturb=True, uniforms=torch.zeros(1, 64)) == DEFAULT_RAYSCHUNK
+
+
+def test_direct_more_refuses_a_bin_count_that_cannot_fit_the_lds():
+    """N_nograd_samples is YAML-reachable (neus.py:735); ~10k+ bins per ray exceed the 160 KiB LDS of k_neus_upsample - refused up
+    front with the limit in the message, not as a generic launch error from inside a render."""
+    import ctypes as C
+    from nerfart_amd import hip
+    null = C.c_void_p(0)
+    args = lambda nn: [null, null, 1, 3, null, null, 8, 1.0, 64.0, 64, 64, 4, 2, nn, 1 / 64., 0, 8192] + [null] * 3 + [0] + [null] * 12 + [null, 0, null]
+    assert hip.lib.nerfart_neus_render_algo_fwd(*args(20000)) != 0 and "10,200" in hip.lib.nerfart_last_error().decode()
+    assert hip.lib.nerfart_neus_render_algo_fwd(*args(2048)) != 0 and "10,200" not in hip.lib.nerfart_last_error().decode()      # passes THIS check (then: no workspace)

@@ -177,7 +177,7 @@ def test_full_frame_bf16x3_vs_fp32():
     kw = {k: v for k, v in rk.items() if k != "rayschunk"}
     a, _, exa = f32(o, d, require_nablas=True, calc_normal=True, detailed_output=True, **kw)
     b, _, exb = f16(o, d, require_nablas=True, calc_normal=True, detailed_output=True, **kw)
-    b2, _, _ = f16(o, d, require_nablas=True, calc_normal=True, detailed_output=False, rayschunk=30000, **kw)
+    b2, _, _ = f16(o, d, require_nablas=True, calc_normal=True, detailed_output=False, rayschunk=30000, honor_rayschunk=True, **kw)
     assert torch.equal(b, b2), "chunk invariance"
     same = (exa["iter_usage"] == exb["iter_usage"]).float().mean().item()
     mse = ((a - b) ** 2).mean().item()

@@ -71,7 +71,7 @@ def test_fp16x2_renders_a_frame_close_to_fp32(fw):
         kw = {k: v for k, v in rk.items() if k != "rayschunk"}
         extra = dict(require_nablas=True) if fw == "VolSDF" else {}
         rgb, depth, _ = fn(o, d, calc_normal=True, detailed_output=False, **extra, **kw)
-        rgb2, _, _ = fn(o, d, calc_normal=True, detailed_output=False, rayschunk=1777, **extra, **kw)
+        rgb2, _, _ = fn(o, d, calc_normal=True, detailed_output=False, rayschunk=1777, honor_rayschunk=True, **extra, **kw)
         assert torch.equal(rgb, rgb2) and torch.isfinite(rgb).all()
         out[precision] = rgb[0]
     err = (out["fp16x2"] - out["fp32"]).abs().max(dim=-1).values

@@ -335,7 +335,7 @@ def test_full_frame_properties():
     acc = ex["mask_volume"]
     assert acc.min() >= 0 and acc.max() <= 1 + 1e-4
     # chunk invariance at full size (bit exact: every ray's arithmetic is independent of its neighbours)
-    rgb2, depth2, _ = render_fn(o, d, require_nablas=True, calc_normal=True, detailed_output=False, rayschunk=40000, **kw)
+    rgb2, depth2, _ = render_fn(o, d, require_nablas=True, calc_normal=True, detailed_output=False, rayschunk=40000, honor_rayschunk=True, **kw)
     assert torch.equal(rgb, rgb2) and torch.equal(depth, depth2)
     # detailed pass on a strided subset: sorted depths, weights sum to acc, oracle agreement
     sel = torch.arange(0, H * W, 2025)[:64]
@@ -577,7 +577,7 @@ def test_nabla_entry_point_is_reentrant_across_streams():
 def test_renderer_is_reentrant_across_threads_and_streams():
     """The fused renderer from two host threads, each on its own stream (ctypes releases the GIL inside the entry point; every
     up-sampling round has a host read): the Python host hands each stream its own workspace, so the two halves of a frame rendered
-    concurrently equal the sequential render bit for bit.  (A workspace shared per DEVICE raced: tools/exp_two_stream.py.)"""
+    concurrently equal the sequential render bit for bit.  (A workspace shared per DEVICE raced: tools/archive/exp_two_stream.py.)"""
     import threading
     from nerfart_amd import scene, rend_util
     model, rk, render_fn = scene.build_model("VolSDF", seed=0, beta=0.01, device=DEV, precision="bf16x3")

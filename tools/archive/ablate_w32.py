@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Timing ablation of k_sdf_only_w32 (csrc/mlp_k2_w32.hip): variant libraries with one component compiled out (results WRONG by
-construction - this only attributes time).   python tools/ablate_w32.py build   (here)  /  run   (on the GPU box)"""
+construction - this only attributes time).   python tools/archive/ablate_w32.py build   (here)  /  run   (on the GPU box)"""
 import json, os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CSRC = os.path.join(ROOT, "nerfart_amd", "csrc")
 OUT = os.path.join(ROOT, "gpurun_ablate")
 VARIANTS = {"full": [], "nodma": ["-DW32_NO_DMA"], "nomfma": ["-DW32_NO_MFMA"], "noepi": ["-DW32_NO_EPI"], "nolds": ["-DW32_NO_LDS"],

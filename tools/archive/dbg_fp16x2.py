@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Debug aid for precision 4: blob (GPU packer vs CPU packer), kernel vs emulation vs oracle on a few points."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import emul_chain as em

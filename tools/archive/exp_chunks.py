@@ -12,10 +12,10 @@ for s in range(5):
     views.append(rend_util.get_rays(c2w[None].to(dev), K[None].to(dev), H, W)[:2])
 ref = None
 for rc, k3 in ((65536, 8192), (131072, 8192), (131072, 16384), (131072, 32768), (65536, 16384), (65536, 8192)):
-    fn(*views[0], require_nablas=True, calc_normal=True, detailed_output=False, rayschunk=rc, k3_rays_chunk=k3, **kw)
+    fn(*views[0], require_nablas=True, calc_normal=True, detailed_output=False, rayschunk=rc, honor_rayschunk=True, k3_rays_chunk=k3, **kw)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for o, d in views[1:]:
-        rgb, _, _ = fn(o, d, require_nablas=True, calc_normal=True, detailed_output=False, rayschunk=rc, k3_rays_chunk=k3, **kw)
+        rgb, _, _ = fn(o, d, require_nablas=True, calc_normal=True, detailed_output=False, rayschunk=rc, honor_rayschunk=True, k3_rays_chunk=k3, **kw)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 4
     if ref is None: ref = rgb.clone()
     print(rc, k3, round(dt * 1e3, 2), "ms", bool(torch.equal(rgb, ref)))

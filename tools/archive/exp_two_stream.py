@@ -4,7 +4,7 @@ HIP streams (ctypes releases the GIL inside the C entry point, so one chunk's ho
 other's launches) against the sequential chunk loop.  Prints ms per frame for both and whether the images are bit-identical."""
 import json, os, sys, threading, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from nerfart_amd import scene, rend_util
 
 dev = torch.device("cuda", 0)

@@ -2,9 +2,9 @@
 """A/B of the two K2 (SDF-only, split-bf16) kernels on one MI355X: the one-wave-per-SIMD kernel (NERFART_K2=w32, csrc/mlp_k2_w32.hip)
 against the 8-wave kernel (default, csrc/mlp_chain_bf16.hip).  Each variant runs in its own process (the switch is read once);
 prints ms per 4 M-point launch, algorithmic TFLOP/s and whether the two outputs are bit-identical.
-    python tools/k2_ab.py [--points 4194304] [--reps 10]"""
+    python tools/archive/k2_ab.py [--points 4194304] [--reps 10]"""
 import argparse, json, os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

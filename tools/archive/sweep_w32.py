@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """Schedule sweep of k_sdf_only_w32 (csrc/mlp_k2_w32.hip): variant libraries that differ in -D macros (placement of the LDS-DMA piece
 inside a double item, ...), each timed on 4 M points and checked against the default library's sdf.
-   python tools/sweep_w32.py build   (here)   /   python tools/sweep_w32.py run   (on the GPU box)"""
+   python tools/archive/sweep_w32.py build   (here)   /   python tools/archive/sweep_w32.py run   (on the GPU box)"""
 import json, os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CSRC = os.path.join(ROOT, "nerfart_amd", "csrc")
 OUT = os.path.join(ROOT, "gpurun_ablate")
 VARIANTS = {f"dma_at_{k}": [f"-DW32_DMA_AT={k}"] for k in range(12)}
