@@ -711,6 +711,8 @@ def main():
                                     "(volsdf.launch_rays; results are bit-identical for any chunking: tests/test_gpu_configs.py)" % rk.get("rayschunk"),
                        "sampler_guard": None if not getattr(model, "sampler_guard", 0.0) else {
                            "guard": model.sampler_guard, "rays_sampled_twice_frac": round(model.render_stats.get("escalated", 0) / max(model.render_stats.get("rays", 1), 1), 5),
+                           "second_run_sdf_ms_per_step": round(prof["k_sdf_only_escalation"][0] / args.steps, 3),
+                           "second_run_sdf_points_per_step": int(prof["k_sdf_only_escalation"][2] / args.steps),
                            "what": "mixed mode: rays whose convergence decision in Algorithm 1 lies within guard * eps of eps, and rays that never converge, are "
                                    "sampled again on the split-bf16 kernels (nerfart_volsdf_fine_sample_guarded); share over every render call of this run"},
                        "samples_per_sec": round(value * (N_SAMPLES + N_IMPORTANCE), 1),

@@ -55,6 +55,9 @@ const char* nerfart_last_error(void);
  * elapsed ms, launch count and units (host arrays of 4). */
 int nerfart_profile_begin(void);
 int nerfart_profile_end(double* ms, long long* launches, long long* units);
+/* (ABI 4) The same with host arrays of 5: class 4 = the SDF queries of the guarded sampler's ESCALATION run (nerfart_volsdf_fine_sample_guarded: the rays
+ * sampled again, on the escalation blob) - kept out of class 0, so that class 0 is the dominant kernel's own launches; nerfart_profile_end drops it. */
+int nerfart_profile_end5(double* ms, long long* launches, long long* units);
 
 /* host helper: torch.linspace(start, end, n) in fp32, bit for bit (out is a HOST array). */
 void nerfart_linspace(float start, float end, int n, float* out);

@@ -19,6 +19,14 @@ SOURCES = ["capi_common.cpp", "wgrad.hip", "pass2_operands.hip", "render_backwar
 HEADERS = ["nerfart_common.h", "ray_common.h", "mlp_common.h", "mlp_bf16_core.h", "gemm_f16.h", "gemm_f32.h"]
 INCLUDES = {"mlp_chain_f16x2.hip": ["mlp_chain_bf16.hip", "mlp_grad_bf16.hip"]}      # sources compiled a second time (precision 4)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-x", "hip"]
+# TEST-ONLY variant libraries (never loaded by the product: nerfart_amd.hip binds libnerfart_hip.so): the same objects with ONE source compiled with
+# extra defines.  scan_generic: the per-ray sampler kernels with the generic two-pass error-bound scan instead of the register-cached one -
+# tests/test_gpu_guarded_sampler.py holds the two bit-identical on whole frames (csrc/ray_common.h).
+VARIANTS = {"scan_generic": ("volsdf_render.hip", ["-DNERFART_SCAN_GENERIC"])}
+
+
+def variant_lib(name: str) -> str:
+    return os.path.join(CSRC, f"libnerfart_hip_{name}.so")
 
 
 def _hipcc() -> str:
@@ -58,6 +66,21 @@ def build(verbose: bool = True, force: bool = False) -> str:
         if verbose:
             print("[nerfart build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    for name, (src_name, defs) in VARIANTS.items():
+        src = os.path.join(CSRC, src_name)
+        obj = os.path.join(bdir, os.path.splitext(src_name)[0] + f".{name}.o")
+        if force or _stale(obj, [src] + hdrs):
+            cmd = [hipcc] + FLAGS + defs + ["-c", src, "-o", obj]
+            if verbose:
+                print("[nerfart build]", " ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        vlib = variant_lib(name)
+        others = [o for o in objs if os.path.basename(o) != os.path.splitext(src_name)[0] + ".o"]
+        if force or _stale(vlib, others + [obj]):
+            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", vlib] + others + [obj]
+            if verbose:
+                print("[nerfart build]", " ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
     return LIB
 
 

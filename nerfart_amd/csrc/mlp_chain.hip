@@ -617,8 +617,9 @@ static size_t nabla_ws_bytes(int precision) {
     if (precision == 1 || precision == 4) return sdf_grad_ws_bytes();
     return 0;                                         // forward-mode tangent kernels (2, 3): none
 }
-static int check_precision(int precision, bool allow_fwd_tangents = false) {
-    if (precision == 0 || precision == 1 || precision == 4 || (allow_fwd_tangents && (precision == 2 || precision == 3))) return 0;
+static int check_precision(int precision, bool allow_fwd_tangents = false, const void* blob = nullptr, const char* who = "point query") {
+    if (precision == 0 || precision == 1 || precision == 4 || (allow_fwd_tangents && (precision == 2 || precision == 3)))
+        return blob ? blob_term_check(blob, term_of_precision(precision), who) : 0;
     set_last_error("precision must be 0 (fp32-exact MFMA), 1 (split-bf16 'bf16x3' MFMA) or 4 (2-MFMA 'fp16x2', measurement variant)");
     return 2;
 }
@@ -652,7 +653,7 @@ static int check_nabla_ws(int precision, const void* ws, long long ws_bytes) {
 extern "C" {
 
 int nerfart_sdf_fwd(const float* blob, int precision, const float* pts, long long M, float R_bg, float* sdf_out, void* stream) {
-    if (int rc = check_precision(precision)) return rc;
+    if (int rc = check_precision(precision, false, blob, "nerfart_sdf_fwd")) return rc;
     if (int rc = check_M(M)) return rc;
     if (M == 0) return 0;
     PointSrc s = make_src(pts, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, M);
@@ -670,7 +671,7 @@ int nerfart_sdf_fwd_rays(const float* blob, int precision, const float* rays_o, 
     if (M == 0) return 0;
     PointSrc s = make_src(nullptr, nullptr, rays_o, rays_d, ray_idx, depth, n_per_ray, depth_stride, M);
     if (int rc = validate_src(s)) return rc;
-    if (int rc = check_precision(precision)) return rc;
+    if (int rc = check_precision(precision, false, blob, "nerfart_sdf_fwd_rays")) return rc;
     if (precision == 4) return sdf_f16x2(blob, s, R_bg, sdf_out, out_stride, (hipStream_t)stream);
     if (precision == 1) return sdf_bf16(blob, s, R_bg, sdf_out, out_stride, (hipStream_t)stream);
     return launch_chain(0, M, k_sdf_only, (unsigned)((M + 127) / 128), (hipStream_t)stream, blob, s, R_bg, sdf_out, out_stride);
@@ -684,7 +685,7 @@ int nerfart_sdf_nabla_fwd(const float* blob, int precision, const float* pts, lo
     if (M == 0) return 0;
     PointSrc s = make_src(pts, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, M);
     if (int rc = validate_src(s)) return rc;
-    if (int rc = check_precision(precision, true)) return rc;
+    if (int rc = check_precision(precision, true, blob, "nerfart_sdf_nabla_fwd")) return rc;
     if (int rc = check_nabla_ws(precision, workspace, workspace_bytes)) return rc;
     if (precision == 1 || precision == 2 || precision == 4) return sdf_nabla_bf16_dispatch(precision, blob, s, R_bg, sdf_out, nabla_out, h7_out, workspace, (hipStream_t)stream);
     return sdf_nabla_f32_dispatch(precision, blob, s, R_bg, sdf_out, nabla_out, h7_out, workspace, (hipStream_t)stream);
@@ -698,7 +699,7 @@ int nerfart_sdf_nabla_fwd_rays(const float* blob, int precision, const float* ra
     if (M == 0) return 0;
     PointSrc s = make_src(nullptr, nullptr, rays_o, rays_d, ray_idx, depth, n_per_ray, depth_stride, M);
     if (int rc = validate_src(s)) return rc;
-    if (int rc = check_precision(precision, true)) return rc;
+    if (int rc = check_precision(precision, true, blob, "nerfart_sdf_nabla_fwd_rays")) return rc;
     if (int rc = check_nabla_ws(precision, workspace, workspace_bytes)) return rc;
     if (precision == 1 || precision == 2 || precision == 4) return sdf_nabla_bf16_dispatch(precision, blob, s, R_bg, sdf_out, nabla_out, h7_out, workspace, (hipStream_t)stream);
     return sdf_nabla_f32_dispatch(precision, blob, s, R_bg, sdf_out, nabla_out, h7_out, workspace, (hipStream_t)stream);
@@ -711,7 +712,7 @@ int nerfart_radiance_fwd(const float* blob, int precision, int view_tiles, const
     if (!view) { set_last_error("radiance_fwd: view dirs required in pts mode"); return 2; }
     PointSrc s = make_src(pts, view, nullptr, nullptr, nullptr, nullptr, 1, 0, M);
     if (int rc = validate_src(s)) return rc;
-    if (int rc = check_precision(precision)) return rc;
+    if (int rc = check_precision(precision, false, blob, "nerfart_radiance_fwd")) return rc;
     if (precision == 4) return radiance_f16x2(blob, view_tiles, s, nabla, h7, rgb_out, (hipStream_t)stream);
     if (precision == 1) return radiance_bf16(blob, view_tiles, s, nabla, h7, rgb_out, (hipStream_t)stream);
     const unsigned nt = (unsigned)((M + 127) / 128);
@@ -729,7 +730,7 @@ int nerfart_radiance_fwd_rays(const float* blob, int precision, int view_tiles, 
     if (M == 0) return 0;
     PointSrc s = make_src(nullptr, nullptr, rays_o, rays_d, ray_idx, depth, n_per_ray, depth_stride, M);
     if (int rc = validate_src(s)) return rc;
-    if (int rc = check_precision(precision)) return rc;
+    if (int rc = check_precision(precision, false, blob, "nerfart_radiance_fwd_rays")) return rc;
     if (precision == 4) return radiance_f16x2(blob, view_tiles, s, nabla, h7, rgb_out, (hipStream_t)stream);
     if (precision == 1) return radiance_bf16(blob, view_tiles, s, nabla, h7, rgb_out, (hipStream_t)stream);
     const unsigned nt = (unsigned)((M + 127) / 128);

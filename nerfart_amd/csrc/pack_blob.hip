@@ -445,6 +445,7 @@ static int launch_pack(const Prog& p, const Tensors& t, int n_layers, float* blo
     const long long threads = NERFART_HDR_INTS + (p.split ? body / 2 : body) + aux_len(p) + L.pad;
     hipLaunchKernelGGL(k_pack, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, a);
     NERFART_HIP(hipGetLastError());
+    blob_term_register(blob, hdr[10]);        // what the entry points that read one fragment encoding check this pointer against (capi_common.cpp)
     return 0;
 }
 

@@ -87,8 +87,10 @@ __device__ __forceinline__ float invert_cdf_at(const float* bins, const float* c
 // a12 error_bound (volsdf.py:56-94) of the n-1 intervals of one ray held in LDS.
 // Returns the maximum bound (wave-uniform).  If w_out != nullptr, bound k is also written to
 // w_out[k] (after NaN -> +inf and, if clamp, clamp to [0, 1e5] as volsdf.py:282).
-__device__ __forceinline__ float error_bound_scan(const float* d, const float* s, int n, float alpha, float beta,
-                                                  float* w_out, bool clamp) {
+// Two passes over a lane's contiguous segment of intervals: local sums of sigma delta and of the E terms, a shuffle scan across the lanes, then
+// the bounds with the running sums.  GENERIC form: any segment length, the second pass recomputes the first pass's two exponentials.
+__device__ __forceinline__ float error_bound_scan_generic(const float* d, const float* s, int n, float alpha, float beta,
+                                                          float* w_out, bool clamp) {
     const int lane = threadIdx.x & 63;
     const int nint = n - 1;
     const int seg = (nint + 63) >> 6;
@@ -117,6 +119,68 @@ __device__ __forceinline__ float error_bound_scan(const float* d, const float* s
         R += sd;
     }
     return wave_max(mx);
+}
+
+// The same for segments of at most MAXSEG intervals (round 6): the first pass keeps each interval's four factors - delta, sigma,
+// alpha / (4 beta) delta^2, exp(-d* / beta) - in registers, so the second pass neither re-reads the LDS rows (lane l's addresses l * seg + i are a
+// seg-word stride: up to 32 lanes per bank) nor recomputes the two exponentials and two divisions per interval, and the fully unrolled first pass
+// runs its MAXSEG independent exp / divide chains interleaved instead of one after the other.  BIT-IDENTICAL to the generic form: the
+// accumulations are written as the fused multiply-adds hipcc contracts the generic form's `+=` into (checked in the ISA: v_fmac_f32 with exactly
+// these operands in both passes), in the same order; tests/test_gpu_guarded_sampler.py::test_cached_scan_equals_generic_scan holds the two equal
+// on whole frames (NERFART_SCAN_GENERIC builds the generic form everywhere).
+template <int MAXSEG>
+__device__ __forceinline__ float error_bound_scan_cached(const float* d, const float* s, int n, float alpha, float beta,
+                                                         float* w_out, bool clamp) {
+    const int lane = threadIdx.x & 63;
+    const int nint = n - 1;
+    const int seg = (nint + 63) >> 6;
+    const int k0 = lane * seg;
+    const int k1 = (k0 + seg < nint) ? k0 + seg : nint;
+    const float a4b = alpha / (4.f * beta);
+    float c_delta[MAXSEG], c_sigma[MAXSEG], c_t[MAXSEG], c_x[MAXSEG];
+    float sR = 0.f, sE = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXSEG; ++i) {
+        const int k = k0 + i;
+        c_delta[i] = 0.f; c_sigma[i] = 0.f; c_t[i] = 0.f; c_x[i] = 0.f;
+        if (k < k1) {
+            const float delta = d[k + 1] - d[k];
+            const float sg = sdf_to_sigma(s[k], alpha, beta);
+            const float dstar = fmaxf(0.5f * (fabsf(s[k]) + fabsf(s[k + 1]) - delta), 0.f);
+            const float t = a4b * (delta * delta);
+            const float x = expf(-dstar / beta);
+            c_delta[i] = delta; c_sigma[i] = sg; c_t[i] = t; c_x[i] = x;
+            sR = __fmaf_rn(delta, sg, sR);
+            sE = __fmaf_rn(t, x, sE);
+        }
+    }
+    float R = wave_excl_sum(sR), E = wave_excl_sum(sE);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < MAXSEG; ++i) {
+        const int k = k0 + i;
+        if (k < k1) {
+            E = __fmaf_rn(c_t[i], c_x[i], E);
+            float b = expf(-R) * (expf(E) - 1.f);
+            if (isnan(b)) b = INFINITY;
+            if (clamp) b = fminf(fmaxf(b, 0.f), 1e5f);
+            if (w_out) w_out[k] = b;
+            mx = fmaxf(mx, b);
+            R = __fmaf_rn(c_delta[i], c_sigma[i], R);
+        }
+    }
+    return wave_max(mx);
+}
+
+__device__ __forceinline__ float error_bound_scan(const float* d, const float* s, int n, float alpha, float beta,
+                                                  float* w_out, bool clamp) {
+#ifndef NERFART_SCAN_GENERIC
+    const int seg = (n - 1 + 63) >> 6;                       // wave-uniform: n is
+    if (seg <= 8) return error_bound_scan_cached<8>(d, s, n, alpha, beta, w_out, clamp);          // 512 samples: the first check
+    if (seg <= 16) return error_bound_scan_cached<16>(d, s, n, alpha, beta, w_out, clamp);        // 1,024: round 1 (every undecided ray of a frame)
+    if (seg <= 24) return error_bound_scan_cached<24>(d, s, n, alpha, beta, w_out, clamp);        // 1,536: round 2 (78 % of them)
+#endif
+    return error_bound_scan_generic(d, s, n, alpha, beta, w_out, clamp);
 }
 
 // cdf[0] = 0, cdf[k+1] = 1 - exp(-R_t[k]) with R_t[k] = sum_{i<k} sigma_i delta_i, k = 0..n-2

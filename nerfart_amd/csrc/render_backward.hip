@@ -417,6 +417,7 @@ long long nerfart_sdf_param_bwd_workspace_bytes(long long M) {
 
 int nerfart_sdf_param_bwd(const float* surf_blob, int multires, const float* pts, long long M, const float* sbar, const float* hbar7, const float* nbar,
                           float* raw, void* workspace, long long workspace_bytes, void* stream) {
+    if (int rc_ = blob_term_check(surf_blob, 1, "nerfart_sdf_param_bwd")) return rc_;
     if (M <= 0) return 0;
     if (M > kMaxPoints) { set_last_error("sdf_param_bwd: at most 2^21 points per call"); return 2; }
     if (!surf_blob || !pts || !nbar || !raw) { set_last_error("sdf_param_bwd: null argument (sbar / hbar7 may be NULL = zero; nbar may not)"); return 2; }
@@ -438,6 +439,7 @@ long long nerfart_radiance_param_bwd_workspace_bytes(long long M) {
 int nerfart_radiance_param_bwd(const float* rad_blob, int view_tiles, const float* pts, const float* view, const float* nabla, const float* h7,
                                long long M, const float* g_rgb, float* rgb_out, float* g_h7_out, float* g_n_out, int train_radiance, float* raw,
                                void* workspace, long long workspace_bytes, void* stream) {
+    if (int rc_ = blob_term_check(rad_blob, 1, "nerfart_radiance_param_bwd")) return rc_;
     if (M <= 0) return 0;
     if (M > kMaxPoints) { set_last_error("radiance_param_bwd: at most 2^21 points per call"); return 2; }
     int mv;
@@ -472,6 +474,8 @@ int nerfart_volsdf_render_bwd(const float* surf_blob, const float* rad_blob, int
                               const float* sdf_state, const float* nabla_state, const float* h7_state, float R_bg, float alpha, float beta,
                               int white_bkgd, float w_eikonal, int eik_group_rays, int train_radiance, float* raw, void* workspace,
                               long long workspace_bytes, void* stream) {
+    if (int rc_ = blob_term_check(surf_blob, 1, "nerfart_volsdf_render_bwd")) return rc_;
+    if (int rc_ = blob_term_check(rad_blob, 1, "nerfart_volsdf_render_bwd")) return rc_;
     if (n_rays <= 0) return 0;
     if (int rc = check_rays(n_rays, P, "volsdf_render_bwd")) return rc;
     int mv;
@@ -516,6 +520,8 @@ int nerfart_neus_render_bwd(const float* surf_blob, const float* rad_blob, int v
                             int n_rays, int P, const float* d_all, const float* g_rgb, const float* g_acc, const float* sdf_state,
                             const float* nabla_state, float s, int white_bkgd, float w_eikonal, int eik_group_rays, int train_radiance, float* raw,
                             void* workspace, long long workspace_bytes, void* stream) {
+    if (int rc_ = blob_term_check(surf_blob, 1, "nerfart_neus_render_bwd")) return rc_;
+    if (int rc_ = blob_term_check(rad_blob, 1, "nerfart_neus_render_bwd")) return rc_;
     if (n_rays <= 0) return 0;
     if (int rc = check_rays(n_rays, P, "neus_render_bwd")) return rc;
     int mv;

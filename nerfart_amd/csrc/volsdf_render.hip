@@ -597,10 +597,13 @@ static int fine_sample_run(const float* surf_blob, int precision, const float* e
     const float* u2 = u_final_per_ray ? w.c_u : (own_tables ? nullptr : u_final_dev);
     const int* esc_list = w.esc_list;
     float *c_d_fine = w.c_d_fine, *c_beta = w.c_beta, *c_iter = w.c_iter;
-    if (int rc = fine_sample_run(esc_blob, esc_precision, nullptr, 0, 0.f, w.c_o, w.c_dn, n_esc, near ? w.c_near : nullptr, far ? w.c_far : nullptr,
-                                 near_s, far_s, R_bg, alpha_net, beta_net, eps, n_init, n_up, n_final, max_iter, max_bisect,
-                                 own_tables ? nullptr : t_init_dev, own_tables ? nullptr : u_up_dev, u2, u_final_per_ray, c_d_fine, c_beta, c_iter,
-                                 workspace, workspace_bytes, nullptr, stream)) return rc;
+    profile_class0_as(4);                     // launch profiling: the escalation run's SDF queries are their own class (nerfart_profile_end5)
+    const int rc_esc = fine_sample_run(esc_blob, esc_precision, nullptr, 0, 0.f, w.c_o, w.c_dn, n_esc, near ? w.c_near : nullptr, far ? w.c_far : nullptr,
+                                       near_s, far_s, R_bg, alpha_net, beta_net, eps, n_init, n_up, n_final, max_iter, max_bisect,
+                                       own_tables ? nullptr : t_init_dev, own_tables ? nullptr : u_up_dev, u2, u_final_per_ray, c_d_fine, c_beta, c_iter,
+                                       workspace, workspace_bytes, nullptr, stream);
+    profile_class0_as(0);
+    if (rc_esc) return rc_esc;
     hipLaunchKernelGGL(k_scatter_samples, dim3(n_esc), dim3(64), 0, stream, esc_list, n_esc, n_final, c_d_fine, c_beta, c_iter, d_fine, beta_map,
                        iter_usage);
     NERFART_HIP(hipGetLastError());

@@ -42,6 +42,7 @@ _SIGS = {
     "nerfart_linspace": (None, [_f, _f, _i, _p]),
     "nerfart_profile_begin": (_i, []),
     "nerfart_profile_end": (_i, [_p, _p, _p]),
+    "nerfart_profile_end5": (_i, [_p, _p, _p]),
     "nerfart_sdf_fwd": (_i, [_p, _i, _p, _ll, _f, _p, _p]),
     "nerfart_sdf_fwd_rays": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _f, _p, _i, _p]),
     "nerfart_sdf_nabla_workspace_bytes": (_ll, [_i]),
@@ -257,10 +258,11 @@ def profile_begin():
 
 def profile_end():
     """-> {kernel: (ms, launches, units)} for the chained-MLP kernels (units = points) and k_wgrad<256> (units = algorithmic bytes)
-    launched since profile_begin()."""
-    ms = (C.c_double * 4)(); ln = (C.c_longlong * 4)(); un = (C.c_longlong * 4)()
-    lib.nerfart_profile_end(ms, ln, un)
-    return {k: (ms[i], ln[i], un[i]) for i, k in enumerate(("k_sdf_only", "k_sdf_nabla", "k_radiance", "k_wgrad256"))}
+    launched since profile_begin(); k_sdf_only_escalation: the SDF queries of the guarded sampler's second run (the re-sampled rays, at the
+    escalation precision) - kept apart from k_sdf_only, the dominant kernel's own launches."""
+    ms = (C.c_double * 5)(); ln = (C.c_longlong * 5)(); un = (C.c_longlong * 5)()
+    lib.nerfart_profile_end5(ms, ln, un)
+    return {k: (ms[i], ln[i], un[i]) for i, k in enumerate(("k_sdf_only", "k_sdf_nabla", "k_radiance", "k_wgrad256", "k_sdf_only_escalation"))}
 
 
 # ---- point queries -----------------------------------------------------------------------

@@ -69,6 +69,7 @@ class Trainer(nn.Module):
         # the uniform numbers of perturb=True: None = torch.rand on the device; a callable (pass_no, first_ray, n_rays, n, device) ->
         # [n_rays, n] lets a test feed the draws the reference made (tests/golden/make_golden_finetune.py records them per pass)
         self.uniform_source = None
+        self._global_rays = None          # (this rank's frame-ray indices, rays in the frame) while a ray-sharded step runs
         # native pass 2: this many of the reference's pass2_rays-ray patches share one set of kernel launches (the per-patch
         # eikonal means are kept); bounded by the kernels' 2^21 points per launch
         self.patches_per_launch = patches_per_launch
@@ -129,6 +130,14 @@ class Trainer(nn.Module):
 
     def _uniform(self, pass_no: int, first_ray: int, n_rays: int, n: int, device):
         if self.uniform_source is not None:
+            if self._global_rays is not None:
+                # ray-sharded step: this rank's rays are tiles of the frame, not a contiguous block - ask the source for the frame's rows and take
+                # the ones this rank holds, so that a sharded step reads exactly the draws of the single-process step
+                idx, n_frame = self._global_rays
+                u = self.uniform_source(pass_no, 0, n_frame, n, device)
+                if tuple(u.shape) != (n_frame, n):
+                    raise ValueError(f"uniform_source returned {tuple(u.shape)}, expected {(n_frame, n)}")
+                return u.to(device=device, dtype=torch.float32)[idx[first_ray:first_ray + n_rays]].contiguous()
             u = self.uniform_source(pass_no, first_ray, n_rays, n, device)
             if tuple(u.shape) != (n_rays, n):
                 raise ValueError(f"uniform_source returned {tuple(u.shape)}, expected {(n_rays, n)}")
@@ -577,6 +586,8 @@ class Trainer(nn.Module):
         self._kept = self._depths2 = None
         if sharded:
             kw = {k: v for k, v in render_kwargs.items() if k != "rayschunk"}
+            n_frame = rays_o.reshape(-1, 3).shape[0]
+            self._global_rays = (nd.shard_plan(n_frame, tile, rays_o.device).idx, n_frame)
             if keep:
                 def fn(ro, rd, **kw_):
                     r = self.render_keep(ro, rd, **kw_)
@@ -621,7 +632,7 @@ class Trainer(nn.Module):
             nd.allreduce_gradients([p for p in self.model.parameters() if p.requires_grad])
         else:
             eik = self.backward_patches(rays_o, rays_d, gradient[0], depths_all=depths_all, kept=self._kept, **render_kwargs)
-        self._kept = self._depths2 = None
+        self._kept = self._depths2 = self._global_rays = None
         return {"loss": float(loss.detach()), "eikonal": eik, "rgb": rgb.detach()}
 
 

@@ -84,10 +84,11 @@ def _perturb_worker(rank, world, port, out_dir):
         tables = {1: torch.rand(H * W, 64, generator=g), 2: torch.rand(H * W, 64, generator=g)}
         loss_fn = lambda pred, gt: ((pred - gt) ** 2).mean()
         kw = dict({k: v for k, v in rk.items() if k != "rayschunk"}, perturb=True)
-        mine = nd.my_ray_indices(H * W, 8, rank, world)
         tr = Trainer(model, pass2_rays=8, patches_per_launch=2)
         assert tr.shares_algorithm1(kw)
-        tr.uniform_source = lambda p, first, count, n, dv: tables[p][mine[first:first + count], :n].to(dv)
+        # the SAME frame-relative source as the single-process step below (round 6, ADVICE r05: the sharded step maps its tiles' rays onto the frame's rows
+        # itself - Trainer._global_rays - instead of handing the source shard-relative offsets)
+        tr.uniform_source = lambda p, first, count, n, dv: tables[p][first:first + count, :n].to(dv)
         model.zero_grad()
         out = tr.finetune_step(render_fn, o, d, target, H, loss_fn, **kw)
         sharded = {n: p.grad.clone() for n, p in model.named_parameters()}

@@ -129,3 +129,90 @@ def test_radiance_net_at_its_own_precision_changes_nothing_but_the_radiance():
     assert float(e) < 3e-4
     c_rgb, _, _ = fn(o[None], d[None], require_nablas=True, calc_normal=True, detailed_output=False, **rk)
     assert torch.equal(c_rgb, a_rgb), "set_radiance_precision(None) restores the model's arithmetic"
+
+
+def test_abi3_mixed_entry_point_is_the_staged_one_with_the_guard_off():
+    """nerfart_volsdf_render_mixed_fwd (ABI 3) keeps its signature and meaning: = nerfart_volsdf_render_staged_fwd(rad_precision = precision, guard = 0)."""
+    from nerfart_amd import hip
+    model, rk, fn, o, d, dn, alpha, beta = _setup(H=24, W=16)
+    surf, rad = model.packed()
+    samp, sprec = model.packed_sampler()
+    R, ns, ni = o.shape[0], 128, 64
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=DEV)
+    rgb, depth, acc, usage = f(R, 3), f(R), f(R), f(R)
+    nb = hip.lib.nerfart_volsdf_render_workspace_bytes(R, ns, ni, 6, 8192)
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    lt = lambda n: hip.lin_table(n, o.device).data_ptr()
+    rc = hip.lib.nerfart_volsdf_render_mixed_fwd(surf.data_ptr(), rad.data_ptr(), 1, samp.data_ptr(), sprec, 1, o.data_ptr(), d.data_ptr(), R, 0.0, 6.0, 3.0, alpha, beta, 0.1,
+                                                 ns, ni, 6, 10, 0, 8192, lt(ns), lt(4 * ns), lt(4 * ns + 2), lt(ni), 0, rgb.data_ptr(), depth.data_ptr(), acc.data_ptr(),
+                                                 None, None, None, None, None, None, None, None, None, usage.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                 torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, hip.lib.nerfart_last_error()
+    ref = hip.volsdf_render(surf, rad, 1, o, d, near=0.0, far=6.0, R_bg=3.0, alpha=alpha, beta=beta, max_upsample_steps=6, detailed=True, precision=1,
+                            sampler=(samp, sprec), guard=0.0)
+    assert torch.equal(rgb, ref["rgb"]) and torch.equal(depth, ref["depth_volume"]) and torch.equal(usage, ref["iter_usage"])
+
+
+_SCAN_CHILD = r'''
+import sys, time, torch
+sys.path.insert(0, %r)
+from nerfart_amd import scene, rend_util, hip
+model, rk, fn = scene.build_model("VolSDF", seed=0, beta=0.01, device="cuda", precision="mixed")
+H, W = 480, 270
+out = {}
+for pose in (5, 40):
+    c2w, K = scene.camera(H, W, angle=scene.spiral(90)[pose])
+    o, d, _ = rend_util.get_rays(c2w[None].cuda(), K[None].cuda(), H, W)
+    dn = hip.normalize_dirs(d[0].contiguous())
+    alpha, beta = (float(t.detach()) for t in model.forward_ab())
+    sa = model.sampler_args()
+    run = lambda: hip.volsdf_fine_sample(sa["blob"], o[0].contiguous(), dn, 0.0, 6.0, 3.0, alpha, beta, 0.1, 512, 512, 64, 6, 10, precision=sa["precision"],
+                                         escalate=sa["escalate"], guard=sa["guard"])
+    run(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    r = run(); torch.cuda.synchronize()
+    out[f"ms_{pose}"] = (time.perf_counter() - t0) * 1e3
+    out[f"pose_{pose}"] = tuple(t.cpu() for t in r)
+# the up-sampling stage on its own (it writes every interval's bound: the w_out / clamp path of the scan), 2,048 rays at three sample counts
+g = torch.Generator().manual_seed(3)
+for n in (512, 1024, 1536, 2048):
+    dA = (torch.rand(2048, n, generator=g) * 6).sort(-1)[0].cuda()
+    sA = (torch.randn(2048, n, generator=g) * 0.3).cuda()
+    act = torch.arange(2048, dtype=torch.int32).cuda()
+    bp = (torch.rand(2048, generator=g) * 0.05 + 0.005).cuda()
+    d_new = torch.empty(2048, 512, device="cuda")
+    hip._check(hip.lib.nerfart_volsdf_upsample(2048, n, n, 512, dA.data_ptr(), sA.data_ptr(), act.data_ptr(), bp.data_ptr(), hip.lin_table(514, dA.device).data_ptr(), 1,
+                                               d_new.data_ptr(), torch.cuda.current_stream().cuda_stream), "upsample")
+    out[f"up_{n}"] = d_new.cpu()
+torch.save(out, sys.argv[1])
+'''
+
+
+def test_cached_scan_equals_generic_scan(tmp_path):
+    """csrc/ray_common.h (round 6): the register-cached error-bound scan (segments of <= 24 intervals per lane: the first check and rounds 1 - 2) against the
+    generic two-pass form (the test-only variant library nerfart_amd.build builds with -DNERFART_SCAN_GENERIC): the guarded sampler's outputs for two
+    whole 480 x 270 frames and the up-sampling stage at 512 .. 2,048 samples per ray, BIT for bit."""
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    from nerfart_amd import build
+    vlib = build.variant_lib("scan_generic")
+    assert os.path.exists(vlib), "python -m nerfart_amd.build builds the test-only variant library"
+    res = {}
+    for name, lib in (("cached", None), ("generic", vlib)):
+        env = dict(os.environ)
+        if lib:
+            env["NERFART_HIP_LIB"] = lib
+        f = str(tmp_path / f"{name}.pt")
+        r = subprocess.run([sys.executable, "-c", _SCAN_CHILD % REPO, f], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[name] = torch.load(f)
+    for k in res["cached"]:
+        if k.startswith("ms_"):
+            continue
+        a, b = res["cached"][k], res["generic"][k]
+        if isinstance(a, tuple):
+            assert all(torch.equal(x, y) for x, y in zip(a, b)), k
+        else:
+            assert torch.equal(a, b), k
+    print("  guarded sampler of a 480x270 frame, ms: " + ", ".join(f"{k[3:]}: cached {res['cached'][k]:.1f} / generic {res['generic'][k]:.1f}" for k in res["cached"] if k.startswith("ms_")))

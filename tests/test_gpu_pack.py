@@ -83,6 +83,19 @@ def test_bf16_only_entry_points_refuse_an_fp16_blob():
     o = torch.zeros(4, 3, device=DEV); d = torch.ones(4, 3, device=DEV); dep = torch.rand(4, 8, device=DEV).sort(-1)[0]
     with pytest.raises(hip.NerfartHipError, match="packed as fp16"):
         hip.volsdf_render_bwd(surf, rad, 1, 6, o, d, dep, torch.zeros(4, 3, device=DEV), hip.new_raw(DEV), R_bg=3.0, alpha=100.0, beta=0.01)
+    # ... and so does the LIBRARY for a C-ABI caller (round 6): the packers record (blob pointer -> fragment encoding) on the host and the
+    # entry points that read one encoding look the pointer up - no Python attribute involved (stripped here), no device read
+    del surf.nerfart_term, rad.nerfart_term
+    with pytest.raises(hip.NerfartHipError, match="packed as fp16"):
+        hip.volsdf_render_bwd(surf, rad, 1, 6, o, d, dep, torch.zeros(4, 3, device=DEV), hip.new_raw(DEV), R_bg=3.0, alpha=100.0, beta=0.01)
+    pts = torch.rand(64, 3, device=DEV)
+    with pytest.raises(hip.NerfartHipError, match="split bf16"):
+        hip.sdf_fwd(surf, pts, 3.0, precision=1)                       # an fp16 blob through the precision-1 kernels
+    with pytest.raises(hip.NerfartHipError, match="fp32"):
+        hip.sdf_fwd(surf, pts, 3.0, precision=0)
+    hip.sdf_fwd(surf, pts, 3.0, precision=4)                           # its own precision: fine
+    copy = surf.clone()                                                # a pointer the packers never saw is not checked (documented)
+    hip.sdf_fwd(copy, pts, 3.0, precision=4)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3", "mixed"])
