@@ -119,7 +119,7 @@ class ImplicitSurface(nn.Module):
 
     def _geometry_feature(self, h7):
         """Rows 1.. of the last linear layer on h7 (models/base.py:258-262): nerfart_geometry_feature - weight_norm fold + fp32 MFMA GEMM in the HIP
-        library (round 6; rounds 1-5 called F.linear here, a rocBLAS GEMM off the frame path)."""
+        library (round 6; rounds 1-5 used a rocBLAS GEMM here, off the frame path)."""
         last = self.surface_fc_layers[self.D]
         return hip.geometry_feature(last.weight_g, last.weight_v, last.bias, h7)
 

@@ -93,7 +93,7 @@ def test_get_model_ships_the_mixed_mode_and_the_yaml_can_override_it():
             with pytest.raises(RuntimeError, match="split-bf16"):
                 tr2.native
     m.set_sampler_precision("fp32")
-    assert m.mode == "bf16x3+fp32 sampler"
+    assert m.mode == "bf16x3+fp32 sampler (guard 0.005)"    # any sampler that is not the model's own arithmetic is guarded by default
     m.set_precision("bf16x3")                               # a precision is the whole mode: it resets the sampler's
     assert m.sampler_precision is None
     with pytest.raises(ValueError):
