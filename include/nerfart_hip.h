@@ -26,7 +26,12 @@
  *       4 = "fp16x2" (csrc/mlp_chain_f16x2.hip): the split-bf16 kernels' data flow with the 2-MFMA split - ONE fp16 activation term
  *           x fp16 hi + lo weight terms, 2 x v_mfma_f32_16x16x32_f16 per product (11-bit activations, TF32 class; blobs from
  *           surface_plan_bf16(term="fp16") / radiance_plan_bf16(term="fp16")).  A MEASUREMENT variant of the three forward
- *           kernels (inference entry points only; workspace as precision 1), never a default - DESIGN.md 4.1b.
+ *           kernels (inference entry points only; workspace as precision 1), never a default - DESIGN.md 4.1b.  It is the arithmetic of
+ *           Algorithm 1's sampler in the shipped `mixed` mode (nerfart_volsdf_render_staged_fwd's sampler_precision, guarded).
+ *       5 = "fp16x1" (csrc/mlp_chain_f16x1.hip; nerfart_sdf_fwd / nerfart_sdf_fwd_rays and the SAMPLER arguments of nerfart_volsdf_fine_sample[_guarded] /
+ *           nerfart_volsdf_render_mixed_fwd / _staged_fwd only - every other entry point refuses it): K2 with ONE v_mfma_f32_16x16x32_f16 per
+ *           product (one fp16 activation term x one fp16 weight term) on the precision-4 blob.  An opt-in, measured and not shipped
+ *           (DESIGN.md 4.1e): no value that reaches a pixel and no gradient is computed in it.
  *   - point sources: either an explicit array pts[M,3], or ("_rays" variants) rays + per-ray depths:
  *     point m = slot m / n_per_ray, sample m % n_per_ray, ray = ray_idx ? ray_idx[slot] : slot,
  *     x = rays_o[ray] + rays_d[ray] * depth[slot * depth_stride + sample]  (two roundings, as the

@@ -15,9 +15,9 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libnerfart_hip.so")
-SOURCES = ["capi_common.cpp", "wgrad.hip", "pass2_operands.hip", "render_backward.hip", "mlp_chain.hip", "mlp_chain_bf16.hip", "mlp_chain_f16x2.hip", "mlp_k2_w32.hip", "mlp_grad_bf16.hip", "mlp_backward_bf16.hip", "volsdf_render.hip", "volsdf_backward.hip", "neus_render.hip", "raygen.hip", "clip_vit.hip", "style_heads.hip", "ray_casting.hip", "vgg_conv.hip", "pack_blob.hip", "geo_feature.hip"]
+SOURCES = ["capi_common.cpp", "wgrad.hip", "pass2_operands.hip", "render_backward.hip", "mlp_chain.hip", "mlp_chain_bf16.hip", "mlp_chain_f16x2.hip", "mlp_chain_f16x1.hip", "mlp_k2_w32.hip", "mlp_grad_bf16.hip", "mlp_backward_bf16.hip", "volsdf_render.hip", "volsdf_backward.hip", "neus_render.hip", "raygen.hip", "clip_vit.hip", "style_heads.hip", "ray_casting.hip", "vgg_conv.hip", "pack_blob.hip", "geo_feature.hip"]
 HEADERS = ["nerfart_common.h", "ray_common.h", "mlp_common.h", "mlp_bf16_core.h", "gemm_f16.h", "gemm_f32.h"]
-INCLUDES = {"mlp_chain_f16x2.hip": ["mlp_chain_bf16.hip", "mlp_grad_bf16.hip"]}      # sources compiled a second time (precision 4)
+INCLUDES = {"mlp_chain_f16x2.hip": ["mlp_chain_bf16.hip", "mlp_grad_bf16.hip"], "mlp_chain_f16x1.hip": ["mlp_chain_bf16.hip"]}      # sources compiled a second time (precision 4)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-x", "hip"]
 # TEST-ONLY variant libraries (never loaded by the product: nerfart_amd.hip binds libnerfart_hip.so): the same objects with ONE source compiled with
 # extra defines.  scan_generic: the per-ray sampler kernels with the generic two-pass error-bound scan instead of the register-cached one -

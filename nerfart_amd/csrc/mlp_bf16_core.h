@@ -121,7 +121,20 @@ __device__ __forceinline__ f32x4 wait_mfma3(u32x4& ah, u32x4& al, const u32x4 bh
                          "v_mfma_f32_16x16x32_f16 %0, %2, %3, %0"
                          : "+v"(acc) : "v"(ah), "v"(al), "v"(bh), "v"(bl), "i"(CNT));
         }
-    } else if constexpr (PAD) {
+    }
+#ifdef NERFART_F16X1          // ONE term each: a_hi b_hi (the lo fragment of this item is never read from LDS: Items)
+    else if constexpr (PAD) {
+        asm volatile("s_waitcnt lgkmcnt(%3)\n\t"
+                     "s_nop 0\n\t"
+                     "v_mfma_f32_16x16x32_f16 %0, %1, %2, %0"
+                     : "+v"(acc) : "v"(ah), "v"(bh), "i"(CNT));
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(%3)\n\t"
+                     "v_mfma_f32_16x16x32_f16 %0, %1, %2, %0"
+                     : "+v"(acc) : "v"(ah), "v"(bh), "i"(CNT));
+    }
+#else
+    else if constexpr (PAD) {
         asm volatile("s_waitcnt lgkmcnt(%4)\n\t"
                      "s_nop 0\n\t"
                      "v_mfma_f32_16x16x32_f16 %0, %1, %3, %0\n\t"
@@ -133,6 +146,7 @@ __device__ __forceinline__ f32x4 wait_mfma3(u32x4& ah, u32x4& al, const u32x4 bh
                      "v_mfma_f32_16x16x32_f16 %0, %2, %3, %0"
                      : "+v"(acc) : "v"(ah), "v"(al), "v"(bh), "i"(CNT));
     }
+#endif
     return acc;
 #else
     if constexpr (PAD) {
@@ -212,7 +226,17 @@ struct Stream {
     int pb;
     bool wrap;                 // another tile follows: chunk 0 comes after chunk nc-1
     int late_st;               // VMEM stores issued after the chunk's last LDS-DMA piece: they may stay in flight across the acquire
+    unsigned long long lo_exec;   // NERFART_F16X1: EXEC mask of the odd (lo fragment) pieces of the chunk being streamed: all lanes or none - see lo_needed
 };
+
+// NERFART_F16X1 (K2 on surface program 3, chunks 0..29 of pack_blob.hip::chunk_desc): wave w streams items 4w..4w+3 of a chunk, i.e. four (hi, lo)
+// fragment pairs of k-step w >> 2 of the chunk - even pieces hi, odd pieces lo.  The lo fragments are read only on the k-steps of the ready-made
+// input units (three-term form): both k-steps of chunk 0 (layer 0), k-step 1 of chunk 16 and k-step 0 of chunk 17 (the skip layer's two encoding
+// units).  Everywhere else the odd pieces are not issued: half the LDS-DMA instructions and half the L2 -> LDS bytes of the weight stream.
+__device__ __forceinline__ bool lo_needed(int chunk) {
+    const unsigned mask = (wave_id() >> 2) ? ((1u << 0) | (1u << 16)) : ((1u << 0) | (1u << 17));
+    return chunk >= 0 && chunk < 32 && ((mask >> chunk) & 1u);
+}
 
 __device__ __forceinline__ void stream_lookup(Stream& s, int chunk) {
     s.nxt = chunk;
@@ -230,6 +254,25 @@ __device__ __forceinline__ int stream_next_of(const Stream& s, int c) {
 // BOTH the global address and the LDS address.
 template <int J>
 __device__ __forceinline__ void stream_piece(const Stream& s) {
+#ifdef NERFART_F16X1
+    if constexpr (J & 1) {
+        // a lo piece: issued under EXEC = lo_exec (all lanes, or none where the chunk's k-step never reads its lo fragments) - no branch inside the
+        // item stream (the counted lgkmcnt windows are straight-line code, tools/audit_asm_loads.py); an instruction with EXEC = 0 moves nothing
+        unsigned keep_m0;
+        unsigned long long keep_exec;
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_add_u32 m0, %4, %5\n\t"
+                     "s_mov_b64 %1, exec\n\t"
+                     "s_mov_b64 exec, %7\n\t"
+                     "global_load_lds_dwordx4 %2, %3 offset:%6\n\t"
+                     "s_mov_b64 exec, %1\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep_m0), "=&s"(keep_exec)
+                     : "v"(J < 4 ? s.voff_a : s.voff_b), "s"(s.iss_src), "s"(s.iss_dst), "i"((J & 4) * 1024), "i"((J & 3) * 1024), "s"(s.lo_exec)
+                     : "memory", "scc");
+        return;
+    }
+#endif
 #ifndef NERFART_ABLATE_DMA
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\t"
@@ -257,6 +300,7 @@ __device__ __forceinline__ void stream_start(Stream& s) {
     s.voff_b = lane_id() * 16 + 4096;
     stream_lookup(s, 0);
     stream_target(s, s.nxt_o0, 0);
+    s.lo_exec = ~0ull;
     stream_piece<0>(s); stream_piece<1>(s); stream_piece<2>(s); stream_piece<3>(s);
     stream_piece<4>(s); stream_piece<5>(s); stream_piece<6>(s); stream_piece<7>(s);
     s.pb = 0;
@@ -276,6 +320,9 @@ __device__ __forceinline__ const float* stream_acquire(Stream& s) {
 #endif
     const float* w = s.lds + s.pb * CHUNK_FLOATS;
     stream_target(s, s.nxt_o0, s.pb ^ 1);
+#ifdef NERFART_F16X1
+    s.lo_exec = __builtin_amdgcn_readfirstlane((int)lo_needed(s.nxt)) != 0 ? ~0ull : 0ull;
+#endif
     stream_lookup(s, stream_next_of(s, s.nxt));
     s.pb ^= 1;
     return w;
@@ -514,6 +561,10 @@ __device__ __forceinline__ void lds_read_pair(u32x4& fh, u32x4& fl, unsigned add
     asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
                  : "=&v"(fh), "=&v"(fl) : "v"(addr), "i"(OFF), "i"(OFF + 1024));
 }
+template <int OFF>
+__device__ __forceinline__ void lds_read_hi(u32x4& fh, unsigned addr) {      // NERFART_F16X1: the item's hi fragment alone
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(fh) : "v"(addr), "i"(OFF));
+}
 template <int CNT>
 __device__ __forceinline__ void lds_wait_pair(u32x4& fh, u32x4& fl) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fh), "+v"(fl) : "i"(CNT));
@@ -547,6 +598,13 @@ struct Cfg {
 
 template <class L, int C, int NKC, int IT>
 struct Items {
+    // NERFART_F16X1: does item `it` of this chunk belong to a k-step of ready-made input units (hi + lo fragments, three terms)?
+    static constexpr bool item_full(int it) { return (CHUNK_KS * C + (it >> 4)) >= L::NH; }
+    static constexpr int pending_after(int it, int n) {
+        int p = 0;
+        for (int i = 1; i <= L::AHEAD && it + i < n; ++i) p += item_full(it + i) ? 2 : 1;
+        return p;
+    }
     static __device__ __forceinline__ void run(const Acc& P, Acc& Q, Unit (&xb)[2], const Unit (&xs)[L::NXA], Unit& x0n, Work2& w,
                                                RingT<L::AHEAD + 1 + RING_EXTRA>& r, unsigned addr, const Stream& s, const EpiCtx& ec, GradCtx& gc) {
         constexpr int N = NKC * 16;
@@ -555,9 +613,19 @@ struct Items {
             constexpr int AH = L::AHEAD, NS = AH + 1 + RING_EXTRA;
             constexpr int S = IT % NS, S2 = (IT + AH) % NS;
             constexpr int LEFT = N - 1 - IT;
+#ifdef NERFART_F16X1
+            // one fragment read per item on the k-steps whose input unit is built from accumulators (1 MFMA: a_hi b_hi), two on the ready-made
+            // units' (three-term form): the counted wait of item IT leaves the reads of the items behind it in flight
+            constexpr int PENDING = pending_after(IT, N);
+            if constexpr (IT + AH < N) {
+                if constexpr (item_full(IT + AH)) lds_read_pair<(IT + AH) * 2048>(r.h[S2], r.l[S2], addr);
+                else lds_read_hi<(IT + AH) * 2048>(r.h[S2], addr);
+            }
+#else
             constexpr int PENDING = 2 * (LEFT < AH ? LEFT : AH);
 #ifndef NERFART_EXP_SEG4
             if constexpr (IT + AH < N) lds_read_pair<(IT + AH) * 2048>(r.h[S2], r.l[S2], addr);
+#endif
 #endif
             u32x4 bh, bl;
             if constexpr (ks < L::NH) { bh = xb[ks & 1].h; bl = xb[ks & 1].l; }
@@ -733,8 +801,19 @@ __device__ __forceinline__ void run_chunk(const Acc& P, Acc& Q, Unit (&xb)[2], c
         // waits below assume only the ring's reads are outstanding
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         RingT<L::AHEAD + 1 + RING_EXTRA> r;
+#ifdef NERFART_F16X1
+        static_assert(L::AHEAD == 2, "the 1-MFMA form is written for a two-item read-ahead");
+        if constexpr (CHUNK_KS * C >= L::NH) {
+            lds_read_pair<0>(r.h[0], r.l[0], addr);
+            lds_read_pair<2048>(r.h[1], r.l[1], addr);
+        } else {
+            lds_read_hi<0>(r.h[0], addr);
+            lds_read_hi<2048>(r.h[1], addr);
+        }
+#else
         lds_read_pair<0>(r.h[0], r.l[0], addr);
         lds_read_pair<2048>(r.h[1], r.l[1], addr);
+#endif
 #ifdef NERFART_EXP_SEG4
         lds_read_pair<4096>(r.h[2], r.l[2], addr);
         lds_read_pair<6144>(r.h[3], r.l[3], addr);
@@ -916,7 +995,7 @@ __device__ __forceinline__ float surface_chain(float px, float py, float pz, int
 __device__ __forceinline__ Stream make_stream(const float* blob, const float* aux, float* smem, int nc) {
     Stream s;
     s.blob = blob; s.tab = reinterpret_cast<const int*>(aux + AUX_FLOATS_MAX); s.lds = smem; s.nc = nc;
-    s.iss_src = blob; s.iss_dst = 0; s.voff_a = 0; s.voff_b = 0; s.nxt = -1; s.nxt_o0 = 0; s.pb = 0; s.wrap = false; s.late_st = 0;
+    s.iss_src = blob; s.iss_dst = 0; s.voff_a = 0; s.voff_b = 0; s.nxt = -1; s.nxt_o0 = 0; s.pb = 0; s.wrap = false; s.late_st = 0; s.lo_exec = ~0ull;
     return s;
 }
 

@@ -611,14 +611,21 @@ int sdf_grad_bf16(const float* blob, const PointSrc& s, float R_bg, float* sdf, 
 int sdf_f16x2(const float* blob, const PointSrc& s, float R_bg, float* out, int out_stride, hipStream_t st);
 int radiance_f16x2(const float* blob, int view_tiles, const PointSrc& s, const float* nabla, const float* h7, float* rgb, hipStream_t st);
 int sdf_grad_f16x2(const float* blob, const PointSrc& s, float R_bg, float* sdf, float* nabla, float* h7, void* ws, hipStream_t st);
+// precision 5 (csrc/mlp_chain_f16x1.hip: K2 alone with ONE MFMA per product, on the precision-4 blob; the SDF-only entry points, i.e. the sampler's queries)
+int sdf_f16x1(const float* blob, const PointSrc& s, float R_bg, float* out, int out_stride, hipStream_t st);
 // bytes of the reverse-mode kernels' softplus' scratch (one private region per resident workgroup): caller owned
 static size_t nabla_ws_bytes(int precision) {
     if (precision == 0) return (size_t)num_cus() * GRADF_WS_PER_WG;
     if (precision == 1 || precision == 4) return sdf_grad_ws_bytes();
     return 0;                                         // forward-mode tangent kernels (2, 3): none
 }
-static int check_precision(int precision, bool allow_fwd_tangents = false, const void* blob = nullptr, const char* who = "point query") {
-    if (precision == 0 || precision == 1 || precision == 4 || (allow_fwd_tangents && (precision == 2 || precision == 3)))
+static int check_precision(int precision, bool allow_fwd_tangents = false, const void* blob = nullptr, const char* who = "point query", bool sdf_only = false) {
+    if (precision == 5 && !sdf_only) {
+        set_last_error("precision 5 (1-MFMA 'fp16x1') exists for the SDF-only queries of Algorithm 1's sampler (nerfart_sdf_fwd / nerfart_sdf_fwd_rays / the sampler "
+                       "stage of the renderers): no value that reaches a pixel is computed in it");
+        return 2;
+    }
+    if (precision == 5 || precision == 1 || precision == 4 || (allow_fwd_tangents && (precision == 2 || precision == 3)))
         return blob ? blob_term_check(blob, term_of_precision(precision), who) : 0;
     set_last_error("precision must be 0 (fp32-exact MFMA), 1 (split-bf16 'bf16x3' MFMA) or 4 (2-MFMA 'fp16x2', measurement variant)");
     return 2;
@@ -653,11 +660,12 @@ static int check_nabla_ws(int precision, const void* ws, long long ws_bytes) {
 extern "C" {
 
 int nerfart_sdf_fwd(const float* blob, int precision, const float* pts, long long M, float R_bg, float* sdf_out, void* stream) {
-    if (int rc = check_precision(precision, false, blob, "nerfart_sdf_fwd")) return rc;
+    if (int rc = check_precision(precision, false, blob, "nerfart_sdf_fwd", true)) return rc;
     if (int rc = check_M(M)) return rc;
     if (M == 0) return 0;
     PointSrc s = make_src(pts, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, M);
     if (int rc = validate_src(s)) return rc;
+    if (precision == 5) return sdf_f16x1(blob, s, R_bg, sdf_out, 0, (hipStream_t)stream);
     if (precision == 4) return sdf_f16x2(blob, s, R_bg, sdf_out, 0, (hipStream_t)stream);
     if (precision == 1) return sdf_bf16(blob, s, R_bg, sdf_out, 0, (hipStream_t)stream);
     return launch_chain(0, M, k_sdf_only, (unsigned)((M + 127) / 128), (hipStream_t)stream, blob, s, R_bg, sdf_out, 0);
@@ -671,7 +679,8 @@ int nerfart_sdf_fwd_rays(const float* blob, int precision, const float* rays_o, 
     if (M == 0) return 0;
     PointSrc s = make_src(nullptr, nullptr, rays_o, rays_d, ray_idx, depth, n_per_ray, depth_stride, M);
     if (int rc = validate_src(s)) return rc;
-    if (int rc = check_precision(precision, false, blob, "nerfart_sdf_fwd_rays")) return rc;
+    if (int rc = check_precision(precision, false, blob, "nerfart_sdf_fwd_rays", true)) return rc;
+    if (precision == 5) return sdf_f16x1(blob, s, R_bg, sdf_out, out_stride, (hipStream_t)stream);
     if (precision == 4) return sdf_f16x2(blob, s, R_bg, sdf_out, out_stride, (hipStream_t)stream);
     if (precision == 1) return sdf_bf16(blob, s, R_bg, sdf_out, out_stride, (hipStream_t)stream);
     return launch_chain(0, M, k_sdf_only, (unsigned)((M + 127) / 128), (hipStream_t)stream, blob, s, R_bg, sdf_out, out_stride);

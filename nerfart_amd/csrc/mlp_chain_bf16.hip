@@ -70,6 +70,7 @@ k_sdf_only_bf16(const float* __restrict__ blob, PointSrc src, float R_bg, float*
     }
 }
 
+#ifndef NERFART_K2_ONLY        // mlp_chain_f16x1.hip instantiates K2 alone
 // =======================================================================================
 // K3a (split bf16): sdf + nabla + h7, forward mode; 32 points per workgroup tile (4 per wave, quads:
 // column 4i = value, 4i+1..3 = d/dx, d/dy, d/dz).
@@ -237,6 +238,7 @@ k_radiance_bf16(const float* __restrict__ blob, PointSrc src, const float* __res
     }
 }
 
+#endif  // NERFART_K2_ONLY
 
 }  // namespace b16
 }  // namespace nerfart
@@ -249,6 +251,7 @@ namespace nerfart {
 int sdf_bf16_v1(const float* blob, const PointSrc& s, float R_bg, float* out, int out_stride, hipStream_t st) {
     return b16::launch_chain(0, (long long)s.M, b16::k_sdf_only_bf16, (s.M + 127u) / 128u, st, blob, s, R_bg, out, out_stride);
 }
+#ifndef NERFART_K2_ONLY
 int sdf_nabla_bf16(const float* blob, const PointSrc& s, float R_bg, float* sdf, float* nabla, float* h7, hipStream_t st) {
     return b16::launch_chain(1, (long long)s.M, b16::k_sdf_nabla_bf16, (s.M + 31u) / 32u, st, blob, s, R_bg, sdf, nabla, h7);
 }
@@ -268,5 +271,6 @@ int radiance_fwd_dump_bf16(const float* blob, int view_tiles, const PointSrc& s,
     set_last_error("radiance_fwd_dump: view_tiles must be 1 or 3");
     return 2;
 }
+#endif  // NERFART_K2_ONLY
 
 }  // namespace nerfart

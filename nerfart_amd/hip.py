@@ -267,6 +267,10 @@ def profile_end():
 
 # ---- point queries -----------------------------------------------------------------------
 PRECISIONS = {"fp32": 0, "bf16x3": 1, "fp16x2": 4}      # 4: the 2-MFMA kernels: the sampler of the shipped "mixed" mode (nets.set_precision); everywhere: a measurement variant
+# Precisions that exist for Algorithm 1's no-gradient SDF queries ONLY (nerfart_sdf_fwd[_rays] and the sampler stage of the renderers refuse them
+# nowhere else): 5 = "fp16x1", one MFMA per product on the precision-4 blob (csrc/mlp_chain_f16x1.hip).
+SAMPLER_PRECISIONS = dict(PRECISIONS, fp16x1=5)
+PACK_PRECISION = {5: 4}                                  # C-ABI precision -> the precision whose blob it reads, where that is another one
 
 
 def sdf_fwd(surf_blob, pts, R_bg: float, precision: int = 0):

@@ -227,8 +227,8 @@ class _PackedModel(nn.Module):
         the rays whose convergence decision is marginal (max B within guard * eps of eps) or that never converge: those are sampled again at the
         model's precision.  guard None = DEFAULT_SAMPLER_GUARD (the shipped mode's), 0 = the unguarded measurement variant of round 5.
         precision None: the sampler uses the model's precision."""
-        if precision is not None and precision not in hip.PRECISIONS:
-            raise ValueError(f"precision must be one of {list(hip.PRECISIONS)} or None")
+        if precision is not None and precision not in hip.SAMPLER_PRECISIONS:
+            raise ValueError(f"precision must be one of {list(hip.SAMPLER_PRECISIONS)} or None")
         self.sampler_precision = precision
         self.sampler_guard = 0.0 if precision is None else (DEFAULT_SAMPLER_GUARD if guard is None else float(guard))
         self._sampler_blob = None
@@ -272,7 +272,8 @@ class _PackedModel(nn.Module):
         on the device).  nerfart_amd/packing.py keeps the same layout as numpy plans - the source of truth of the CPU emulation
         (tests/emul_chain.py) - and tests/test_pack_plan.py holds the library's closed-form layout equal to them, entry for entry."""
         g, v, b = self._surface_layers()
-        return hip.pack_surface_blob(hip.PRECISIONS[precision], self.implicit_surface.embed_multires, g, v, b)
+        pid = hip.SAMPLER_PRECISIONS[precision]
+        return hip.pack_surface_blob(hip.PACK_PRECISION.get(pid, pid), self.implicit_surface.embed_multires, g, v, b)
 
     def _pack_radiance(self, precision: str) -> torch.Tensor:
         last = self.implicit_surface.surface_fc_layers[self.implicit_surface.D]
@@ -289,7 +290,7 @@ class _PackedModel(nn.Module):
             with torch.no_grad():
                 blob = self._pack_surface(self.sampler_precision)
             self._sampler_blob = (key, blob)
-        return self._sampler_blob[1], hip.PRECISIONS[self.sampler_precision]
+        return self._sampler_blob[1], hip.SAMPLER_PRECISIONS[self.sampler_precision]
 
     @property
     def precision_id(self) -> int:

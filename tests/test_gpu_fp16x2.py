@@ -152,3 +152,45 @@ def test_finetune_step_with_the_fp16x2_sampler():
     for n, g in res[None][1].items():
         rel = float((res["fp16x2"][1][n] - g).norm() / (g.norm() + 1e-12))
         assert rel < 0.1, (n, rel)
+
+
+def test_fp16x1_sampler_only_precision():
+    """C-ABI precision 5 ("fp16x1", csrc/mlp_chain_f16x1.hip): K2 with ONE MFMA per product on the precision-4 blob - an opt-in arithmetic of Algorithm
+    1's no-gradient SDF queries, measured (profiles/r09_guard_sweep_fp16x1_8views.json: - 27 % of K2, - 11 % of a frame at guard 0.05) and NOT shipped
+    (one or two rays of 2,048 more than pure split-bf16 past 1e-3 on 2 of 8 views).  Held: close to the 2-MFMA kernel on the same blob (the
+    dropped term is 2^-12 of a product), refused everywhere a value that reaches a pixel is computed, and a guarded frame with it is a valid
+    rendering whose escalated rays are pure split-bf16's."""
+    from nerfart_amd import hip, scene, rend_util
+    model, rk, fn = scene.build_model("VolSDF", seed=0, beta=0.01, device=DEV, precision="bf16x3")
+    g, v, b = model._surface_layers()
+    blob4 = hip.pack_surface_blob(4, 6, g, v, b)
+    gen = torch.Generator().manual_seed(5)
+    x = ((torch.rand(1 << 16, 3, generator=gen) * 2 - 1) * 1.5).to(DEV)
+    s4 = hip.sdf_fwd(blob4, x, 3.0, precision=4)
+    s5 = hip.sdf_fwd(blob4, x, 3.0, precision=5)
+    s1 = hip.sdf_fwd(model.packed()[0], x, 3.0, precision=1)
+    e45, e51, e41 = (s5 - s4).abs(), (s5 - s1).abs(), (s4 - s1).abs()
+    print(f"  fp16x1 vs fp16x2: max {float(e45.max()):.2e} mean {float(e45.mean()):.2e}; vs bf16x3: fp16x1 {float(e51.max()):.2e} / {float(e51.mean()):.2e}, fp16x2 {float(e41.max()):.2e} / {float(e41.mean()):.2e}")
+    assert float(e45.max()) < 1.5e-3 and float(e45.mean()) < 1e-4 and float(e51.max()) < 2e-3 and float(e51.mean()) < 2e-4
+    with pytest.raises(hip.NerfartHipError, match="precision 5"):
+        hip.sdf_nabla_fwd(blob4, x[:256], 3.0, precision=5)
+    with pytest.raises(hip.NerfartHipError):
+        hip.sdf_fwd(model.packed()[0], x[:256], 3.0, precision=5)           # a split-bf16 blob: the library's encoding check
+    with pytest.raises(ValueError):
+        model.set_precision("fp16x1")
+    H, W = 96, 54
+    c2w, K = scene.camera(H, W)
+    o, d, _ = rend_util.get_rays(c2w[None].to(DEV), K[None].to(DEV), H, W)
+    kw = dict(require_nablas=True, calc_normal=True, detailed_output=True, **rk)
+    base, _, ex0 = fn(o, d, **kw)
+    model.set_sampler_precision("fp16x1", guard=0.05)
+    assert model.mode == "bf16x3+fp16x1 sampler (guard 0.05)"
+    model.render_stats = {}
+    rgb, _, ex = fn(o, d, **kw)
+    err = (rgb - base).abs().max(dim=-1).values[0]
+    same = (ex["iter_usage"] == ex0["iter_usage"])[0]
+    print(f"  bf16x3 + fp16x1 sampler (guard 0.05) vs bf16x3, {H * W} rays: {int((err > 1e-3).sum())} past 1e-3, max {float(err.max()):.2e}, identical rounds "
+          f"{float(same.float().mean()):.4f}, sampled twice {model.render_stats['escalated'] / model.render_stats['rays']:.3f}")
+    assert torch.isfinite(rgb).all() and float(err.max()) < 2e-2 and int((err > 1e-3).sum()) <= H * W // 100 and float(same.float().mean()) > 0.97
+    never = (ex["iter_usage"] < 0)[0]
+    assert torch.equal(rgb[0][never], base[0][never]), "a never-converged ray is sampled again at the model's precision: pure split-bf16's pixel"

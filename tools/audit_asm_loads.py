@@ -95,13 +95,13 @@ def audit_mfma(lines, kernel, need=12):
 
 def main():
     total, bad = 0, []
-    for src in ("mlp_chain_bf16.hip", "mlp_grad_bf16.hip", "mlp_backward_bf16.hip"):
+    for src in ("mlp_chain_bf16.hip", "mlp_grad_bf16.hip", "mlp_backward_bf16.hip", "mlp_chain_f16x1.hip"):
         with tempfile.TemporaryDirectory() as td:
             out = os.path.join(td, "k.s")
             subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-S", "--cuda-device-only",
                                    os.path.join(CSRC, src), "-o", out], stderr=subprocess.DEVNULL)
             text = open(out).read().split("\n")
-        starts = [i for i, l in enumerate(text) if re.match(r"^_ZN7nerfart3b16\w+:", l)]
+        starts = [i for i, l in enumerate(text) if re.match(r"^_ZN7nerfart(3b16|5f16x1)\w+:", l)]
         for a, b in zip(starts, starts[1:] + [len(text)]):
             name = text[a].rstrip(":")
             n, p = audit(text[a:b], name)
