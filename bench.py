@@ -375,7 +375,33 @@ def main():
                      "series stays comparable" if other == "bf16x3" else
                      "Algorithm 1's SDF queries at C-ABI precision 4, the 192 final samples (sdf, nabla, radiance, compositing) in "
                      "split-bf16: model.set_precision('mixed')")}
-        del m32, f32, m16, f16, mmx, fmx
+        # the 1-MFMA sampler (C-ABI precision 5, opt-in, NOT shipped: one or two rays of 2,048 more than pure split-bf16 past 1e-3 on 2 of 8 views,
+        # profiles/r09_guard_sweep_fp16x1_8views.json) at the guard where its statistics come closest to the shipped mode's - what 1 MFMA per product buys
+        mx1, _, fx1 = scene.build_model("VolSDF", seed=0, beta=args.beta, device=dev, precision="bf16x3")
+        mx1.set_sampler_precision("fp16x1", guard=0.05)
+        mx1.render_stats = {}
+        bx1, _, _ = fx1(o_, d_, require_nablas=True, calc_normal=True, detailed_output=False, **kw)
+        torch.cuda.synchronize()
+        hip.profile_begin()
+        t1 = time.perf_counter()
+        for oo_, dd_ in views32[:3]:
+            fx1(oo_, dd_, require_nablas=True, calc_normal=True, detailed_output=False, **kw)
+        torch.cuda.synchronize()
+        tx1 = (time.perf_counter() - t1) / 3
+        px1 = hip.profile_end()
+        k_ms, k_n, k_pts = px1["k_sdf_only"]
+        secondary["bf16x3_with_fp16x1_sampler_guard_0.05"] = {
+            "value": round(H * W / tx1, 1), "unit": "rays/s", "ms_per_step": round(tx1 * 1e3, 2), "steps": 3,
+            "rays_sampled_twice_frac": round(mx1.render_stats["escalated"] / max(mx1.render_stats["rays"], 1), 5),
+            "roofline_k_sdf_only": None if not k_n else {
+                "kernel": "f16x1::k_sdf_only_bf16", "mfma_per_product": 1,
+                "achieved": round(k_pts / k_n * F_SDF / (k_ms / k_n * 1e-3) / 1e12, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(k_pts / k_n * F_SDF / (k_ms / k_n * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4), "avg_launch_ms": round(k_ms / k_n, 4),
+                "launches": int(k_n)},
+            "what": "OPT-IN, not the headline: Algorithm 1's SDF queries on the 1-MFMA kernel (model.set_sampler_precision('fp16x1', guard=0.05); one fp16 "
+                    "activation term x one fp16 weight term), the 192 final samples in split-bf16; measured against the shipped mode's contract and short "
+                    "of it by one or two rays of 2,048 on 2 of 8 views (DESIGN.md 4.1e)"}
+        del m32, f32, m16, f16, mmx, fmx, mx1, fx1, bx1
         # the other single-GPU configurations of BASELINE.json: one warm-up frame, then N_SEC timed frames on N_SEC views of the orbit
         # (bench lines of their own: tools/bench_neus.py, tools/bench_train.py)
         N_SEC = 3

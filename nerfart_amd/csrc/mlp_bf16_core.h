@@ -978,7 +978,9 @@ __device__ __forceinline__ float surface_chain(float px, float py, float pz, int
 #pragma nounroll
     for (int L = 1; L < 7; ++L) {
         if (L == 4) {
-            encode_units(px, py, pz, g, dq, enc);
+            // K2 (MODE 0) has the registers to keep layer 0's encoding units alive until the skip layer (16 VGPRs, round 6: 2 sincosf + 4 angle
+            // doublings + 16 splits per lane per tile less, ~6 % of K2's VALU instructions, same bits); the tangent kernels recompute them
+            if constexpr (MODE != 0) encode_units(px, py, pz, g, dq, enc);
             layer<Cfg<MODE, MODE, 7, 2, true, false, false, false, AH>>(A, B, x0, enc, x0n, s, aux + L * 256, ec, gc);
         } else {
             layer<Cfg<MODE, MODE, 8, 0, true, false, false, false, AH>>(A, B, x0, none, x0n, s, aux + L * 256, ec, gc);

@@ -625,7 +625,7 @@ static int check_precision(int precision, bool allow_fwd_tangents = false, const
                        "stage of the renderers): no value that reaches a pixel is computed in it");
         return 2;
     }
-    if (precision == 5 || precision == 1 || precision == 4 || (allow_fwd_tangents && (precision == 2 || precision == 3)))
+    if (precision == 5 || precision == 0 || precision == 1 || precision == 4 || (allow_fwd_tangents && (precision == 2 || precision == 3)))
         return blob ? blob_term_check(blob, term_of_precision(precision), who) : 0;
     set_last_error("precision must be 0 (fp32-exact MFMA), 1 (split-bf16 'bf16x3' MFMA) or 4 (2-MFMA 'fp16x2', measurement variant)");
     return 2;
