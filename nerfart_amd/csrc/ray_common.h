@@ -5,7 +5,9 @@
 // different banks: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE fell from 86 / 73 / 52 % to 8 / 0 / 2 % in k_merge_check / k_first_check /
 // k_upsample (profiles/r02n_pmc_lds.txt) but the kernels' times did not move (1.27 -> 1.22 ms, 0.55 -> 0.54 ms: they wait on
 // dependent expf chains and binary searches, not on LDS bandwidth), and the regrouped prefix sums flipped a bisection branch of one
-// golden ray past the 1e-3 pixel bound in the split-bf16 mode.  A conflict-free layout has to keep the partition and pad addresses.)
+// golden ray past the 1e-3 pixel bound in the split-bf16 mode.  A conflict-free layout has to keep the partition and pad addresses.
+// Round 6: the conflicts were taken out of the loop that runs 11 times per ray instead - SegConsts below - with the same partition and the same bits:
+// k_merge_check 1.13 -> 1.07 ms per launch; the kernel waits on its exp / divide chains, as round 2 found.)
 #pragma once
 #include "nerfart_common.h"
 #include <math.h>
@@ -167,6 +169,73 @@ __device__ __forceinline__ float error_bound_scan_cached(const float* d, const f
             if (w_out) w_out[k] = b;
             mx = fmaxf(mx, b);
             R = __fmaf_rn(c_delta[i], c_sigma[i], R);
+        }
+    }
+    return wave_max(mx);
+}
+
+// The beta-INDEPENDENT part of a lane's intervals, held in registers across scans (round 6 b): k_merge_check scans the same merged
+// rows up to 11 times (the check at the net's beta + 10 bisection steps, volsdf.py:240-275) and only (alpha, beta) change in between - delta, s_k,
+// d*_k and delta^2 do not.  Loaded once per ray (the one stride-seg pass over the LDS rows that is left: lane l's addresses l * seg + i put up to 32
+// lanes on a bank), after which a scan touches no LDS at all.  scan_consts is error_bound_scan_cached with its first pass's loads and
+// beta-independent arithmetic hoisted: the same operations on the same values in the same order (delta * delta and 0.5 (|s_k| + |s_k+1| - delta)
+// are not contractable into their consumers), i.e. the same bits - tests/test_gpu_guarded_sampler.py::test_cached_scan_equals_generic_scan holds
+// whole frames equal to the generic form.
+template <int MAXSEG>
+struct SegConsts { float delta[MAXSEG], s[MAXSEG], dstar[MAXSEG], dd[MAXSEG]; int cnt; };
+
+template <int MAXSEG>
+__device__ __forceinline__ void load_seg_consts(const float* d, const float* s, int n, SegConsts<MAXSEG>& C) {
+    const int lane = threadIdx.x & 63;
+    const int nint = n - 1;
+    const int seg = (nint + 63) >> 6;
+    const int k0 = lane * seg;
+    const int k1 = (k0 + seg < nint) ? k0 + seg : nint;
+    C.cnt = k1 - k0;
+    float dk = 0.f, sk = 0.f;
+    if (k0 < k1) { dk = d[k0]; sk = s[k0]; }
+#pragma unroll
+    for (int i = 0; i < MAXSEG; ++i) {
+        C.delta[i] = 0.f; C.s[i] = 0.f; C.dstar[i] = 0.f; C.dd[i] = 0.f;
+        if (i < C.cnt) {
+            const float dn = d[k0 + i + 1], sn = s[k0 + i + 1];
+            const float delta = dn - dk;
+            C.delta[i] = delta;
+            C.s[i] = sk;
+            C.dstar[i] = fmaxf(0.5f * (fabsf(sk) + fabsf(sn) - delta), 0.f);
+            C.dd[i] = delta * delta;
+            dk = dn; sk = sn;
+        }
+    }
+}
+
+template <int MAXSEG>
+__device__ __forceinline__ float scan_consts(const SegConsts<MAXSEG>& C, float alpha, float beta) {
+    const float a4b = alpha / (4.f * beta);
+    float c_sigma[MAXSEG], c_t[MAXSEG], c_x[MAXSEG];
+    float sR = 0.f, sE = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXSEG; ++i) {
+        c_sigma[i] = 0.f; c_t[i] = 0.f; c_x[i] = 0.f;
+        if (i < C.cnt) {
+            const float sg = sdf_to_sigma(C.s[i], alpha, beta);
+            const float t = a4b * C.dd[i];
+            const float x = expf(-C.dstar[i] / beta);
+            c_sigma[i] = sg; c_t[i] = t; c_x[i] = x;
+            sR = __fmaf_rn(C.delta[i], sg, sR);
+            sE = __fmaf_rn(t, x, sE);
+        }
+    }
+    float R = wave_excl_sum(sR), E = wave_excl_sum(sE);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < MAXSEG; ++i) {
+        if (i < C.cnt) {
+            E = __fmaf_rn(c_t[i], c_x[i], E);
+            float b = expf(-R) * (expf(E) - 1.f);
+            if (isnan(b)) b = INFINITY;
+            mx = fmaxf(mx, b);
+            R = __fmaf_rn(C.delta[i], c_sigma[i], R);
         }
     }
     return wave_max(mx);

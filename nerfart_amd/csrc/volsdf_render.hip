@@ -114,6 +114,8 @@ k_upsample(SamplerParams P, const float* __restrict__ dA, const float* __restric
     error_bound_scan(d, s, n, 1.f / bp, bp, w, clamp_bounds != 0);
     __syncthreads();
     // pdf = (w + 1e-5) / sum; cdf = [0, cumsum(pdf)]   (rend_util.py:260-265)
+    // (round 6 b, measured and not kept: the bounds, the pdf and the running cdf of a lane's segment in registers instead of three passes over the LDS
+    // row w - 264 VGPRs at 16 intervals per lane, spills at 24: one wave per SIMD where this kernel, which waits on dependent binary-search reads, has two)
     const int lane = threadIdx.x;
     const int nint = n - 1, seg = (nint + 63) >> 6, k0 = lane * seg, k1 = (k0 + seg < nint) ? k0 + seg : nint;
     float part = 0.f;
@@ -128,6 +130,43 @@ k_upsample(SamplerParams P, const float* __restrict__ dA, const float* __restric
     for (int j = lane; j < P.n_up; j += 64) out[j] = invert_cdf_at(d, cdf, n, u_up[j + 1]);
     bitonic_sort(out, P.n_up);
     for (int j = lane; j < P.n_up; j += 64) d_new[(size_t)slot * P.n_up + j] = out[j];
+}
+
+// What k_merge_check does once the merged rows are in LDS: the bound check at the net's beta, then sampling (converged) or the bisection for beta+.
+// MAXSEG > 0: the lane's beta-independent interval constants are loaded once and every scan runs from registers (ray_common.h::SegConsts);
+// MAXSEG = 0: every scan through error_bound_scan (any row length; NERFART_SCAN_GENERIC builds this form everywhere).
+template <int MAXSEG>
+__device__ __forceinline__ void merge_check_tail(const SamplerParams& P, int ray, const float* d, const float* s, float* cdf, int nm,
+                                                 const float* __restrict__ u_final, float* __restrict__ d_fine, float* __restrict__ beta_plus,
+                                                 float* __restrict__ beta_map, float* __restrict__ iter_usage, int* __restrict__ act_out,
+                                                 int* __restrict__ act_count) {
+    constexpr int NS = MAXSEG > 0 ? MAXSEG : 1;
+    SegConsts<NS> C;
+    if constexpr (MAXSEG > 0) load_seg_consts<NS>(d, s, nm, C);
+    auto scan = [&](float alpha, float beta) -> float {
+        if constexpr (MAXSEG > 0) return scan_consts<NS>(C, alpha, beta);
+        else return error_bound_scan(d, s, nm, alpha, beta, nullptr, false);
+    };
+    const float mx = scan(P.alpha_net, P.beta_net);
+    if (in_guard_band(P, mx)) { escalate(P, ray); return; }
+    if (!(mx > P.eps)) {
+        // cdf = the two depth rows of the merge: dead by now, exactly n + nu = nm floats
+        opacity_cdf(d, s, nm, P.alpha_net, P.beta_net, cdf);
+        __syncthreads();
+        emit_final_samples(d, cdf, nm, u_final + (size_t)ray * P.u_final_stride, P.n_final, d_fine + (size_t)ray * P.n_final);
+        if (threadIdx.x == 0) { iter_usage[ray] = (float)P.it; beta_map[ray] = P.beta_net; }
+    } else {
+        float hi = beta_plus[ray], lo = P.beta_net;
+        for (int b = 0; b < P.max_bisect; ++b) {
+            const float mid = 0.5f * (lo + hi);
+            const float m = scan(1.f / mid, mid);
+            if (m <= P.eps) hi = mid; else lo = mid;
+        }
+        if (threadIdx.x == 0) {
+            beta_plus[ray] = hi;
+            act_out[atomicAdd(act_count, 1)] = ray;
+        }
+    }
 }
 
 // Merge the 512 new (depth, sdf) pairs into the ray's sorted sample set, re-check the bound at the
@@ -164,26 +203,13 @@ k_merge_check(SamplerParams P, const float* __restrict__ dA, const float* __rest
         dB[(size_t)ray * P.cap + i] = d[i];
         sB[(size_t)ray * P.cap + i] = s[i];
     }
-    const float mx = error_bound_scan(d, s, nm, P.alpha_net, P.beta_net, nullptr, false);
-    if (in_guard_band(P, mx)) { escalate(P, ray); return; }
-    if (!(mx > P.eps)) {
-        float* cdf = d_old;                      // the two depth rows are dead: exactly n + nu = nm floats
-        opacity_cdf(d, s, nm, P.alpha_net, P.beta_net, cdf);
-        __syncthreads();
-        emit_final_samples(d, cdf, nm, u_final + (size_t)ray * P.u_final_stride, P.n_final, d_fine + (size_t)ray * P.n_final);
-        if (threadIdx.x == 0) { iter_usage[ray] = (float)P.it; beta_map[ray] = P.beta_net; }
-    } else {
-        float hi = beta_plus[ray], lo = P.beta_net;
-        for (int b = 0; b < P.max_bisect; ++b) {
-            const float mid = 0.5f * (lo + hi);
-            const float m = error_bound_scan(d, s, nm, 1.f / mid, mid, nullptr, false);
-            if (m <= P.eps) hi = mid; else lo = mid;
-        }
-        if (threadIdx.x == 0) {
-            beta_plus[ray] = hi;
-            act_out[atomicAdd(act_count, 1)] = ray;
-        }
-    }
+#ifndef NERFART_SCAN_GENERIC
+    // rounds 1 and 2 (1,024 / 1,536 merged samples: every undecided ray of a frame / 78 % of them): the check and the 10 bisection scans from registers
+    const int seg = (nm - 1 + 63) >> 6;
+    if (seg <= 16) { merge_check_tail<16>(P, ray, d, s, d_old, nm, u_final, d_fine, beta_plus, beta_map, iter_usage, act_out, act_count); return; }
+    if (seg <= 24) { merge_check_tail<24>(P, ray, d, s, d_old, nm, u_final, d_fine, beta_plus, beta_map, iter_usage, act_out, act_count); return; }
+#endif
+    merge_check_tail<0>(P, ray, d, s, d_old, nm, u_final, d_fine, beta_plus, beta_map, iter_usage, act_out, act_count);
 }
 
 // Rays still active after the last round: sample with the last beta+ (volsdf.py:294-300).
