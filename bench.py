@@ -536,7 +536,11 @@ def main():
             # ONE fp16 activation term x fp16 hi + lo weight terms: 2 x v_mfma_f32_16x16x32_f16 per product (the dense fp16 peak = the bf16 one)
             roofline["mfma_per_product"] = 2
             roofline["mfma_executed_frac"] = round(2 * 2.0 * MFMA_MAC_SDF * (points / launches) / avg_s / 1e12 / peak, 4)
-            roofline["ceiling_frac"] = {"matrix_pipe_only": round(0.91 / 2, 4), "source": "profiles/r02s_ubench_coissue.txt (MFMA-only rate 0.91 of peak)"}
+            roofline["ceiling_frac"] = {"matrix_pipe_only": round(0.91 / 2, 4), "source": "profiles/r02s_ubench_coissue.txt (MFMA-only rate 0.91 of peak)",
+                                        "units": "ALGORITHMIC flops, i.e. comparable with `frac` (a stream of nothing but 2-MFMA products reaches 0.91 / 2); "
+                                                 "`mfma_executed_frac` (what the matrix pipe executes: 2 MFMAs per product + tile padding) compares with 0.91 "
+                                                 "(MFMAs alone) and with 0.56 - 0.58 (a synthetic stream of the 3-MFMA kernel's own instruction mix at the power "
+                                                 "cap, profiles/r03u_ubench_power.txt)"}
             roofline["note"] = ("the sampler's kernel: Algorithm 1's 512 (1 + rounds) SDF queries per ray, 69 % of a bf16x3 frame; frac = ALGORITHMIC flops "
                                 "(F_sdf per point) / launch time / 2,500 TFLOP/s, comparable across modes; the sustained rate is set by the package "
                                 "power cap (joules per product: profiles/r05n power probes), which is why 2 MFMAs per product buy time")
