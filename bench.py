@@ -143,6 +143,8 @@ def main():
     ap.add_argument("--shard", choices=["views", "tiles"], default="views",
                     help="N > 1: views = one view per rank per step (weak scaling, the primary line); tiles = one frame per step "
                          "sharded over the ranks in 2,048-ray tiles (strong scaling).  The other mode is reported as a secondary object.")
+    ap.add_argument("--no-calibrate", action="store_true", help="--precision mixed: render with the mode as get_model ships it (2-MFMA sampler), i.e. without the "
+                    "render.py line model.calibrate_sampler() (INTEGRATION.md section A); the default runs that line, as render.py does")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (fp32 mode, the other sharding mode)")
     ap.add_argument("--cpu-rays", type=int, default=2048)
@@ -196,6 +198,16 @@ def main():
     from nerfart_amd import scene, rend_util, hip, bench_util, dist as nd
 
     model, rk, render_fn = scene.build_model("VolSDF", seed=0, beta=args.beta, device=dev, precision=args.precision)
+    # the workload is render.py's (configs[1]): the weights are a checkpoint's and do not change - INTEGRATION.md section A's render.py calls
+    # model.calibrate_sampler() after load_state_dict (Algorithm 1's no-gradient SDF queries on the 1-MFMA kernel over error-compensated one-term weights,
+    # same guard; nerfart_amd/calibrate.py, ~2 s on the host, once per set of weights: timed here, outside the steps as any checkpoint loading is)
+    calibrated, t_cal = False, None
+    if args.precision == "mixed" and not args.no_calibrate:
+        torch.cuda.synchronize(); t_c0 = time.perf_counter()
+        model.calibrate_sampler()
+        model.packed_sampler()
+        torch.cuda.synchronize(); t_cal = time.perf_counter() - t_c0
+        calibrated = model.sampler_precision == "fp16x1c"
     # render_kwargs_test AS get_model BUILDS THEM, `rayschunk` = val_rayschunk (1024) included: every call below is
     # render_fn(rays_o, rays_d, ..., **render_kwargs_test), the reference's own call shape (render.py:527, train.py:189).  volsdf.launch_rays reads the
     # value as the memory hint it is (results are chunk-invariant bit for bit); `secondary.as_the_reference_calls_it` times render.py's 2048 too and
@@ -375,7 +387,21 @@ def main():
                      "series stays comparable" if other == "bf16x3" else
                      "Algorithm 1's SDF queries at C-ABI precision 4, the 192 final samples (sdf, nabla, radiance, compositing) in "
                      "split-bf16: model.set_precision('mixed')")}
-        # the 1-MFMA sampler (C-ABI precision 5, opt-in, NOT shipped: one or two rays of 2,048 more than pure split-bf16 past 1e-3 on 2 of 8 views,
+        if calibrated:
+            mgm, _, fgm = scene.build_model("VolSDF", seed=0, beta=args.beta, device=dev, precision="mixed")
+            fgm(o_, d_, require_nablas=True, calc_normal=True, detailed_output=False, **kw)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for oo_, dd_ in views32[:3]:
+                fgm(oo_, dd_, require_nablas=True, calc_normal=True, detailed_output=False, **kw)
+            torch.cuda.synchronize()
+            tgm = (time.perf_counter() - t1) / 3
+            secondary["mixed_as_get_model_ships"] = {
+                "value": round(H * W / tgm, 1), "unit": "rays/s", "ms_per_step": round(tgm * 1e3, 2), "steps": 3,
+                "what": "the mode exactly as frameworks.get_model returns it - 2-MFMA sampler (fp16 act x fp16 hi + lo weights), same guard - i.e. render.py WITHOUT "
+                        "the calibrate_sampler() line, and what pass 1 of a training step runs (its weights change every step)"}
+            del mgm, fgm
+        # the 1-MFMA sampler on NEAREST-rounded weights (C-ABI precision 5 without the calibration, opt-in, NOT shipped: one or two rays of 2,048 more than pure split-bf16 past 1e-3 on 2 of 8 views,
         # profiles/r09_guard_sweep_fp16x1_8views.json) at the guard where its statistics come closest to the shipped mode's - what 1 MFMA per product buys
         mx1, _, fx1 = scene.build_model("VolSDF", seed=0, beta=args.beta, device=dev, precision="bf16x3")
         mx1.set_sampler_precision("fp16x1", guard=0.05)
@@ -526,7 +552,7 @@ def main():
         # bf16x3 issues 3 bf16 MFMAs per algorithmic product: priced against the dense bf16 MFMA peak
         peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
         # (mixed: every k_sdf_only launch of a frame is Algorithm 1's - the 2-MFMA kernel, namespace f16x2; the final samples run k_sdf_grad_bf16)
-        kname = {"fp32": "k_sdf_only", "bf16x3": "k_sdf_only_bf16"}.get(args.precision, "f16x2::k_sdf_only_bf16")
+        kname = {"fp32": "k_sdf_only", "bf16x3": "k_sdf_only_bf16"}.get(args.precision, "f16x1::k_sdf_only_bf16" if calibrated else "f16x2::k_sdf_only_bf16")
         roofline = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
                     "launches": int(launches), "avg_launch_ms": round(ms / launches, 4),
@@ -534,16 +560,20 @@ def main():
                     "flops_per_point": F_SDF}
         if args.precision in ("mixed", "fp16x2"):
             # ONE fp16 activation term x fp16 hi + lo weight terms: 2 x v_mfma_f32_16x16x32_f16 per product (the dense fp16 peak = the bf16 one)
-            roofline["mfma_per_product"] = 2
-            roofline["mfma_executed_frac"] = round(2 * 2.0 * MFMA_MAC_SDF * (points / launches) / avg_s / 1e12 / peak, 4)
-            roofline["ceiling_frac"] = {"matrix_pipe_only": round(0.91 / 2, 4), "source": "profiles/r02s_ubench_coissue.txt (MFMA-only rate 0.91 of peak)",
-                                        "units": "ALGORITHMIC flops, i.e. comparable with `frac` (a stream of nothing but 2-MFMA products reaches 0.91 / 2); "
-                                                 "`mfma_executed_frac` (what the matrix pipe executes: 2 MFMAs per product + tile padding) compares with 0.91 "
+            mpp = 1 if calibrated else 2              # (the four k-steps of ready-made encoding units of K2's 59 run three terms in either form)
+            roofline["mfma_per_product"] = mpp
+            roofline["mfma_executed_frac"] = round(mpp * 2.0 * MFMA_MAC_SDF * (points / launches) / avg_s / 1e12 / peak, 4)
+            roofline["ceiling_frac"] = {"matrix_pipe_only": round(0.91 / mpp, 4), "source": "profiles/r02s_ubench_coissue.txt (MFMA-only rate 0.91 of peak)",
+                                        "units": "ALGORITHMIC flops, i.e. comparable with `frac` (a stream of nothing but mfma_per_product-MFMA products reaches 0.91 / mfma_per_product); "
+                                                 "`mfma_executed_frac` (what the matrix pipe executes: mfma_per_product MFMAs per product + tile padding) compares with 0.91 "
                                                  "(MFMAs alone) and with 0.56 - 0.58 (a synthetic stream of the 3-MFMA kernel's own instruction mix at the power "
                                                  "cap, profiles/r03u_ubench_power.txt)"}
             roofline["note"] = ("the sampler's kernel: Algorithm 1's 512 (1 + rounds) SDF queries per ray, 69 % of a bf16x3 frame; frac = ALGORITHMIC flops "
                                 "(F_sdf per point) / launch time / 2,500 TFLOP/s, comparable across modes; the sustained rate is set by the package "
-                                "power cap (joules per product: profiles/r05n power probes), which is why 2 MFMAs per product buy time")
+                                "power cap (joules per product: profiles/r05n power probes), which is why fewer MFMAs per product buy time" +
+                                ("; calibrated sampler: ONE v_mfma_f32_16x16x32_f16 per product over error-compensated one-term weights (csrc/mlp_chain_f16x1.hip, "
+                                 "nerfart_amd/calibrate.py) - with one MFMA per item the kernel is bound by its fragment reads, LDS-DMA pieces and epilogue VALU, not by "
+                                 "the matrix pipe (DESIGN.md 4.1e / 4.1f)" if calibrated else ""))
         if args.precision == "bf16x3":
             # what the matrix pipe executes: MFMA_MAC_SDF multiply-adds per point, each as `mfma_per_product` bf16 MFMAs
             # (hi.hi + hi.lo + lo.hi), as a fraction of the dense bf16 peak
@@ -727,7 +757,10 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong" if primary_tiles else "weak",
             "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (f32 split into 2 bf16 terms, f32 accumulate)",
                                            "mixed": "pixels bf16x3 (sdf, nabla, radiance, compositing of the 192 final samples: f32 split into 2 bf16 terms, 3 MFMAs per "
-                                                    "product, f32 accumulate), Algorithm-1 sampler fp16x2 (fp16 act x fp16 hi+lo weights, 2 MFMAs per product, f32 accumulate)",
+                                                    "product, f32 accumulate), Algorithm-1 sampler " +
+                                                    ("fp16x1 on error-compensated one-term weights (fp16 act x fp16 weight, 1 MFMA per product, f32 accumulate; "
+                                                     "model.calibrate_sampler())" if calibrated else "fp16x2 (fp16 act x fp16 hi+lo weights, 2 MFMAs per product, f32 accumulate)") +
+                                                    ", guarded: marginal decisions, never-converged rays and rays still active after round 3 re-sampled in bf16x3",
                                            "fp16x2": "fp16x2 (1 fp16 activation term x 2 fp16 weight terms, f32 accumulate) - EXPERIMENT, not the benchmark precision"}[args.precision], "data": "synthetic",
             "config": {"workload": ("configs[1]" if (H, W) == (480, 270) else "configs[4] frame size" if (H, W) == (960, 540) else "custom frame") +
                                    ": volsdf_fangzhou_nature.yaml dims, %dx%d rays/frame, 128 coarse + 64 fine " % (H, W) +
@@ -739,12 +772,21 @@ def main():
                        "rayschunk": "render_kwargs_test['rayschunk'] = val_rayschunk = %s is PASSED to render_fn, as the reference does (train.py:189, render.py:527); "
                                     "the library reads it as the memory hint it is and launches max(rayschunk, volsdf.DEFAULT_RAYSCHUNK = 131,072) rays "
                                     "(volsdf.launch_rays; results are bit-identical for any chunking: tests/test_gpu_configs.py)" % rk.get("rayschunk"),
+                       "sampler": None if args.precision != "mixed" else {
+                           "mode": model.mode, "precision": model.sampler_precision, "calibration_s": None if t_cal is None else round(t_cal, 2),
+                           "dropped_product_rms_nearest_to_compensated": None if not calibrated else
+                               {str(k): [float(f"{a:.2e}"), float(f"{b:.2e}")] for k, (a, b) in getattr(model, "calibration_stats", {}).items()},
+                           "what": "model.calibrate_sampler() - the line INTEGRATION.md section A adds to render.py after load_state_dict: Algorithm 1's SDF queries on the "
+                                   "1-MFMA kernel (C-ABI precision 5) over one-term fp16 weights whose rounding is error-compensated against this checkpoint's own "
+                                   "activations (once per set of weights; `calibration_s`, outside the timed steps like the checkpoint load); `--no-calibrate` / "
+                                   "secondary.mixed_as_get_model_ships: the mode as get_model returns it (2-MFMA sampler: what a training step runs)"},
                        "sampler_guard": None if not getattr(model, "sampler_guard", 0.0) else {
-                           "guard": model.sampler_guard, "rays_sampled_twice_frac": round(model.render_stats.get("escalated", 0) / max(model.render_stats.get("rays", 1), 1), 5),
+                           "guard": model.sampler_guard, "late_round": model.sampler_late_round, "rays_sampled_twice_frac": round(model.render_stats.get("escalated", 0) / max(model.render_stats.get("rays", 1), 1), 5),
                            "second_run_sdf_ms_per_step": round(prof["k_sdf_only_escalation"][0] / args.steps, 3),
                            "second_run_sdf_points_per_step": int(prof["k_sdf_only_escalation"][2] / args.steps),
-                           "what": "mixed mode: rays whose convergence decision in Algorithm 1 lies within guard * eps of eps, and rays that never converge, are "
-                                   "sampled again on the split-bf16 kernels (nerfart_volsdf_fine_sample_guarded); share over every render call of this run"},
+                           "what": "mixed mode: rays whose convergence decision in Algorithm 1 lies within guard * eps of eps, rays that never converge and rays still "
+                                   "active after up-sampling round `late_round` are sampled again on the split-bf16 kernels (nerfart_volsdf_fine_sample_guarded2); share "
+                                   "over every render call of this run"},
                        "samples_per_sec": round(value * (N_SAMPLES + N_IMPORTANCE), 1),
                        "iter_usage_hist": hist,
                        "algorithmic_tflop_per_frame": round(flops_frame / 1e12, 2),

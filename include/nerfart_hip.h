@@ -44,7 +44,9 @@
 extern "C" {
 #endif
 
-/* 4 (round 6).  History: 3 -> 4, additions only: the guarded sampler (nerfart_volsdf_fine_sample_guarded) and the per-stage-precision renderer
+/* 5 (round 6, second session).  History: 4 -> 5, additions only: nerfart_volsdf_fine_sample_guarded2 / nerfart_volsdf_render_staged2_fwd (the guarded sampler's
+ * `late_round`), C-ABI precision 5 on the SDF-only entry points.
+ * 3 -> 4, additions only: the guarded sampler (nerfart_volsdf_fine_sample_guarded) and the per-stage-precision renderer
  * (nerfart_volsdf_render_staged_fwd), nerfart_pack_layer_dims, nerfart_geometry_feature.
  * 2 -> 3, additions only (every version-2 entry point keeps its signature): the weight-blob packers
  * (nerfart_pack_surface_blob / nerfart_pack_radiance_blob + size queries; header word 10 of a split blob now names its fragment encoding),
@@ -187,6 +189,17 @@ int nerfart_volsdf_fine_sample_guarded(const float* surf_blob, int precision, co
                                        const float* u_final_dev, int u_final_per_ray, float* d_fine, float* beta_map,
                                        float* iter_usage, int* n_escalated, void* workspace, long long workspace_bytes, void* stream);
 
+/* (ABI 5) The same with a third escalation rule: late_round > 0 - a ray still active after up-sampling round `late_round` is escalated there (its remaining
+ * rounds would each start from a 10-step bisection for beta+, volsdf.py:266-275, whose threshold decisions feed the next round's sampling density: the
+ * branch-sensitive rays of Algorithm 1) instead of being carried through them on the cheap arithmetic.  late_round = 0: nerfart_volsdf_fine_sample_guarded. */
+int nerfart_volsdf_fine_sample_guarded2(const float* surf_blob, int precision, const float* esc_blob, int esc_precision, float guard, int late_round,
+                                        const float* rays_o, const float* rays_dn, int n_rays,
+                                        const float* near, const float* far, float near_s, float far_s, float R_bg,
+                                        float alpha_net, float beta_net, float eps, int n_init, int n_up, int n_final,
+                                        int max_iter, int max_bisect, const float* t_init_dev, const float* u_up_dev,
+                                        const float* u_final_dev, int u_final_per_ray, float* d_fine, float* beta_map,
+                                        float* iter_usage, int* n_escalated, void* workspace, long long workspace_bytes, void* stream);
+
 /* out[r] = sort(cat(a[r, :na], b[r, :nb]))  (volsdf.py:501-502) */
 int nerfart_sort_concat(int n_rays, const float* a, int na, int a_stride, const float* b, int nb, int b_stride,
                         float* out, int out_stride, void* stream);
@@ -247,6 +260,16 @@ int nerfart_volsdf_render_staged_fwd(const float* surf_blob, int precision, cons
                                      float* rgb, float* depth, float* acc, float* normals, float* d_all_out, float* sdf_out, float* nabla_out,
                                      float* radiance_out, float* sigma_out, float* p_out, float* tau_out, float* beta_map_out,
                                      float* iter_usage_out, int* n_escalated, void* workspace, long long workspace_bytes, void* stream);
+
+/* (ABI 5) nerfart_volsdf_render_staged_fwd with the sampler's late_round (nerfart_volsdf_fine_sample_guarded2); 0 = that function. */
+int nerfart_volsdf_render_staged2_fwd(const float* surf_blob, int precision, const float* rad_blob, int rad_precision, const float* sampler_blob,
+                                      int sampler_precision, float sampler_guard, int sampler_late_round, int view_tiles, const float* rays_o, const float* rays_d,
+                                      int n_rays, float near_s, float far_s, float R_bg, float alpha, float beta, float eps, int n_samples, int n_importance,
+                                      int max_upsample_steps, int max_bisection_steps, int white_bkgd, int k3_rays_chunk, const float* t_coarse_dev,
+                                      const float* t_init_dev, const float* u_up_dev, const float* u_final_dev, int u_final_per_ray,
+                                      float* rgb, float* depth, float* acc, float* normals, float* d_all_out, float* sdf_out, float* nabla_out,
+                                      float* radiance_out, float* sigma_out, float* p_out, float* tau_out, float* beta_map_out,
+                                      float* iter_usage_out, int* n_escalated, void* workspace, long long workspace_bytes, void* stream);
 
 /* ---- NeuS (models/frameworks/neus.py): up-sampling 'official_solution' :275-303 ('direct_use' / 'direct_more' :242-269 below), helpers :29-78,
  * volume_render :142-424; near_far_from_sphere utils/rend_util.py:168-186. */

@@ -103,5 +103,5 @@ static int profile_end_n(double* ms, long long* launches, long long* units, int 
 int nerfart_profile_end(double* ms, long long* launches, long long* units) { return profile_end_n(ms, launches, units, 4); }
 int nerfart_profile_end5(double* ms, long long* launches, long long* units) { return profile_end_n(ms, launches, units, 5); }
 const char* nerfart_last_error(void) { return nerfart::g_last_error.c_str(); }
-int nerfart_abi_version(void) { return 4; }
+int nerfart_abi_version(void) { return 5; }
 }

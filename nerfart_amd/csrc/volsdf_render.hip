@@ -532,8 +532,11 @@ long long nerfart_volsdf_sampler_workspace_bytes(int n_rays, int n_init, int n_u
 // arithmetic - but every ray whose outcome hangs on a marginal threshold decision is sampled AGAIN, from its first query on, on (esc_blob,
 // esc_precision):  (i) a ray whose max B lies within guard * eps of eps at a convergence check (volsdf.py:162-163, :240-242) stops there;
 // (ii) a ray still active after the last round (volsdf.py:294-300: sampled with its last bisected beta+, the rays any change of rounding moves).
+// (iii) late_round > 0 (ABI 5): a ray still active after round `late_round` - from there on every further round starts from a 10-step bisection for
+// beta+ whose threshold decisions (volsdf.py:266-275) feed the next round's sampling density: the branch-sensitive rays of Algorithm 1, 3.6 % of a
+// frame at late_round = 3 - is escalated there instead of being carried through the remaining rounds on the cheap arithmetic.
 // Rays are independent, so the escalated rays' samples are bit-identical to a run of the whole batch on esc_blob.
-static int fine_sample_run(const float* surf_blob, int precision, const float* esc_blob, int esc_precision, float guard,
+static int fine_sample_run(const float* surf_blob, int precision, const float* esc_blob, int esc_precision, float guard, int late_round,
                            const float* rays_o, const float* rays_dn, int n_rays,
                            const float* near, const float* far, float near_s, float far_s, float R_bg,
                            float alpha_net, float beta_net, float eps, int n_init, int n_up, int n_final,
@@ -600,6 +603,7 @@ static int fine_sample_run(const float* surf_blob, int precision, const float* e
         t = sA; sA = sB; sB = t;
         int* ti = act; act = act_next; act_next = ti;
         n += n_up;
+        if (guarded && late_round > 0 && it >= late_round) break;       // the rays still active go to the escalation list below
     }
     if (!guarded) {
         if (n_act > 0)
@@ -624,7 +628,7 @@ static int fine_sample_run(const float* surf_blob, int precision, const float* e
     const int* esc_list = w.esc_list;
     float *c_d_fine = w.c_d_fine, *c_beta = w.c_beta, *c_iter = w.c_iter;
     profile_class0_as(4);                     // launch profiling: the escalation run's SDF queries are their own class (nerfart_profile_end5)
-    const int rc_esc = fine_sample_run(esc_blob, esc_precision, nullptr, 0, 0.f, w.c_o, w.c_dn, n_esc, near ? w.c_near : nullptr, far ? w.c_far : nullptr,
+    const int rc_esc = fine_sample_run(esc_blob, esc_precision, nullptr, 0, 0.f, 0, w.c_o, w.c_dn, n_esc, near ? w.c_near : nullptr, far ? w.c_far : nullptr,
                                        near_s, far_s, R_bg, alpha_net, beta_net, eps, n_init, n_up, n_final, max_iter, max_bisect,
                                        own_tables ? nullptr : t_init_dev, own_tables ? nullptr : u_up_dev, u2, u_final_per_ray, c_d_fine, c_beta, c_iter,
                                        workspace, workspace_bytes, nullptr, stream);
@@ -642,9 +646,21 @@ int nerfart_volsdf_fine_sample(const float* surf_blob, int precision, const floa
                                int max_iter, int max_bisect, const float* t_init_dev, const float* u_up_dev,
                                const float* u_final_dev, int u_final_per_ray, float* d_fine, float* beta_map,
                                float* iter_usage, void* workspace, long long workspace_bytes, void* stream) {
-    return fine_sample_run(surf_blob, precision, nullptr, 0, 0.f, rays_o, rays_dn, n_rays, near, far, near_s, far_s, R_bg, alpha_net, beta_net, eps, n_init,
+    return fine_sample_run(surf_blob, precision, nullptr, 0, 0.f, 0, rays_o, rays_dn, n_rays, near, far, near_s, far_s, R_bg, alpha_net, beta_net, eps, n_init,
                            n_up, n_final, max_iter, max_bisect, t_init_dev, u_up_dev, u_final_dev, u_final_per_ray, d_fine, beta_map, iter_usage, workspace,
                            workspace_bytes, nullptr, (hipStream_t)stream);
+}
+
+int nerfart_volsdf_fine_sample_guarded2(const float* surf_blob, int precision, const float* esc_blob, int esc_precision, float guard, int late_round,
+                                       const float* rays_o, const float* rays_dn, int n_rays,
+                                       const float* near, const float* far, float near_s, float far_s, float R_bg,
+                                       float alpha_net, float beta_net, float eps, int n_init, int n_up, int n_final,
+                                       int max_iter, int max_bisect, const float* t_init_dev, const float* u_up_dev,
+                                       const float* u_final_dev, int u_final_per_ray, float* d_fine, float* beta_map,
+                                       float* iter_usage, int* n_escalated, void* workspace, long long workspace_bytes, void* stream) {
+    return fine_sample_run(surf_blob, precision, esc_blob, esc_precision, guard, late_round, rays_o, rays_dn, n_rays, near, far, near_s, far_s, R_bg, alpha_net, beta_net, eps,
+                           n_init, n_up, n_final, max_iter, max_bisect, t_init_dev, u_up_dev, u_final_dev, u_final_per_ray, d_fine, beta_map, iter_usage,
+                           workspace, workspace_bytes, n_escalated, (hipStream_t)stream);
 }
 
 int nerfart_volsdf_fine_sample_guarded(const float* surf_blob, int precision, const float* esc_blob, int esc_precision, float guard,
@@ -654,9 +670,9 @@ int nerfart_volsdf_fine_sample_guarded(const float* surf_blob, int precision, co
                                        int max_iter, int max_bisect, const float* t_init_dev, const float* u_up_dev,
                                        const float* u_final_dev, int u_final_per_ray, float* d_fine, float* beta_map,
                                        float* iter_usage, int* n_escalated, void* workspace, long long workspace_bytes, void* stream) {
-    return fine_sample_run(surf_blob, precision, esc_blob, esc_precision, guard, rays_o, rays_dn, n_rays, near, far, near_s, far_s, R_bg, alpha_net, beta_net, eps,
-                           n_init, n_up, n_final, max_iter, max_bisect, t_init_dev, u_up_dev, u_final_dev, u_final_per_ray, d_fine, beta_map, iter_usage,
-                           workspace, workspace_bytes, n_escalated, (hipStream_t)stream);
+    return nerfart_volsdf_fine_sample_guarded2(surf_blob, precision, esc_blob, esc_precision, guard, 0, rays_o, rays_dn, n_rays, near, far, near_s, far_s, R_bg,
+                                               alpha_net, beta_net, eps, n_init, n_up, n_final, max_iter, max_bisect, t_init_dev, u_up_dev, u_final_dev,
+                                               u_final_per_ray, d_fine, beta_map, iter_usage, n_escalated, workspace, workspace_bytes, stream);
 }
 
 // ---- whole-chunk VolSDF render (boundary B1: render_fn / volume_render, volsdf.py:389-615) ----
@@ -710,8 +726,8 @@ long long nerfart_volsdf_render_workspace_bytes(int n_rays, int n_samples, int n
 //   surf_blob / precision: sdf + nabla of the 192 final samples;   rad_blob / rad_precision: the radiance net there;   compositing: fp32.
 // nerfart_volsdf_render_mixed_fwd = this with rad_precision = precision and the guard off; nerfart_volsdf_render_fwd passes the same blob and
 // precision everywhere.
-int nerfart_volsdf_render_staged_fwd(const float* surf_blob, int precision, const float* rad_blob, int rad_precision, const float* sampler_blob,
-                                     int sampler_precision, float sampler_guard, int view_tiles, const float* rays_o,
+int nerfart_volsdf_render_staged2_fwd(const float* surf_blob, int precision, const float* rad_blob, int rad_precision, const float* sampler_blob,
+                                     int sampler_precision, float sampler_guard, int sampler_late_round, int view_tiles, const float* rays_o,
                               const float* rays_d, int n_rays, float near_s, float far_s, float R_bg, float alpha,
                               float beta, float eps, int n_samples, int n_importance, int max_upsample_steps,
                               int max_bisection_steps, int white_bkgd, int k3_rays_chunk, const float* t_coarse_dev,
@@ -736,7 +752,7 @@ int nerfart_volsdf_render_staged_fwd(const float* surf_blob, int precision, cons
 
     if (int rc = nerfart_normalize_dirs(rays_d, w.rays_dn, n_rays, stream)) return rc;
     const bool guarded = sampler_guard > 0.f && (sampler_blob != surf_blob || sampler_precision != precision);
-    if (int rc = fine_sample_run(sampler_blob, sampler_precision, guarded ? surf_blob : nullptr, precision, sampler_guard, rays_o, w.rays_dn, n_rays,
+    if (int rc = fine_sample_run(sampler_blob, sampler_precision, guarded ? surf_blob : nullptr, precision, sampler_guard, sampler_late_round, rays_o, w.rays_dn, n_rays,
                                  nullptr, nullptr, near_s, far_s, R_bg, alpha, beta, eps, 4 * n_samples, 4 * n_samples, n_importance,
                                  max_upsample_steps, max_bisection_steps, t_init_dev, u_up_dev, u_final_dev,
                                  u_final_per_ray, w.d_fine, beta_map, iter_usage, w.sampler, (long long)w.sampler_bytes, n_escalated, stream)) return rc;
@@ -763,6 +779,22 @@ int nerfart_volsdf_render_staged_fwd(const float* surf_blob, int precision, cons
     }
     return nerfart_volsdf_composite(n_rays, P, d_all, sdf, rad, nabla, alpha, beta, white_bkgd, rgb, depth, acc, normals,
                                     sigma_out, p_out, tau_out, stream);
+}
+
+int nerfart_volsdf_render_staged_fwd(const float* surf_blob, int precision, const float* rad_blob, int rad_precision, const float* sampler_blob,
+                                     int sampler_precision, float sampler_guard, int view_tiles, const float* rays_o,
+                              const float* rays_d, int n_rays, float near_s, float far_s, float R_bg, float alpha,
+                              float beta, float eps, int n_samples, int n_importance, int max_upsample_steps,
+                              int max_bisection_steps, int white_bkgd, int k3_rays_chunk, const float* t_coarse_dev,
+                              const float* t_init_dev, const float* u_up_dev, const float* u_final_dev, int u_final_per_ray,
+                              float* rgb, float* depth, float* acc, float* normals, float* d_all_out, float* sdf_out, float* nabla_out,
+                              float* radiance_out, float* sigma_out, float* p_out, float* tau_out, float* beta_map_out,
+                              float* iter_usage_out, int* n_escalated, void* workspace, long long workspace_bytes, void* stream_) {
+    return nerfart_volsdf_render_staged2_fwd(surf_blob, precision, rad_blob, rad_precision, sampler_blob, sampler_precision, sampler_guard, 0, view_tiles, rays_o,
+                                             rays_d, n_rays, near_s, far_s, R_bg, alpha, beta, eps, n_samples, n_importance, max_upsample_steps,
+                                             max_bisection_steps, white_bkgd, k3_rays_chunk, t_coarse_dev, t_init_dev, u_up_dev, u_final_dev, u_final_per_ray,
+                                             rgb, depth, acc, normals, d_all_out, sdf_out, nabla_out, radiance_out, sigma_out, p_out, tau_out, beta_map_out,
+                                             iter_usage_out, n_escalated, workspace, workspace_bytes, stream_);
 }
 
 int nerfart_volsdf_render_mixed_fwd(const float* surf_blob, const float* rad_blob, int precision, const float* sampler_blob, int sampler_precision,

@@ -68,6 +68,7 @@ _SIGS = {
     "nerfart_volsdf_sampler_workspace_bytes": (_ll, [_i, _i, _i, _i, _i]),
     "nerfart_volsdf_fine_sample": (_i, [_p, _i, _p, _p, _i, _p, _p, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _ll, _p]),
     "nerfart_volsdf_fine_sample_guarded": (_i, [_p, _i, _p, _i, _f, _p, _p, _i, _p, _p, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _ll, _p]),
+    "nerfart_volsdf_fine_sample_guarded2": (_i, [_p, _i, _p, _i, _f, _i, _p, _p, _i, _p, _p, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _ll, _p]),
     "nerfart_sort_concat": (_i, [_i, _p, _i, _i, _p, _i, _i, _p, _i, _p]),
     "nerfart_volsdf_composite": (_i, [_i, _i, _p, _p, _p, _p, _f, _f, _i] + [_p] * 8),
     "nerfart_volsdf_composite_bwd": (_i, [_i, _i, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p, _p]),
@@ -83,6 +84,7 @@ _SIGS = {
     "nerfart_volsdf_render_fwd": (_i, [_p, _p, _i, _i, _p, _p, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i] + [_p] * 4 + [_i] + [_p] * 13 + [_p, _ll, _p]),
     "nerfart_volsdf_render_mixed_fwd": (_i, [_p, _p, _i, _p, _i, _i, _p, _p, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i] + [_p] * 4 + [_i] + [_p] * 13 + [_p, _ll, _p]),
     "nerfart_volsdf_render_staged_fwd": (_i, [_p, _i, _p, _i, _p, _i, _f, _i, _p, _p, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i] + [_p] * 4 + [_i] + [_p] * 13 + [_p, _p, _ll, _p]),
+    "nerfart_volsdf_render_staged2_fwd": (_i, [_p, _i, _p, _i, _p, _i, _f, _i, _i, _p, _p, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i] + [_p] * 4 + [_i] + [_p] * 13 + [_p, _p, _ll, _p]),
     "nerfart_near_far_from_sphere": (_i, [_p, _p, _i, _f, _p, _p, _p]),
     "nerfart_neus_upsample_step": (_i, [_i, _i, _i, _i, _f, _p, _p, _p, _i, _p, _p]),
     "nerfart_merge_sorted_pairs": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p]),
@@ -269,7 +271,7 @@ def profile_end():
 PRECISIONS = {"fp32": 0, "bf16x3": 1, "fp16x2": 4}      # 4: the 2-MFMA kernels: the sampler of the shipped "mixed" mode (nets.set_precision); everywhere: a measurement variant
 # Precisions that exist for Algorithm 1's no-gradient SDF queries ONLY (nerfart_sdf_fwd[_rays] and the sampler stage of the renderers refuse them
 # nowhere else): 5 = "fp16x1", one MFMA per product on the precision-4 blob (csrc/mlp_chain_f16x1.hip).
-SAMPLER_PRECISIONS = dict(PRECISIONS, fp16x1=5)
+SAMPLER_PRECISIONS = dict(PRECISIONS, fp16x1=5, fp16x1c=5)     # fp16x1c: the same kernel on error-compensated one-term weights (nerfart_amd/calibrate.py)
 PACK_PRECISION = {5: 4}                                  # C-ABI precision -> the precision whose blob it reads, where that is another one
 
 
@@ -453,11 +455,12 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 def volsdf_fine_sample(surf_blob, rays_o, rays_dn, near: float, far: float, R_bg: float, alpha: float, beta: float,
                        eps: float, n_init: int, n_up: int, n_final: int, max_iter: int, max_bisect: int, precision: int = 0,
-                       u_final=None, escalate=None, guard: float = 0.0, stats=None):
+                       u_final=None, escalate=None, guard: float = 0.0, stats=None, late_round: int = 0):
     """u_final [R, n_final]: the caller's uniform random numbers for the final inverse-CDF samples (perturb=True:
     sample_cdf(det=False), rend_util.py:306-307); None: the deterministic linspace table.
     escalate = (surface blob, precision id) + guard > 0: the GUARDED sampler (nerfart_volsdf_fine_sample_guarded): rays whose convergence decision
-    lies within guard * eps of eps, and rays that never converge, are sampled again on that blob.  stats (dict): 'escalated' += rays that ran twice."""
+    lies within guard * eps of eps, and rays that never converge, are sampled again on that blob.  stats (dict): 'escalated' += rays that ran twice.
+    late_round > 0 (with the guard): rays still active after that up-sampling round are escalated there (nerfart_volsdf_fine_sample_guarded2)."""
     R = rays_o.shape[0]
     dev = rays_o.device
     if u_final is not None and tuple(u_final.shape) != (R, n_final):
@@ -469,13 +472,13 @@ def volsdf_fine_sample(surf_blob, rays_o, rays_dn, near: float, far: float, R_bg
     ws = _workspace(nb, dev)
     esc_blob, esc_prec = escalate if (escalate is not None and guard > 0) else (None, 0)
     n_esc = C.c_int(0)
-    _check(lib.nerfart_volsdf_fine_sample_guarded(_dev(surf_blob), int(precision), _dev(esc_blob, name="esc_blob"), int(esc_prec), float(guard),
+    _check(lib.nerfart_volsdf_fine_sample_guarded2(_dev(surf_blob), int(precision), _dev(esc_blob, name="esc_blob"), int(esc_prec), float(guard), int(late_round),
                                                   _dev(rays_o), _dev(rays_dn), R, None, None, float(near), float(far),
                                                   float(R_bg), float(alpha), float(beta), float(eps), n_init, n_up, n_final, max_iter,
                                                   max_bisect, _dev(lin_table(n_init, dev)), _dev(lin_table(n_up + 2, dev)),
                                                   _dev(lin_table(n_final, dev) if u_final is None else u_final, name="u_final"),
                                                   int(u_final is not None), _dev(d_fine), _dev(beta_map), _dev(usage), C.byref(n_esc), ws.data_ptr(),
-                                                  ws.numel(), _stream()), "nerfart_volsdf_fine_sample_guarded")
+                                                  ws.numel(), _stream()), "nerfart_volsdf_fine_sample_guarded2")
     if stats is not None:
         stats["escalated"] = stats.get("escalated", 0) + n_esc.value
         stats["rays"] = stats.get("rays", 0) + R
@@ -667,8 +670,8 @@ def weight_norm_bwd(dW, weight_v, weight_g):
 def volsdf_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, near, far, R_bg, alpha, beta, eps=0.1,
                   n_samples=128, n_importance=64, max_upsample_steps=5, max_bisection_steps=10, white_bkgd=False,
                   calc_normal=True, detailed=False, k3_rays_chunk=8192, precision=0, u_final=None, sampler=None, guard: float = 0.0,
-                  radiance=None, stats=None):
-    """One chunk of rays through nerfart_volsdf_render_staged_fwd.  Returns a dict of flat [R, ...] tensors.
+                  radiance=None, stats=None, late_round: int = 0):
+    """One chunk of rays through nerfart_volsdf_render_staged2_fwd (late_round: the guarded sampler's third rule, hip.volsdf_fine_sample).  Returns a dict of flat [R, ...] tensors.
     u_final [R, n_importance]: uniform random numbers of the final samples (perturb=True); None: deterministic.
     sampler = (surface blob, precision id): Algorithm 1 on its own blob / precision; None: the model's.  guard > 0: the guarded sampler (marginal
     and never-converged rays sampled again on (surf_blob, precision)).  radiance = (radiance blob, precision id): the radiance net of the final
@@ -692,9 +695,9 @@ def volsdf_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, near, far,
     samp_blob, samp_prec = sampler if sampler is not None else (surf_blob, precision)
     rblob, rprec = radiance if radiance is not None else (rad_blob, precision)
     n_esc = C.c_int(0)
-    _check(lib.nerfart_volsdf_render_staged_fwd(
+    _check(lib.nerfart_volsdf_render_staged2_fwd(
         _dev(surf_blob), int(precision), _dev(rblob, name="rad_blob"), int(rprec), _dev(samp_blob, name="sampler_blob"), int(samp_prec), float(guard),
-        int(view_tiles), _dev(rays_o, name="rays_o"), _dev(rays_d, name="rays_d"), R,
+        int(late_round), int(view_tiles), _dev(rays_o, name="rays_o"), _dev(rays_d, name="rays_d"), R,
         float(near), float(far), float(R_bg), float(alpha), float(beta), float(eps), n_samples, n_importance,
         max_upsample_steps, max_bisection_steps, int(bool(white_bkgd)), k3_rays_chunk,
         _dev(lin_table(n_samples, dev)), _dev(lin_table(4 * n_samples, dev)), _dev(lin_table(4 * n_samples + 2, dev)),
@@ -702,7 +705,7 @@ def volsdf_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, near, far,
         _dev(out["rgb"]), _dev(out["depth_volume"]), _dev(out["mask_volume"]), _dev(out.get("normals_volume")),
         g("d_vals"), g("implicit_surface"), g("implicit_nablas"), g("radiance"), g("sigma"), g("p_i"),
         g("visibility_weights"), g("beta_map"), g("iter_usage"), C.byref(n_esc), ws.data_ptr(), ws.numel(), _stream()),
-        "nerfart_volsdf_render_staged_fwd")
+        "nerfart_volsdf_render_staged2_fwd")
     if stats is not None:
         stats["escalated"] = stats.get("escalated", 0) + n_esc.value
         stats["rays"] = stats.get("rays", 0) + R
@@ -712,7 +715,7 @@ def volsdf_render(surf_blob, rad_blob, view_tiles, rays_o, rays_d, *, near, far,
 
 def volsdf_render_mixed(surf_blob, rad_blob, sampler_blob, sampler_precision: int, view_tiles, rays_o, rays_d, *, near, far, R_bg, alpha, beta, eps=0.1,
                         n_samples=128, n_importance=64, max_upsample_steps=5, max_bisection_steps=10, white_bkgd=False, calc_normal=True,
-                        detailed=False, k3_rays_chunk=8192, precision=1, u_final=None, guard: float = 0.0):
+                        detailed=False, k3_rays_chunk=8192, precision=1, u_final=None, guard: float = 0.0, late_round: int = 0):
     """volsdf_render(..., sampler=(sampler_blob, sampler_precision), guard=guard) restated on the PER-STAGE entry points, in the fused renderer's own order
     (tests: the two must agree bit for bit, every output): the SAMPLER (Algorithm 1: 512 (1 + rounds) SDF queries per ray, no gradient,
     volsdf.py:479) on another blob / precision than the 192 final samples.  The final samples -
@@ -725,7 +728,7 @@ def volsdf_render_mixed(surf_blob, rad_blob, sampler_blob, sampler_precision: in
     dn = normalize_dirs(rays_d)
     d_fine, beta_map, usage = volsdf_fine_sample(sampler_blob, rays_o, dn, near, far, R_bg, alpha, beta, eps, 4 * n_samples, 4 * n_samples, n_importance,
                                                  max_upsample_steps, max_bisection_steps, precision=sampler_precision, u_final=u_final,
-                                                 escalate=(surf_blob, precision), guard=guard)
+                                                 escalate=(surf_blob, precision), guard=guard, late_round=late_round)
     d_coarse = f(R, n_samples)
     _check(lib.nerfart_linspace_depths(_dev(lin_table(n_samples, dev)), n_samples, None, None, float(near), float(far), R, _dev(d_coarse), n_samples,
                                        _stream()), "nerfart_linspace_depths")

@@ -26,6 +26,12 @@ from . import hip
 # CPU oracle on all 8 measured views (profiles/r08_guard_sweep*.json, tools/guard_sweep.py: rays past 1e-3 <= bf16x3's + 1 per view, identical counts
 # among the oracle-converged rays; 1.5 - 2.3 % of the rays run twice, + 2 % of a frame); the never-converged rays carry most of it (guard -> 0: 1.1 %).
 DEFAULT_SAMPLER_GUARD = 0.005
+# Third rule of the guarded sampler (nerfart_volsdf_fine_sample_guarded2, second session of round 6): a ray still active after up-sampling round 3 is sampled again on
+# the split-bf16 kernels too.  From round 4 on every round starts from a 10-step bisection for beta+ whose threshold decisions feed the next round's sampling
+# density - the branch-sensitive 3.6 % of a frame, and every converged ray any cheap sampler moved past 5e-4 on the 8 measured views.  With it the mode's
+# frame differs from the pure split-bf16 frame on 0 - 2 of 129,600 rays by more than 1e-3 (37 - 66 without it) and reproduces its outlier counts against the
+# CPU oracle on all 8 views exactly (profiles/r10_guard_sweep_*); + 5 ms per frame on the 2-MFMA sampler.
+DEFAULT_SAMPLER_LATE_ROUND = 3
 
 
 def embed_dim(multires: int, c: int = 3) -> int:
@@ -162,6 +168,7 @@ class _PackedModel(nn.Module):
         self.precision = "fp32"
         self.sampler_precision = None
         self.sampler_guard = 0.0
+        self.sampler_late_round = 0
         self._sampler_blob = None
         self.radiance_precision = None
         self._radiance_blob = None
@@ -199,10 +206,12 @@ class _PackedModel(nn.Module):
             self.precision = "bf16x3"
             self.sampler_precision = "fp16x2" if hasattr(self, "ln_beta") else None
             self.sampler_guard = DEFAULT_SAMPLER_GUARD if hasattr(self, "ln_beta") else 0.0
+            self.sampler_late_round = DEFAULT_SAMPLER_LATE_ROUND if hasattr(self, "ln_beta") else 0
         elif precision in hip.PRECISIONS:
             self.precision = precision
             self.sampler_precision = None
             self.sampler_guard = 0.0
+            self.sampler_late_round = 0
         else:
             raise ValueError(f"precision must be one of {list(hip.PRECISIONS) + ['mixed']}")
         self._blobs = None
@@ -216,11 +225,26 @@ class _PackedModel(nn.Module):
         """'mixed' | 'fp32' | 'bf16x3' | 'fp16x2' | 'bf16x3+<sampler precision> sampler'."""
         if self.sampler_precision is None or self.sampler_precision == self.precision:
             return self.precision
-        if (self.precision, self.sampler_precision) == ("bf16x3", "fp16x2") and self.sampler_guard > 0:
+        if (self.precision, self.sampler_precision) == ("bf16x3", "fp16x2") and self.sampler_guard > 0 and self.sampler_late_round == DEFAULT_SAMPLER_LATE_ROUND:
             return "mixed"
-        return f"{self.precision}+{self.sampler_precision} sampler" + (f" (guard {self.sampler_guard:g})" if self.sampler_guard > 0 else " (unguarded)")
+        if (self.precision, self.sampler_precision) == ("bf16x3", "fp16x1c") and self.sampler_guard > 0 and self.sampler_late_round == DEFAULT_SAMPLER_LATE_ROUND:
+            return "mixed (calibrated sampler)"
+        late = f", late round {self.sampler_late_round}" if self.sampler_late_round > 0 else ""
+        return f"{self.precision}+{self.sampler_precision} sampler" + (f" (guard {self.sampler_guard:g}{late})" if self.sampler_guard > 0 else " (unguarded)")
 
-    def set_sampler_precision(self, precision, guard: float = None):
+    def calibrate_sampler(self):
+        """VolSDF, weights that are not about to change (rendering: the one line INTEGRATION.md section A adds to render.py after load_state_dict): Algorithm 1's
+        SDF queries on ONE matrix instruction per product (C-ABI precision 5) over one-term fp16 weights that are error-compensated against this model's own
+        activations (nerfart_amd/calibrate.py: ~2 s on the host, once per set of weights, cached by parameter version), behind the same guard as `mixed`
+        (marginal decisions, never-converged rays and rays still active after round 3 sampled again in split-bf16).  - 15 % of a frame against `mixed` with
+        the statistics of pure split-bf16 on all 8 measured views.  Training keeps `mixed`'s hi + lo sampler: a Trainer switches back."""
+        if not hasattr(self, "ln_beta"):
+            return self                                 # NeuS has no such sampler
+        if self.precision != "bf16x3":
+            raise RuntimeError("calibrate_sampler() is the shipped `mixed` mode's rendering form: set_precision('mixed') first")
+        return self.set_sampler_precision("fp16x1c", guard=DEFAULT_SAMPLER_GUARD, late_round=DEFAULT_SAMPLER_LATE_ROUND)
+
+    def set_sampler_precision(self, precision, guard: float = None, late_round: int = 0):
         """VolSDF only: run Algorithm 1's SDF queries (512 (1 + rounds) per ray, no gradient, volsdf.py:479) at another precision than the 192 final
         samples - e.g. model.set_precision("bf16x3").set_sampler_precision("fp16x2") (= set_precision("mixed")): every number that reaches
         a pixel is computed in split-bf16, only WHERE the fine samples sit comes from the 2-MFMA kernels - and, with guard > 0, not even that for
@@ -231,6 +255,7 @@ class _PackedModel(nn.Module):
             raise ValueError(f"precision must be one of {list(hip.SAMPLER_PRECISIONS)} or None")
         self.sampler_precision = precision
         self.sampler_guard = 0.0 if precision is None else (DEFAULT_SAMPLER_GUARD if guard is None else float(guard))
+        self.sampler_late_round = 0 if precision is None else int(late_round)      # > 0: rays still active after that round are escalated too
         self._sampler_blob = None
         return self
 
@@ -260,8 +285,8 @@ class _PackedModel(nn.Module):
         surf_blob, _ = self.packed()
         samp = self.packed_sampler()
         if samp is None:
-            return dict(blob=surf_blob, precision=self.precision_id, escalate=None, guard=0.0)
-        return dict(blob=samp[0], precision=samp[1], escalate=(surf_blob, self.precision_id), guard=self.sampler_guard)
+            return dict(blob=surf_blob, precision=self.precision_id, escalate=None, guard=0.0, late_round=0)
+        return dict(blob=samp[0], precision=samp[1], escalate=(surf_blob, self.precision_id), guard=self.sampler_guard, late_round=self.sampler_late_round)
 
     def _surface_layers(self):
         L = list(self.implicit_surface.surface_fc_layers)
@@ -271,7 +296,11 @@ class _PackedModel(nn.Module):
         """The SDF net's blob at `precision` through the C ABI (nerfart_pack_surface_blob: weight_norm fold, unit-order permutation, hi / lo split
         on the device).  nerfart_amd/packing.py keeps the same layout as numpy plans - the source of truth of the CPU emulation
         (tests/emul_chain.py) - and tests/test_pack_plan.py holds the library's closed-form layout equal to them, entry for entry."""
-        g, v, b = self._surface_layers()
+        if precision == "fp16x1c":          # one-term fp16 weights, error-compensated against this model's own activations (pack-time calibration)
+            from . import calibrate
+            g, v, b, self.calibration_stats = calibrate.compensated_surface_layers(self)
+        else:
+            g, v, b = self._surface_layers()
         pid = hip.SAMPLER_PRECISIONS[precision]
         return hip.pack_surface_blob(hip.PACK_PRECISION.get(pid, pid), self.implicit_surface.embed_multires, g, v, b)
 

@@ -116,6 +116,16 @@ class Trainer(nn.Module):
             self.style_loss = criteria.build_style_loss(args, hw, device=next(self.model.parameters()).device)
         return getattr(self, "style_loss", None)
 
+    def _training_sampler(self):
+        """A model whose sampler was calibrated for rendering (nets.calibrate_sampler: one-term weights error-compensated against ONE set of weights,
+        ~2 s on the host) goes back to `mixed`'s hi + lo sampler before a step renders anything: the weights change every step."""
+        m = self.model
+        if getattr(m, "sampler_precision", None) == "fp16x1c":
+            import warnings
+            warnings.warn("Trainer: the model's sampler was calibrated for rendering (calibrate_sampler()); training uses the `mixed` mode's hi + lo "
+                          "sampler - call calibrate_sampler() again before rendering with the trained weights")
+            m.set_sampler_precision("fp16x2", guard=m.sampler_guard, late_round=m.sampler_late_round)
+
     def resamples(self, render_kwargs) -> bool:
         """Does pass 2 of a fine-tune step with these render kwargs run the sampler again (module docstring)?"""
         if self.reuse_pass1_samples:
@@ -149,6 +159,7 @@ class Trainer(nn.Module):
     def render_image(self, render_fn, rays_o, rays_d, want_depths: bool = False, **render_kwargs):
         """Pass 1 on the fused renderer.  want_depths: also return the sample depths [N, P] of every ray (with perturb=False and
         unchanged weights pass 2 would re-derive exactly these - it can reuse them)."""
+        self._training_sampler()
         kw = dict(render_kwargs)
         kw.pop("rayschunk", None)
         if kw.get("perturb", False) and self.uniform_source is not None:
@@ -182,7 +193,7 @@ class Trainer(nn.Module):
         d_fine, _, _ = hip.volsdf_fine_sample(sa["blob"], o, dn, near, far, rk.get("obj_bounding_radius", 3.0), float(alpha.detach()),
                                               float(beta.detach()), rk.get("epsilon", 0.1), 4 * ns, 4 * ns, ni,
                                               rk.get("max_upsample_steps", 5), rk.get("max_bisection_steps", 10),
-                                              precision=sa["precision"], escalate=sa["escalate"], guard=sa["guard"],
+                                              precision=sa["precision"], escalate=sa["escalate"], guard=sa["guard"], late_round=sa["late_round"],
                                               u_final=self._uniform(pass_no, first_ray, o.shape[0], ni, o.device) if perturb else None)
         t = hip.lin_table(ns, o.device)
         d_coarse = (near * (1.0 - t) + far * t)[None, :].expand(o.shape[0], ns)
@@ -204,6 +215,7 @@ class Trainer(nn.Module):
         k_sdf_grad, radiance, composite), KEEPING every launch group's sample depths, sdf, nablas and layer-7 activations
         (1 KiB / point in HBM) for pass 2: the weights do not change between the passes and perturb=False is
         deterministic, so pass 2 would recompute exactly these.  Returns rgb [N, 3]; the state waits in self._kept."""
+        self._training_sampler()
         m = self.model
         if not self.is_neus:
             from .volsdf import check_render_kwargs
@@ -262,6 +274,7 @@ class Trainer(nn.Module):
         Pass 1's image is evaluated at the first set (sdf + nabla, radiance, composite: the fused renderer's stages, nothing kept); the
         depths of the second set wait in self._depths2 [N, P] for backward_patches(depths_all=...), whose nerfart_volsdf_render_bwd
         (have_state = 0) evaluates the per-point state there.  Returns rgb [N, 3]."""
+        self._training_sampler()
         m = self.model
         if self.is_neus:
             raise RuntimeError("render_two_draws: VolSDF only (NeuS draws in every up-sampling round)")
@@ -290,7 +303,7 @@ class Trainer(nn.Module):
             u = torch.cat([self._uniform(1, i, n, ni, o.device), self._uniform(2, i, n, ni, o.device)], dim=1).contiguous()
             d_fine, _, _ = hip.volsdf_fine_sample(sa["blob"], oi, dn, near, far, rk.get("obj_bounding_radius", 3.0), ab[0], ab[1], rk.get("epsilon", 0.1),
                                                   4 * ns, 4 * ns, 2 * ni, rk.get("max_upsample_steps", 5), rk.get("max_bisection_steps", 10),
-                                                  precision=sa["precision"], escalate=sa["escalate"], guard=sa["guard"], u_final=u)
+                                                  precision=sa["precision"], escalate=sa["escalate"], guard=sa["guard"], late_round=sa["late_round"], u_final=u)
             d_coarse = (near * (1.0 - t) + far * t)[None, :].expand(n, ns)
             dep1 = torch.sort(torch.cat([d_coarse, d_fine[:, :ni]], dim=-1), dim=-1)[0]
             deps2.append(torch.sort(torch.cat([d_coarse, d_fine[:, ni:]], dim=-1), dim=-1)[0])
@@ -311,6 +324,7 @@ class Trainer(nn.Module):
         depths_all [N, P]: sample depths from pass 1 (skips the re-sampling); kept: render_keep's per-group state of
         exactly these rays (skips the SDF re-evaluation too).  Returns the mean eikonal loss over the reference's
         pass2_rays-ray patches (what the reference prints)."""
+        self._training_sampler()
         o_all = rays_o.reshape(-1, 3).float().contiguous()
         d_all_ = rays_d.reshape(-1, 3).float().contiguous()
         g_all = gradient.reshape(-1, 3)
@@ -397,6 +411,7 @@ class Trainer(nn.Module):
         NeuS (neus.py:578-617): |rgb - target| (masked mean over target_mask if given: `with_mask`) + w_eikonal * MSE over
         the nablas of ALL samples + w_mask * BCE(clamp(mask_volume, 1e-3, 1 - 1e-3), target_mask); the radiance net trains
         if its parameters require grad."""
+        self._training_sampler()
         if self.is_neus:
             return self._reconstruction_step_neus(render_fn, rays_o, rays_d, target_rgb, w_eikonal, optimizer, mask_ignore, target_mask,
                                                   w_mask, **render_kwargs)
@@ -578,6 +593,7 @@ class Trainer(nn.Module):
         tile (rays dealt to a rank at a time) defaults to pass2_rays: every rank then owns WHOLE patches of the single-process
         step's patch grid, the per-patch eikonal means coincide and the all-reduced gradients equal the single-GPU step's up to
         summation order."""
+        self._training_sampler()
         sharded = nd.world_size() > 1
         tile = self.pass2_rays if tile is None else tile
         resample = self.resamples(render_kwargs)           # pass 2 draws its own samples (the reference under perturb=True)

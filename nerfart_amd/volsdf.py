@@ -87,7 +87,8 @@ def volume_render(rays_o, rays_d, model: VolSDF, near=0.0, far=6.0, obj_bounding
             n_importance=N_importance, max_upsample_steps=max_upsample_steps,
             max_bisection_steps=max_bisection_steps, white_bkgd=white_bkgd, calc_normal=want_normal,
             detailed=detailed_output, k3_rays_chunk=k3_rays_chunk, precision=model.precision_id, u_final=u_final, sampler=sampler,
-            guard=model.sampler_guard if sampler is not None else 0.0, radiance=radiance, stats=model.render_stats))
+            guard=model.sampler_guard if sampler is not None else 0.0, late_round=model.sampler_late_round if sampler is not None else 0,
+            radiance=radiance, stats=model.render_stats))
     ret = OrderedDict()
     order = ["rgb", "depth_volume", "mask_volume", "normals_volume", "implicit_surface", "implicit_nablas", "radiance",
              "alpha", "p_i", "visibility_weights", "d_vals", "sigma", "beta_map", "iter_usage"]

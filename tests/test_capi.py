@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(hip.lib, s), f"{s} declared in include/nerfart_hip.h but not exported by {hip.LIB_PATH}"
     assert set(hip._SIGS) == set(syms), "ctypes signature table and header disagree"
-    assert hip.ABI_VERSION == 4
+    assert hip.ABI_VERSION == 5
 
 
 def test_library_is_gfx950_code_object():

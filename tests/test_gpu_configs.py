@@ -260,8 +260,18 @@ def test_cfg2_mixed_mode_over_eight_orbit_views():
     sel = torch.arange(0, H * W, (H * W) // n)[:n]
     sd, _ = scene_state("VolSDF", 0.01)
     models = {m: scene.build_model("VolSDF", seed=0, beta=0.01, device=DEV, precision=m) for m in ("bf16x3", "mixed")}
-    assert models["mixed"][0].mode == "mixed" and models["mixed"][0].sampler_guard > 0
+    assert models["mixed"][0].mode == "mixed" and models["mixed"][0].sampler_guard > 0 and models["mixed"][0].sampler_late_round == 3
     models["mixed"][0].render_stats = {}
+    # second session of round 6: the RENDERING form of the shipped mode (model.calibrate_sampler(): the 1-MFMA sampler on error-compensated one-term weights,
+    # same guard) - what bench.py's headline and INTEGRATION.md's render.py run - held to the same contract on the same rays
+    models["calibrated"] = scene.build_model("VolSDF", seed=0, beta=0.01, device=DEV, precision="mixed")
+    models["calibrated"][0].calibrate_sampler()
+    assert models["calibrated"][0].mode == "mixed (calibrated sampler)" and models["calibrated"][0].packed_sampler()[1] == 5
+    cs = models["calibrated"][0].calibration_stats
+    print("  dropped product (W - fp16 W) . a on the calibration set, rms per hidden layer, nearest -> compensated: " +
+          ", ".join(f"{a:.1e} -> {b:.1e}" for a, b in cs.values()))
+    assert all(b < 0.35 * a for a, b in cs.values())
+    models["calibrated"][0].render_stats = {}
     angles = scene.spiral(90)
     for pose in (int(p) for p in z["poses"]):
         c2w, K = scene.camera(H, W, angle=angles[pose])
@@ -284,9 +294,15 @@ def test_cfg2_mixed_mode_over_eight_orbit_views():
               f"{st['mixed']['psnr_db']} / {st['bf16x3']['psnr_db']} dB, identical rounds {st['mixed']['same_upsampling_rounds_frac']} / {st['bf16x3']['same_upsampling_rounds_frac']}")
         assert bench_util.view_budget(st["bf16x3"]) == [], (pose, "bf16x3", bench_util.view_budget(st["bf16x3"]))
         assert bench_util.view_budget(st["mixed"], base=st["bf16x3"]) == [], (pose, "mixed", bench_util.view_budget(st["mixed"], base=st["bf16x3"]))
-    rs = models["mixed"][0].render_stats
-    print(f"  guard {models['mixed'][0].sampler_guard}: {rs['escalated']} of {rs['rays']} sampled rays ran Algorithm 1 twice ({100.0 * rs['escalated'] / rs['rays']:.2f} %)")
-    assert rs["escalated"] <= 0.05 * rs["rays"]
+        c = st["calibrated"]
+        print(f"           calibrated 1-MFMA sampler: rays past 1e-3 {c['rays_over_1e-3']} (oracle-converged {c['rays_over_1e-3_among_oracle_converged']}), max "
+              f"{c['max_abs_rgb_all']:.2e}, PSNR {c['psnr_db']} dB, identical rounds {c['same_upsampling_rounds_frac']}")
+        assert bench_util.view_budget(c, base=st["bf16x3"]) == [], (pose, "calibrated", bench_util.view_budget(c, base=st["bf16x3"]))
+    for m in ("mixed", "calibrated"):
+        rs = models[m][0].render_stats
+        print(f"  {m}: guard {models[m][0].sampler_guard}, late round {models[m][0].sampler_late_round}: {rs['escalated']} of {rs['rays']} sampled rays ran Algorithm 1 twice "
+              f"({100.0 * rs['escalated'] / rs['rays']:.2f} %)")
+        assert rs["escalated"] <= 0.07 * rs["rays"]          # measured 4.3 % of whole frames (1.9 % before the late-round rule)
 
 
 def test_the_frame_through_the_references_call_shape_is_the_same_frame():

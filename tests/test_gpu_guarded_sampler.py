@@ -24,10 +24,10 @@ def _setup(H=96, W=54, pose=3):
     return model, rk, render_fn, o, d, dn, alpha, beta
 
 
-def _sample(model, o, dn, alpha, beta, blob, prec, escalate=None, guard=0.0, u=None, n_final=64, stats=None, max_iter=6):
+def _sample(model, o, dn, alpha, beta, blob, prec, escalate=None, guard=0.0, u=None, n_final=64, stats=None, max_iter=6, late_round=0):
     from nerfart_amd import hip
     return hip.volsdf_fine_sample(blob, o, dn, 0.0, 6.0, 3.0, alpha, beta, 0.1, 512, 512, n_final, max_iter, 10, precision=prec, u_final=u,
-                                  escalate=escalate, guard=guard, stats=stats)
+                                  escalate=escalate, guard=guard, stats=stats, late_round=late_round)
 
 
 @pytest.mark.parametrize("perturb", [False, True])
@@ -85,6 +85,45 @@ def test_guarded_sampler_edge_cases():
     assert torch.equal(two[0][:, :64], one[0]) and torch.equal(two[2], one[2])
 
 
+@pytest.mark.parametrize("sampler", ["fp16x2", "fp16x1c"])
+def test_late_round_rule_sends_the_branch_sensitive_rays_through_the_split_bf16_kernels(sampler):
+    """nerfart_volsdf_fine_sample_guarded2's third rule (ABI 5; nets.DEFAULT_SAMPLER_LATE_ROUND = 3): a ray still active after round `late_round` is
+    escalated there.  Every ray of the guarded run is then either the cheap sampler's own (it converged by round late_round with every decision
+    clear) or the split-bf16 run's, bit for bit; every ray the split-bf16 run needs more than late_round rounds for - or never converges on - that
+    the cheap run also carried past late_round is the split-bf16 run's; late_round = 0 is the two-rule sampler; the fused renderer passes it through."""
+    from nerfart_amd import hip
+    model, rk, fn, o, d, dn, alpha, beta = _setup()
+    model.set_sampler_precision(sampler, guard=0.005, late_round=3)
+    surf, rad = model.packed()
+    samp, sprec = model.packed_sampler()
+    assert sprec == (4 if sampler == "fp16x2" else 5)
+    R = o.shape[0]
+    pure = _sample(model, o, dn, alpha, beta, surf, 1)
+    cheap = _sample(model, o, dn, alpha, beta, samp, sprec)
+    two = _sample(model, o, dn, alpha, beta, samp, sprec, escalate=(surf, 1), guard=0.005)
+    for late in (1, 3, 5):
+        st = {}
+        g = _sample(model, o, dn, alpha, beta, samp, sprec, escalate=(surf, 1), guard=0.005, late_round=late, stats=st)
+        like_pure = (g[0] == pure[0]).all(dim=1) & (g[1] == pure[1]) & (g[2] == pure[2])
+        like_cheap = (g[0] == cheap[0]).all(dim=1) & (g[1] == cheap[1]) & (g[2] == cheap[2])
+        assert bool((like_pure | like_cheap).all())
+        carried = (cheap[2] > late) | (cheap[2] < 0)                      # the cheap run did not decide these by round `late`
+        assert bool(like_pure[carried].all()), "a ray the cheap sampler carries past late_round is the split-bf16 run's"
+        assert bool((g[2][~like_pure] <= late).all()) and bool((g[2][~like_pure] >= 0).all()), "what stays the cheap sampler's converged by round late_round"
+        assert st["escalated"] >= int(carried.sum())
+        print(f"  {sampler}, late_round {late}: {st['escalated']} of {R} rays sampled twice ({int(carried.sum())} carried past round {late}); rounds equal to the "
+              f"split-bf16 run's on {float((g[2] == pure[2]).float().mean()):.4f} (two rules: {float((two[2] == pure[2]).float().mean()):.4f})")
+    g0 = _sample(model, o, dn, alpha, beta, samp, sprec, escalate=(surf, 1), guard=0.005, late_round=0)
+    assert all(torch.equal(a, b) for a, b in zip(g0, two))
+    kw = dict(near=0.0, far=6.0, R_bg=3.0, alpha=alpha, beta=beta, max_upsample_steps=6, detailed=True, precision=1)
+    fused = hip.volsdf_render(surf, rad, 1, o, d, sampler=(samp, sprec), guard=0.005, late_round=3, **kw)
+    staged = hip.volsdf_render_mixed(surf, rad, samp, sprec, 1, o, d, guard=0.005, late_round=3, **kw)
+    for k in fused:
+        assert torch.equal(fused[k], staged[k]), k
+    rgb, _, ex = fn(o[None], d[None], require_nablas=True, calc_normal=True, detailed_output=True, **rk)      # the model's own call
+    assert torch.equal(rgb[0], fused["rgb"]) and torch.equal(ex["iter_usage"][0], fused["iter_usage"])
+
+
 def test_fused_staged_renderer_equals_the_stage_entry_points_with_the_guard_on():
     from nerfart_amd import hip
     model, rk, fn, o, d, dn, alpha, beta = _setup(H=48, W=27)
@@ -101,7 +140,7 @@ def test_fused_staged_renderer_equals_the_stage_entry_points_with_the_guard_on()
     model.render_stats = {}
     rgb, _, ex = fn(o[None], d[None], require_nablas=True, calc_normal=True, detailed_output=True, **rk)
     assert model.render_stats["rays"] == o.shape[0] and model.render_stats["escalated"] > 0
-    ref = hip.volsdf_render(surf, rad, 1, o, d, sampler=samp, guard=model.sampler_guard, **kw)
+    ref = hip.volsdf_render(surf, rad, 1, o, d, sampler=samp, guard=model.sampler_guard, late_round=model.sampler_late_round, **kw)
     assert torch.equal(rgb[0], ref["rgb"]) and torch.equal(ex["iter_usage"][0], ref["iter_usage"])
     # rays that never converge render exactly as in the pure split-bf16 mode
     model.set_precision("bf16x3")
@@ -167,7 +206,7 @@ for pose in (5, 40):
     alpha, beta = (float(t.detach()) for t in model.forward_ab())
     sa = model.sampler_args()
     run = lambda: hip.volsdf_fine_sample(sa["blob"], o[0].contiguous(), dn, 0.0, 6.0, 3.0, alpha, beta, 0.1, 512, 512, 64, 6, 10, precision=sa["precision"],
-                                         escalate=sa["escalate"], guard=sa["guard"])
+                                         escalate=sa["escalate"], guard=sa["guard"], late_round=sa["late_round"])
     run(); torch.cuda.synchronize(); t0 = time.perf_counter()
     r = run(); torch.cuda.synchronize()
     out[f"ms_{pose}"] = (time.perf_counter() - t0) * 1e3

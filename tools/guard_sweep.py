@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--size", default="480x270")
     ap.add_argument("--n-samples", type=int, default=128)
     ap.add_argument("--sampler", default="fp16x2", help="the sampler's arithmetic: fp16x2 (2 MFMAs per product, C-ABI precision 4) or fp16x1 (1 MFMA, precision 5)")
+    ap.add_argument("--late", type=int, default=0, help="late_round of the guarded sampler: rays still active after that round are escalated too")
     ap.add_argument("--oracle-cache", default=None, help="npz of oracle outputs per (size, spp, pose, rays): read if present, written back (the oracle "
                     "costs ~30 s per view on the GPU box's host cores)")
     args = ap.parse_args()
@@ -46,7 +47,7 @@ def main():
     mm, _, fm = scene.build_model("VolSDF", seed=0, beta=0.01, device=dev, precision="bf16x3")
     kw = dict({k: v for k, v in rk.items() if k != "rayschunk"}, N_samples=args.n_samples)
     sd = {k: v.detach().cpu() for k, v in mb.state_dict().items()}
-    out = {"frame": f"{H}x{W}, {args.n_samples} + 64 spp, beta 0.01", "oracle_rays": args.rays, "sampler": args.sampler, "csrc_sha256": hip.csrc_sha256(), "views": {}, "timing": {}}
+    out = {"frame": f"{H}x{W}, {args.n_samples} + 64 spp, beta 0.01", "oracle_rays": args.rays, "sampler": args.sampler, "late_round": args.late, "csrc_sha256": hip.csrc_sha256(), "views": {}, "timing": {}}
 
     def frame(fn, o, d):
         rgb, _, ex = fn(o, d, require_nablas=True, calc_normal=True, detailed_output=True, **kw)
@@ -70,7 +71,7 @@ def main():
         rays_t.append((o2, d2))
     out["timing"]["bf16x3"] = {"ms_per_frame": ms_per_frame(fb)}
     for g in guards:
-        mm.set_sampler_precision(args.sampler, guard=g)
+        mm.set_sampler_precision(args.sampler, guard=g, late_round=args.late)
         mm.render_stats = {}
         ms = ms_per_frame(fm)
         out["timing"][f"guard_{g:g}"] = {"ms_per_frame": ms, "escalated_frac": round(mm.render_stats["escalated"] / max(mm.render_stats["rays"], 1), 5)}
@@ -107,7 +108,7 @@ def main():
             return st
         rec["modes"]["bf16x3"] = {"vs_oracle": vs_oracle(base_rgb, base_use)}
         for g in guards:
-            mm.set_sampler_precision(args.sampler, guard=g)
+            mm.set_sampler_precision(args.sampler, guard=g, late_round=args.late)
             mm.render_stats = {}
             rgb, use = frame(fm, o, d)
             _, stb = stats(rgb, base_rgb)

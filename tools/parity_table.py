@@ -5,7 +5,7 @@ rays, on the default camera and on bench.py's view (orbit pose 1), plus ms per f
 against the oracle is listed with the OTHER modes' errors on the same ray (is it the arithmetic, or one of Algorithm 1's
 discontinuities that flips under any rounding?).
 
-    python tools/parity_table.py [--precisions fp32,mixed,bf16x3,fp16x2] [--rays 2048] > profiles/rNN_parity_table.json
+    python tools/parity_table.py [--precisions fp32,calibrated,mixed,bf16x3,fp16x2] [--rays 2048] > profiles/rNN_parity_table.json
 """
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,7 +24,7 @@ def stats(got, ref):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--precisions", default="fp32,mixed,bf16x3,fp16x2")
+    ap.add_argument("--precisions", default="fp32,calibrated,mixed,bf16x3,fp16x2")
     ap.add_argument("--rays", type=int, default=2048)
     ap.add_argument("--frames", type=int, default=3)
     args = ap.parse_args()
@@ -33,12 +33,15 @@ def main():
     dev = "cuda:0"
     H, W = 480, 270
     MIXED = "mixed"            # the shipped mode: Algorithm 1 on the 2-MFMA kernels, the 192 final samples in split-bf16 (set_precision("mixed"))
-    precisions = [p for p in args.precisions.split(",") if p in hip.PRECISIONS or p == MIXED]
+    CAL = "calibrated"         # ... and its rendering form: mixed + model.calibrate_sampler() (the 1-MFMA sampler on error-compensated one-term weights)
+    precisions = [p for p in args.precisions.split(",") if p in hip.PRECISIONS or p in (MIXED, CAL)]
     if "fp32" not in precisions:
         precisions = ["fp32"] + precisions
     angles = scene.spiral(90)
     out = {"frame": f"{H}x{W}, 128 + 64 spp, beta 0.01", "oracle_rays": args.rays, "csrc_sha256": hip.csrc_sha256(), "views": {}}
-    models = {p: scene.build_model("VolSDF", seed=0, beta=0.01, device=dev, precision=p) for p in precisions}
+    models = {p: scene.build_model("VolSDF", seed=0, beta=0.01, device=dev, precision=MIXED if p == CAL else p) for p in precisions}
+    if CAL in models:
+        models[CAL][0].calibrate_sampler()
     sd = {k: v.detach().cpu() for k, v in models["fp32"][0].state_dict().items()}
     for view, ang in (("default", 0.0), ("bench_orbit_pose_1", angles[1])):
         c2w, K = scene.camera(H, W, angle=ang)
