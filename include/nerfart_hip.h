@@ -30,8 +30,9 @@
  *           Algorithm 1's sampler in the shipped `mixed` mode (nerfart_volsdf_render_staged_fwd's sampler_precision, guarded).
  *       5 = "fp16x1" (csrc/mlp_chain_f16x1.hip; nerfart_sdf_fwd / nerfart_sdf_fwd_rays and the SAMPLER arguments of nerfart_volsdf_fine_sample[_guarded] /
  *           nerfart_volsdf_render_mixed_fwd / _staged_fwd only - every other entry point refuses it): K2 with ONE v_mfma_f32_16x16x32_f16 per
- *           product (one fp16 activation term x one fp16 weight term) on the precision-4 blob.  An opt-in, measured and not shipped
- *           (DESIGN.md 4.1e): no value that reaches a pixel and no gradient is computed in it.
+ *           product (one fp16 activation term x one fp16 weight term) on a precision-4 blob - for rendering, one whose hidden-layer hi fragments hold
+ *           ERROR-COMPENSATED one-term weights (nerfart_amd/calibrate.py feeds nerfart_pack_surface_blob folded matrices that already sit on the fp16 grid;
+ *           DESIGN.md 4.1e / 4.1f).  No value that reaches a pixel and no gradient is computed in it.
  *   - point sources: either an explicit array pts[M,3], or ("_rays" variants) rays + per-ray depths:
  *     point m = slot m / n_per_ray, sample m % n_per_ray, ray = ray_idx ? ray_idx[slot] : slot,
  *     x = rays_o[ray] + rays_d[ray] * depth[slot * depth_stride + sample]  (two roundings, as the
