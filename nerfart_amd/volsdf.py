@@ -150,6 +150,11 @@ def get_model(args, render_target=None):
     # the arithmetic of the kernels (not a reference key; `model.precision` in the YAML or --model:precision overrides it): 'mixed' = the
     # shipped mode (nets._PackedModel.set_precision) - a model from get_model renders AND trains without a further call
     model.set_precision(m.get("precision", "mixed"))
+    # `model.calibrate_sampler: true` (YAML of this repo, or `--model:calibrate_sampler true` on render.py's command line - the reference's own override syntax,
+    # utils/io_util.py:270-319): the rendering form of `mixed` without touching render.py (nets.calibrate_sampler; the calibration itself runs at the first render,
+    # on the weights loaded by then; a Trainer switches it back)
+    if m.get("calibrate_sampler", False) and model.mode == "mixed":
+        model.calibrate_sampler()
     render_kwargs_train = {
         "near": args.data.near, "far": args.data.far, "batched": True,
         "perturb": m.setdefault("perturb", True), "white_bkgd": m.setdefault("white_bkgd", False),

@@ -92,6 +92,17 @@ def test_get_model_ships_the_mixed_mode_and_the_yaml_can_override_it():
         if name == "fp32":
             with pytest.raises(RuntimeError, match="split-bf16"):
                 tr2.native
+    # the rendering form of `mixed` (second session of round 6): a method, or a key of the YAML / of render.py's command line; the calibration itself is lazy
+    assert m.sampler_late_round == 3 and m.calibrate_sampler() is m and (m.sampler_precision, m.sampler_guard, m.sampler_late_round) == ("fp16x1c", 0.005, 3)
+    assert m.mode == "mixed (calibrated sampler)" and n.calibrate_sampler() is n and n.mode == "bf16x3"
+    cfg = scene.synthetic_config("VolSDF")
+    cfg.model.calibrate_sampler = True
+    m3, tr3, _, _, _ = frameworks.get_model(cfg)
+    assert m3.mode == "mixed (calibrated sampler)" and tr3.native is True
+    with pytest.warns(UserWarning, match="calibrated for rendering"):
+        tr3._training_sampler()                             # what every step entry point of a Trainer does first: weights are about to change
+    assert m3.mode == "mixed"
+    m.set_precision("mixed")
     m.set_sampler_precision("fp32")
     assert m.mode == "bf16x3+fp32 sampler (guard 0.005)"    # any sampler that is not the model's own arithmetic is guarded by default
     m.set_precision("bf16x3")                               # a precision is the whole mode: it resets the sampler's
