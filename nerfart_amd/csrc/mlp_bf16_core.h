@@ -256,6 +256,9 @@ template <int J>
 __device__ __forceinline__ void stream_piece(const Stream& s) {
 #ifdef NERFART_F16X1
     if constexpr (J & 1) {
+#ifdef NERFART_ABLATE_DMA        // timing experiments only
+        return;
+#endif
         // a lo piece: issued under EXEC = lo_exec (all lanes, or none where the chunk's k-step never reads its lo fragments) - no branch inside the
         // item stream (the counted lgkmcnt windows are straight-line code, tools/audit_asm_loads.py); an instruction with EXEC = 0 moves nothing
         unsigned keep_m0;
@@ -563,6 +566,10 @@ __device__ __forceinline__ void lds_read_pair(u32x4& fh, u32x4& fl, unsigned add
 }
 template <int OFF>
 __device__ __forceinline__ void lds_read_hi(u32x4& fh, unsigned addr) {      // NERFART_F16X1: the item's hi fragment alone
+#ifdef NERFART_ABLATE_LDSREAD    // timing experiments only
+    asm volatile("; no read %0 %1" : "=&v"(fh) : "v"(addr));
+    return;
+#endif
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(fh) : "v"(addr), "i"(OFF));
 }
 template <int CNT>
@@ -721,9 +728,18 @@ struct Items {
                 if constexpr (kk == 0 && T < 8) stream_piece<T>(s);
             } else
 #endif
+#ifdef NERFART_F16X1
+            // the odd pieces are lo fragments (stream_piece): where the chunk being streamed - chunk C + 1 of this layer, or the next layer's first chunk,
+            // which in K2 holds ready-made input units only after the LAST layer (NEXT0 false: layer 0 of the next tile) - has no k-step that reads them, they
+            // are not even issued under EXEC = 0: 27 of K2's 30 chunks
+            constexpr int NA = CHUNK_KS * (C + 1), NB = NA + 1;
+            constexpr bool LO_NEXT = (NA < L::NKS) ? (NA >= L::NH || (NB < L::NKS && NB >= L::NH)) : !L::NEXT0;
+#else
+            constexpr bool LO_NEXT = true;
+#endif
             if constexpr (DMA_HERE) {
-                if constexpr (NKC == 2) stream_piece<kk * 4 + DMA_J>(s);
-                else { stream_piece<2 * DMA_J>(s); stream_piece<2 * DMA_J + 1>(s); }
+                if constexpr (NKC == 2) { if constexpr (LO_NEXT || ((kk * 4 + DMA_J) & 1) == 0) stream_piece<kk * 4 + DMA_J>(s); }
+                else { stream_piece<2 * DMA_J>(s); if constexpr (LO_NEXT) stream_piece<2 * DMA_J + 1>(s); }
             }
             // epilogue slice hosted by this item
 #ifdef NERFART_EXP_EPI2      // experiment: plain softplus layers run TWO independent pairs per slice (items 4..9), ILP 2
