@@ -24,6 +24,7 @@ import torch
 
 from . import hip
 
+C_SCALE = 100.0 * math.log2(math.e)      # the 1-MFMA kernel's scaled softplus recursion (mlp_bf16_core.h, NERFART_F16X1): accumulators hold z' = c z, activations a' = c a
 N_CALIB = 12288          # calibration points: half uniform in the bounding sphere, half with |sdf| < NEAR
 NEAR = 0.1
 DAMP = 0.01              # GPTQ damping: lambda = DAMP * mean(diag H)
@@ -79,39 +80,52 @@ def calibration_points(model, n: int = N_CALIB, seed: int = 0) -> torch.Tensor:
     return torch.cat([u[: n - near.shape[0]], near])
 
 
-def compensated_surface_layers(model, n: int = N_CALIB, seed: int = 0):
-    """(weight_g, weight_v, bias) lists for hip.pack_surface_blob(4, ...): per layer the FOLDED weight matrix as `weight_v` with its row norms as `weight_g`
-    (the packer's fold g v / ||v|| then reproduces it to an fp32 ulp, far inside an fp16 step), hidden-layer columns on the fp16 grid, compensated;
-    layer 0 and the skip layer's encoding columns - ready-made input units, hi + lo in the kernel - and the last layer untouched.
+def compensated_surface_layers(model, n: int = N_CALIB, seed: int = 0, compensate: bool = True):
+    """(weight_g, weight_v, bias) lists for hip.pack_surface_blob(5, ...) - the blob of the 1-MFMA K2 (C-ABI precision 5): per layer the FOLDED weight matrix
+    as `weight_v` with its row norms as `weight_g` (the packer's fold g v / ||v|| then reproduces it to an fp32 ulp, far inside an fp16 step), in the SCALED
+    recursion the kernel runs (z' = c z, a' = c softplus(z), c = 100 log2 e: layer 0's weights, the skip layer's encoding columns and every hidden bias times
+    c, the last layer's row divided by c, the hidden layers' own weights unchanged), hidden-layer columns on the fp16 grid -
+    compensate=True: error-compensated against the model's activations (what model.calibrate_sampler() ships); False: rounded to nearest (the measured,
+    not shipped form of DESIGN.md 4.1e; no calibration points are drawn).
     Also returns a dict of per-layer statistics (rms of the dropped product on the calibration set: nearest / compensated)."""
     S = model.implicit_surface
     L = list(S.surface_fc_layers)
     dev = L[0].weight_v.device
     D, skips, multires = S.D, tuple(S.skips), S.embed_multires
-    pts = calibration_points(model, n, seed).double()
+    c = C_SCALE
     with torch.no_grad():
         Wf = [_fold(l.weight_g.detach().cpu(), l.weight_v.detach().cpu()) for l in L]
         bf = [l.bias.detach().cpu().double() for l in L]
-        e = _embed(pts, multires)
-        h = e
-        out_w, stats = [], {}
+        out_w, out_b, stats = [], [], {}
+        if compensate:
+            pts = calibration_points(model, n, seed).double()
+            e = _embed(pts, multires)
+            h = e
         for i in range(D):
             W = Wf[i]
+            out_b.append(bf[i] * c)
             if i == 0:
-                out_w.append(W)
-                h = _softplus100(h @ W.T + bf[i])
+                out_w.append(W * c)                                     # ready-made input units (hi + lo in the kernel): z'_0 = (c W_0) enc + c b_0
+                if compensate:
+                    h = _softplus100(h @ W.T + bf[i])
                 continue
-            nh = h.shape[-1]
+            nh = Wf[i - 1].shape[0]                                     # the previous layer's outputs = this layer's hidden inputs
             scale = 1.0 / math.sqrt(2.0) if i in skips else 1.0       # cat[h, enc] / sqrt 2 (base.py:248-250): the packer folds it into layer i's weights
-            hq = h.float().half().double()                              # the kernel's B operand: one fp16 term of the activation
             Wh = W[:, :nh] * scale
-            Wq = compensated_round_fp16(Wh, hq)
-            stats[i] = (float(((Wh - Wh.float().half().double()) @ hq.T).pow(2).mean().sqrt()), float(((Wh - Wq) @ hq.T).pow(2).mean().sqrt()))
-            out_w.append(torch.cat([Wq / scale, W[:, nh:]], dim=1) if i in skips else Wq)
-            x = torch.cat([h, e], dim=-1) * scale if i in skips else h
-            h = _softplus100(x @ W.T + bf[i])
-        out_w.append(Wf[D])
+            if compensate:
+                hq = (h * c).float().half().double()                    # the kernel's B operand: one fp16 term of the scaled activation a' = c a
+                Wq = compensated_round_fp16(Wh, hq)
+                stats[i] = (float(((Wh - Wh.float().half().double()) @ hq.T).pow(2).mean().sqrt()) / c, float(((Wh - Wq) @ hq.T).pow(2).mean().sqrt()) / c)
+            else:
+                Wq = Wh.float().half().double()
+            # the skip layer's encoding columns multiply the raw encoding: they carry c (and keep hi + lo); the packer applies 1 / sqrt 2 to the whole tensor
+            out_w.append(torch.cat([Wq / scale, W[:, nh:] * c], dim=1) if i in skips else Wq)
+            if compensate:
+                x = torch.cat([h, e], dim=-1) * scale if i in skips else h
+                h = _softplus100(x @ W.T + bf[i])
+        out_w.append(Wf[D] / c)                                         # sdf (and the unused feature rows) = (W_8 / c) a'_7 + b_8
+        out_b.append(bf[D])
     g = [w.norm(dim=1).float().reshape(-1, 1).to(dev) for w in out_w]
     v = [w.float().contiguous().to(dev) for w in out_w]
-    b = [l.bias.detach() for l in L]
+    b = [x.float().contiguous().to(dev) for x in out_b]
     return g, v, b, stats

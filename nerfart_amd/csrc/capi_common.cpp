@@ -40,13 +40,13 @@ int blob_term_check(const void* blob, int want, const char* who) {
     // blob's own header word 10 - a device synchronisation, paid only on this suspected-mismatch path - and believe the header.
     int hdr10 = -1;
     if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(&hdr10, (const int*)blob + 10, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess &&
-        hdr10 >= 0 && hdr10 <= 2) {
+        hdr10 >= 0 && hdr10 <= 3) {
         blob_term_register(blob, hdr10);
         if (hdr10 == want) return 0;
         have = hdr10;
     }
-    static const char* names[] = {"fp32", "split bf16 (precision 1)", "fp16 hi + lo (precision 4)"};
-    g_last_error = std::string(who) + ": this entry point reads a " + names[want] + " blob; the blob was packed as " + names[have < 3 ? have : 0] +
+    static const char* names[] = {"fp32", "split bf16 (precision 1)", "fp16 hi + lo (precision 4)", "softplus-scaled fp16 (precision 5: the 1-MFMA sampler's)"};
+    g_last_error = std::string(who) + ": this entry point reads a " + names[want < 4 ? want : 0] + " blob; the blob was packed as " + names[have < 4 ? have : 0] +
                    " (nerfart_pack_*_blob's precision argument)";
     return 2;
 }

@@ -362,6 +362,10 @@ __device__ __forceinline__ float relu1(float z) {
 __device__ __forceinline__ float softplus_tail(float z, float L) {
 #ifdef NERFART_OLD_ITEM
     return relu1(z) + L * (0.69314718055994530942f / 100.0f);
+#elif defined(NERFART_F16X1)     // scaled recursion: max(z', 0) + log2(1 + e)
+    float y;
+    asm("v_max_f32 %0, 0, %1\n\tv_add_f32 %0, %0, %2" : "=&v"(y) : "v"(z), "v"(L));
+    return y;
 #else
     float y;
     asm("v_max_f32 %0, 0, %1\n\tv_fmac_f32 %0, 0x3be32166, %2" : "=&v"(y) : "v"(z), "v"(L));
@@ -389,8 +393,17 @@ __device__ __forceinline__ void epi_phase(float z0, float z1, Work& w, unsigned&
             asm volatile("" : "+v"(z0), "+v"(z1));
         }
         if constexpr (MODE == 0 || MODE == 1 || MODE == 4 || MODE == 5 || MODE == 10) {
+#ifdef NERFART_F16X1
+            // SCALED recursion (precision 5; the blob comes from nerfart_amd/calibrate.py): the accumulators hold z' = c z, c = 100 log2 e - layer 0's weights,
+            // the skip layer's encoding columns and every bias carry c - and the activation is a' = c softplus(z) = max(z', 0) + log2(1 + 2^-|z'|): the
+            // hidden layers' weights are the network's own (c a is what they multiply), the last row carries 1 / c.  One multiply per value less in an
+            // epilogue that costs the 1-MFMA kernel more than its matrix work.
+            w.e0 = __builtin_amdgcn_exp2f(-fabsf(z0));
+            w.e1 = __builtin_amdgcn_exp2f(-fabsf(z1));
+#else
             w.e0 = __builtin_amdgcn_exp2f(fabsf(z0) * -144.269504088896340736f);     // exp(-|100 z|)
             w.e1 = __builtin_amdgcn_exp2f(fabsf(z1) * -144.269504088896340736f);
+#endif
         }
         if constexpr (MODE == 11) {
             w.r0 = (float)(din & 0xffffu);
@@ -885,7 +898,11 @@ __device__ __forceinline__ void last_epilogue(const Acc& Q, const float* rows, f
                 d = quad_bcast0(d);
                 y[r] = ec.is_val ? v : d * a;
             } else {
+#ifdef NERFART_F16X1
+                y[r] = fmaxf(a, 0.f) + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(a)));     // a' = c softplus(z), the sdf row carries 1 / c
+#else
                 y[r] = softplus100(a);
+#endif
             }
         }
 #pragma unroll

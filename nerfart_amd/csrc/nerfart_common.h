@@ -96,7 +96,7 @@ void profile_close(void* handle, hipStream_t s);
 void profile_class0_as(int cls);                                     // 0: off; 4: record class-0 launches as the escalation class (this thread)
 void blob_term_register(const void* blob, int term);                 // packers: header word 10 of the blob just written (0 fp32, 1 bf16, 2 fp16)
 int blob_term_check(const void* blob, int want, const char* who);    // 0, or 2 + last_error when the packers recorded another encoding for this pointer
-inline int term_of_precision(int precision) { return (precision == 4 || precision == 5) ? 2 : ((precision == 1 || precision == 2) ? 1 : 0); }
+inline int term_of_precision(int precision) { return precision == 5 ? 3 : precision == 4 ? 2 : ((precision == 1 || precision == 2) ? 1 : 0); }
 }
 #define NERFART_HIP(expr)                                                   \
     do {                                                                    \

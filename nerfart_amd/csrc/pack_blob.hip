@@ -300,7 +300,9 @@ __host__ inline void make_header(const Prog& p, const Layout& L, int* hdr) {
         for (int i = 0; i < 24; ++i) hdr[132 + i] = L.offs[34 + i];
         hdr[8] = 30; hdr[9] = 63;                        // the 32x32x16-fragment program: chunk count, first chunk
     }
-    if (p.split) hdr[10] = p.fp16 ? 2 : 1;               // fragment encoding: 1 = bf16 hi + lo, 2 = fp16 hi + lo (ABI 3)
+    // fragment encoding: 1 = bf16 hi + lo, 2 = fp16 hi + lo (ABI 3), 3 = fp16 hi + lo of a SOFTPLUS-SCALED network (ABI 5, precision 5: the caller's tensors
+    // carry the scale, see nerfart_pack_surface_blob) - same layout as 2, read by the 1-MFMA K2 only
+    if (p.split) hdr[10] = p.fp16 ? (p.fp16 == 2 ? 3 : 2) : 1;
 }
 
 // ---- device side ----------------------------------------------------------------------------------------------------------------------
@@ -450,9 +452,10 @@ static int launch_pack(const Prog& p, const Tensors& t, int n_layers, float* blo
 }
 
 static int prog_of(int precision, bool radiance, int* fp16) {
-    *fp16 = precision == 4;
+    *fp16 = precision == 4 ? 1 : (precision == 5 ? 2 : 0);
     if (precision == 0) return radiance ? 2 : 1;
     if (precision == 1 || precision == 4) return radiance ? 4 : 3;
+    if (precision == 5 && !radiance) return 3;            // the SDF net only: Algorithm 1's sampler (csrc/mlp_chain_f16x1.hip)
     return 0;
 }
 

@@ -213,7 +213,7 @@ def pack_surface_blob(precision: int, multires: int, weight_g, weight_v, bias) -
     b = [t.detach().contiguous() for t in bias]
     _check(lib.nerfart_pack_surface_blob(int(precision), int(multires), _ptr_table(g, "weight_g"), _ptr_table(v, "weight_v"), _ptr_table(b, "bias"),
                                          _dev(blob), n, ws.data_ptr(), ws.numel(), _stream()), "nerfart_pack_surface_blob")
-    blob.nerfart_term = {0: "fp32", 1: "bf16", 4: "fp16"}[int(precision)]
+    blob.nerfart_term = {0: "fp32", 1: "bf16", 4: "fp16", 5: "fp16 (softplus-scaled, precision 5)"}[int(precision)]
     return blob
 
 
@@ -272,7 +272,6 @@ PRECISIONS = {"fp32": 0, "bf16x3": 1, "fp16x2": 4}      # 4: the 2-MFMA kernels:
 # Precisions that exist for Algorithm 1's no-gradient SDF queries ONLY (nerfart_sdf_fwd[_rays] and the sampler stage of the renderers refuse them
 # nowhere else): 5 = "fp16x1", one MFMA per product on the precision-4 blob (csrc/mlp_chain_f16x1.hip).
 SAMPLER_PRECISIONS = dict(PRECISIONS, fp16x1=5, fp16x1c=5)     # fp16x1c: the same kernel on error-compensated one-term weights (nerfart_amd/calibrate.py)
-PACK_PRECISION = {5: 4}                                  # C-ABI precision -> the precision whose blob it reads, where that is another one
 
 
 def sdf_fwd(surf_blob, pts, R_bg: float, precision: int = 0):

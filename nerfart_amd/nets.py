@@ -296,13 +296,16 @@ class _PackedModel(nn.Module):
         """The SDF net's blob at `precision` through the C ABI (nerfart_pack_surface_blob: weight_norm fold, unit-order permutation, hi / lo split
         on the device).  nerfart_amd/packing.py keeps the same layout as numpy plans - the source of truth of the CPU emulation
         (tests/emul_chain.py) - and tests/test_pack_plan.py holds the library's closed-form layout equal to them, entry for entry."""
-        if precision == "fp16x1c":          # one-term fp16 weights, error-compensated against this model's own activations (pack-time calibration)
+        if precision in ("fp16x1c", "fp16x1"):
+            # C-ABI precision 5, the 1-MFMA K2: one-term fp16 weights in the kernel's scaled softplus recursion - "fp16x1c": error-compensated against this
+            # model's own activations (pack-time calibration, what calibrate_sampler() ships); "fp16x1": rounded to nearest (measured, not shipped)
             from . import calibrate
-            g, v, b, self.calibration_stats = calibrate.compensated_surface_layers(self)
+            g, v, b, stats = calibrate.compensated_surface_layers(self, compensate=precision == "fp16x1c")
+            if precision == "fp16x1c":
+                self.calibration_stats = stats
         else:
             g, v, b = self._surface_layers()
-        pid = hip.SAMPLER_PRECISIONS[precision]
-        return hip.pack_surface_blob(hip.PACK_PRECISION.get(pid, pid), self.implicit_surface.embed_multires, g, v, b)
+        return hip.pack_surface_blob(hip.SAMPLER_PRECISIONS[precision], self.implicit_surface.embed_multires, g, v, b)
 
     def _pack_radiance(self, precision: str) -> torch.Tensor:
         last = self.implicit_surface.surface_fc_layers[self.implicit_surface.D]

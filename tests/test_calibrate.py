@@ -29,11 +29,14 @@ def test_compensated_rounding_cancels_the_dropped_product_and_stays_on_the_fp16_
     assert sorted(stats) == [1, 2, 3, 4, 5, 6, 7]
     for i, (nearest, comp) in stats.items():
         assert comp < 0.35 * nearest, (i, nearest, comp)           # measured 0.12 - 0.21 at 12,288 points
+    c = calibrate.C_SCALE                 # the kernel's scaled softplus recursion: z' = c z, a' = c softplus(z)
     for i in range(9):
         W = nets.folded_weight(sd, f"implicit_surface.surface_fc_layers.{i}")
         fold = g[i].reshape(-1, 1) * v[i] / v[i].norm(dim=1, keepdim=True)       # what nerfart_pack_surface_blob computes from (weight_g, weight_v)
+        bias = sd[f"implicit_surface.surface_fc_layers.{i}.bias"]
+        assert torch.allclose(b[i], bias * (c if i < 8 else 1.0), rtol=1e-6, atol=1e-9), "hidden biases carry c, the last layer's does not"
         if i in (0, 8):
-            assert torch.allclose(fold, W, rtol=1e-6, atol=1e-9), "layer 0 (ready-made input units) and the last layer are untouched"
+            assert torch.allclose(fold, W * (c if i == 0 else 1.0 / c), rtol=1e-5, atol=1e-9), "layer 0 carries c (its inputs are the raw encoding), the sdf row 1 / c; no rounding"
             continue
         nh = 217 if i == 4 else W.shape[1]
         sc = np.float32(1 / np.sqrt(2)) if i == 4 else np.float32(1.0)             # the packer folds the skip layer's 1 / sqrt 2 into its weights
@@ -46,7 +49,21 @@ def test_compensated_rounding_cancels_the_dropped_product_and_stays_on_the_fp16_
         moved = float((hid.half() != (W[:, :nh] * sc).half()).float().mean())
         assert 0.05 < moved < 0.5, moved
         if i == 4:
-            assert torch.allclose(fold[:, nh:], W[:, nh:], rtol=1e-6), "the skip layer's encoding columns keep their hi + lo weights"
+            assert torch.allclose(fold[:, nh:], W[:, nh:] * c, rtol=1e-5), "the skip layer's encoding columns keep their hi + lo weights (times c: they multiply the raw encoding)"
+    # the scaled recursion is the same network: z'_l = c z_l, a'_l = c a_l, sdf unchanged (fp64 restatement with the returned tensors)
+    x = torch.rand(256, 3, dtype=torch.float64, generator=torch.Generator().manual_seed(2)) * 2 - 1
+    e = calibrate._embed(x, 6)
+    h = e
+    for i in range(8):
+        Wi = (g[i].reshape(-1, 1) * v[i] / v[i].norm(dim=1, keepdim=True)).double()
+        if i == 4:
+            Wi = Wi / np.sqrt(2.0)
+            h = torch.cat([h, e], dim=-1)
+        z = h @ Wi.T + b[i].double()
+        h = torch.clamp(z, min=0) + torch.log2(1 + torch.exp2(-z.abs()))
+    sdf = h @ (g[8].reshape(-1, 1) * v[8] / v[8].norm(dim=1, keepdim=True)).double()[0] + b[8].double()[0]
+    ref = nets.surface_forward({k: t.double() for k, t in sd.items()}, x)[0]
+    assert float((sdf - ref).abs().max()) < 2e-3, float((sdf - ref).abs().max())       # one-term weights: 1e-4-class, not bits
 
 
 def test_compensated_round_fp16_is_nearest_rounding_when_nothing_correlates():

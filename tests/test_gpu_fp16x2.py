@@ -164,16 +164,23 @@ def test_fp16x1_sampler_only_precision():
     model, rk, fn = scene.build_model("VolSDF", seed=0, beta=0.01, device=DEV, precision="bf16x3")
     g, v, b = model._surface_layers()
     blob4 = hip.pack_surface_blob(4, 6, g, v, b)
+    model.set_sampler_precision("fp16x1", guard=0.05)                       # nearest-rounded one-term weights in the kernel's scaled softplus recursion
+    blob5, p5 = model.packed_sampler()
+    assert p5 == 5
     gen = torch.Generator().manual_seed(5)
     x = ((torch.rand(1 << 16, 3, generator=gen) * 2 - 1) * 1.5).to(DEV)
     s4 = hip.sdf_fwd(blob4, x, 3.0, precision=4)
-    s5 = hip.sdf_fwd(blob4, x, 3.0, precision=5)
+    s5 = hip.sdf_fwd(blob5, x, 3.0, precision=5)
+    with pytest.raises(hip.NerfartHipError, match="packed as"):
+        hip.sdf_fwd(blob4, x[:256], 3.0, precision=5)                         # the 2-MFMA blob is NOT the 1-MFMA kernel's (its recursion is scaled): refused
+    with pytest.raises(hip.NerfartHipError, match="packed as"):
+        hip.sdf_fwd(blob5, x[:256], 3.0, precision=4)
     s1 = hip.sdf_fwd(model.packed()[0], x, 3.0, precision=1)
     e45, e51, e41 = (s5 - s4).abs(), (s5 - s1).abs(), (s4 - s1).abs()
     print(f"  fp16x1 vs fp16x2: max {float(e45.max()):.2e} mean {float(e45.mean()):.2e}; vs bf16x3: fp16x1 {float(e51.max()):.2e} / {float(e51.mean()):.2e}, fp16x2 {float(e41.max()):.2e} / {float(e41.mean()):.2e}")
     assert float(e45.max()) < 2e-3 and float(e45.mean()) < 2.5e-4 and float(e51.max()) < 2e-3 and float(e51.mean()) < 2e-4      # measured 9.6e-4 / 1.2e-4 (both sides carry their own 11-bit activation noise), 8.5e-4 / 1.0e-4
     with pytest.raises(hip.NerfartHipError, match="precision 5"):
-        hip.sdf_nabla_fwd(blob4, x[:256], 3.0, precision=5)
+        hip.sdf_nabla_fwd(blob5, x[:256], 3.0, precision=5)
     with pytest.raises(hip.NerfartHipError):
         hip.sdf_fwd(model.packed()[0], x[:256], 3.0, precision=5)           # a split-bf16 blob: the library's encoding check
     with pytest.raises(ValueError):
@@ -183,7 +190,6 @@ def test_fp16x1_sampler_only_precision():
     o, d, _ = rend_util.get_rays(c2w[None].to(DEV), K[None].to(DEV), H, W)
     kw = dict(require_nablas=True, calc_normal=True, detailed_output=True, **rk)
     base, _, ex0 = fn(o, d, **kw)
-    model.set_sampler_precision("fp16x1", guard=0.05)
     assert model.mode == "bf16x3+fp16x1 sampler (guard 0.05)"
     model.render_stats = {}
     rgb, _, ex = fn(o, d, **kw)

@@ -25,8 +25,8 @@ import sys, json, torch
 sys.path.insert(0, %r)
 from nerfart_amd import scene, hip
 model, _, _ = scene.build_model("VolSDF", seed=0, beta=0.01, device="cuda", precision="bf16x3")
-g_, v_, b_ = model._surface_layers()
-blob = hip.pack_surface_blob(4, 6, g_, v_, b_)
+model.set_sampler_precision("fp16x1", guard=0.05)
+blob = model.packed_sampler()[0]
 g = torch.Generator().manual_seed(0)
 pts = ((torch.rand(1 << 22, 3, generator=g) * 2 - 1) * 1.5).cuda()
 fn = lambda: hip.sdf_fwd(blob, pts, 3.0, precision=5)

@@ -9,7 +9,11 @@ blob1 = hip.pack_surface_blob(1, 6, g, v, b); blob4 = hip.pack_surface_blob(4, 6
 torch.manual_seed(0)
 x = (torch.rand(4 << 20, 3, device=dev) * 2 - 1) * 1.5
 ref = hip.sdf_fwd(blob1, x, 3.0, precision=1)
-for name, blob, p in (('bf16x3', blob1, 1), ('fp16x2', blob4, 4), ('fp16x1', blob4, 5)):
+m.set_sampler_precision('fp16x1', guard=0.05)
+blob5 = m.packed_sampler()[0]
+m.set_sampler_precision('fp16x1c', guard=0.005, late_round=3)
+blob5c = m.packed_sampler()[0]
+for name, blob, p in (('bf16x3', blob1, 1), ('fp16x2', blob4, 4), ('fp16x1 (nearest)', blob5, 5), ('fp16x1 (compensated)', blob5c, 5)):
     out = hip.sdf_fwd(blob, x, 3.0, precision=p)
     torch.cuda.synchronize()
     ts = []
