@@ -365,7 +365,7 @@ def main():
                                "vs_fp32_pixels": pix2,
                                "what": "same workload at C-ABI precision 4: ONE fp16 activation term x fp16 hi + lo weights, 2 x v_mfma_f32_16x16x32_f16 per "
                                        "product (11-bit activations, TF32 class) - a measurement variant, NOT the headline precision; table vs the "
-                                       "oracle: profiles/r11_parity_table.json (tools/parity_table.py)"}
+                                       "oracle: profiles/r12_parity_table.json (tools/parity_table.py)"}
         torch.cuda.synchronize()
         hip.profile_begin()
         t1 = time.perf_counter()

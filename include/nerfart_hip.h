@@ -30,9 +30,11 @@
  *           Algorithm 1's sampler in the shipped `mixed` mode (nerfart_volsdf_render_staged_fwd's sampler_precision, guarded).
  *       5 = "fp16x1" (csrc/mlp_chain_f16x1.hip; nerfart_sdf_fwd / nerfart_sdf_fwd_rays and the SAMPLER arguments of nerfart_volsdf_fine_sample[_guarded] /
  *           nerfart_volsdf_render_mixed_fwd / _staged_fwd only - every other entry point refuses it): K2 with ONE v_mfma_f32_16x16x32_f16 per
- *           product (one fp16 activation term x one fp16 weight term) on a precision-4 blob - for rendering, one whose hidden-layer hi fragments hold
- *           ERROR-COMPENSATED one-term weights (nerfart_amd/calibrate.py feeds nerfart_pack_surface_blob folded matrices that already sit on the fp16 grid;
- *           DESIGN.md 4.1e / 4.1f).  No value that reaches a pixel and no gradient is computed in it.
+ *           product (one fp16 activation term x one fp16 weight term) in a SCALED softplus recursion (accumulators z' = c z, activations a' = c softplus(z),
+ *           c = 100 log2 e).  Its blob: nerfart_pack_surface_blob(precision = 5, ...) - the precision-4 layout under encoding word 3 - from tensors the CALLER
+ *           hands over in that recursion (layer 0's weights, the skip layer's encoding columns and the hidden biases times c, the last layer's rows / c) with the
+ *           hidden layers' folded weights on the fp16 grid; for rendering, ERROR-COMPENSATED ones (nerfart_amd/calibrate.py).  The library
+ *           refuses a precision-4 blob at precision 5 and vice versa.  No value that reaches a pixel and no gradient is computed in it.
  *   - point sources: either an explicit array pts[M,3], or ("_rays" variants) rays + per-ray depths:
  *     point m = slot m / n_per_ray, sample m % n_per_ray, ray = ray_idx ? ray_idx[slot] : slot,
  *     x = rays_o[ray] + rays_d[ray] * depth[slot * depth_stride + sample]  (two roundings, as the
@@ -498,7 +500,7 @@ int nerfart_weight_norm_bwd(const float* dW, const float* weight_v, const float*
  * w = g * v / ||v||_row, the permutation into the kernels' fragment order (a closed form the library owns; tests/test_pack_plan.py holds it
  * equal, entry for entry, to the numpy plans of nerfart_amd/packing.py that the CPU emulation walks) and, for the split programs, hi = rne(w),
  * lo = rne(w - hi) in bf16 (precision 1) or fp16 (precision 4).  Call once per weight update (two launches per blob).
- *   precision       : the C-ABI precision the blob is for: 0 fp32, 1 split bf16 ("bf16x3"; also what every training entry point reads),
+ *   precision       : the C-ABI precision the blob is for (5: nerfart_pack_surface_blob only, see the precision list above): 0 fp32, 1 split bf16 ("bf16x3"; also what every training entry point reads),
  *                     4 fp16 hi + lo ("fp16x2"; the sampler blob of nerfart_volsdf_render_mixed_fwd)
  *   weight_g/_v/bias: HOST arrays of DEVICE pointers, one per layer: `implicit_surface.surface_fc_layers.{0..8}.*` (W 256, D 8, skips [4],
  *                     embed_multires 6, W_geo_feat 256 - the four shipped configs) resp. `radiance_net.layers.{0..4}.*` (W 256, D 4;

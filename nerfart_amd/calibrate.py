@@ -13,8 +13,12 @@ What runs where.  This is a property of a set of WEIGHTS, computed once per set 
 parameter version) - never per frame, never in training (the trainer's sampler blob changes every step and stays hi + lo).  Calibration points are drawn
 in the model's bounding sphere and, half of them, near its surface - selected with the HIP SDF kernel; the layer inputs at those points and the seven
 256 x 256 solves are plain fp64 linear algebra on the host CPU (torch as a LAPACK front end; no GPU library call, no part of any render or training path).
-The result goes through the ordinary C-ABI packer (nerfart_pack_surface_blob, precision 4) as folded weights that already sit on the fp16 grid: its
-hi fragments of the hidden k-steps hold them exactly, the encodings' k-steps keep hi + lo.
+The result goes through the ordinary C-ABI packer (nerfart_pack_surface_blob, precision 5: the fp16 hi + lo layout under its own encoding word) as folded
+weights that already sit on the fp16 grid: its hi fragments of the hidden k-steps hold them exactly, the encodings' k-steps keep hi + lo.
+
+The tensors are handed over in the kernel's SCALED recursion (C_SCALE = 100 log2 e; mlp_bf16_core.h, NERFART_F16X1): accumulators hold z' = c z, activations
+a' = c softplus(z) = max(z', 0) + log2(1 + 2^-|z'|) - one multiply per value less in an epilogue that costs the 1-MFMA kernel more than its matrix work.  Layer 0's
+weights, the skip layer's encoding columns and the hidden biases carry c, the sdf row 1 / c, the hidden weights are the network's own (they multiply c a).
 """
 from __future__ import annotations
 

@@ -297,7 +297,7 @@ class _PackedModel(nn.Module):
         on the device).  nerfart_amd/packing.py keeps the same layout as numpy plans - the source of truth of the CPU emulation
         (tests/emul_chain.py) - and tests/test_pack_plan.py holds the library's closed-form layout equal to them, entry for entry."""
         if precision in ("fp16x1c", "fp16x1"):
-            # C-ABI precision 5, the 1-MFMA K2: one-term fp16 weights in the kernel's scaled softplus recursion - "fp16x1c": error-compensated against this
+            # C-ABI precision 5, the 1-MFMA K2: one-term fp16 weights in the kernel's scaled activation recursion - "fp16x1c": error-compensated against this
             # model's own activations (pack-time calibration, what calibrate_sampler() ships); "fp16x1": rounded to nearest (measured, not shipped)
             from . import calibrate
             g, v, b, stats = calibrate.compensated_surface_layers(self, compensate=precision == "fp16x1c")

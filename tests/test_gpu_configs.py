@@ -176,7 +176,7 @@ def pixel_budget(got, ref, label, stable=None, over_frac=2e-3, max_abs=4e-3, psn
     Why a budget at all: the CPU oracle ITSELF moves such rays by more than 1e-3 when the SDF weights change by one fp32 ulp
     (tools/oracle_sensitivity.py, profiles/r05_oracle_sensitivity_cfg{1,2}.json: 3 of 2,048 rays, max 2.1e-3, 86.2 dB at cfg 2; 22 of
     4,096, max 8.0e-3, 74.6 dB at 32 spp - every one a never-converged ray, zero among the converged) - so does the reference on another
-    machine.  Measured here (profiles/r11_parity_table.json, 2,048 rays; the figures below are round 4's, unchanged): bf16x3 3 / 2 rays past 1e-3 on the two views, max 2.4e-3,
+    machine.  Measured here (profiles/r12_parity_table.json, 2,048 rays; the figures below are round 4's, unchanged): bf16x3 3 / 2 rays past 1e-3 on the two views, max 2.4e-3,
     83.9 / 88.4 dB; the EXACT-fp32 HIP mode 3 / 0 rays, max 1.4e-3, 87.2 / 90.7 dB; all of them never-converged rays.  Returns the errors."""
     err = (got - ref).abs().max(dim=-1).values
     n = err.numel()
