@@ -97,6 +97,16 @@ def compensated_surface_layers(model, n: int = N_CALIB, seed: int = 0, compensat
     dev = L[0].weight_v.device
     D, skips, multires = S.D, tuple(S.skips), S.embed_multires
     c = C_SCALE
+    # at most 8 host threads (what the ~2 s were measured on): one process per GPU calibrates its own copy, concurrently with the other ranks'
+    n_threads = torch.get_num_threads()
+    torch.set_num_threads(min(n_threads, 8))
+    try:
+        return _compensated_surface_layers(model, L, dev, D, skips, multires, c, n, seed, compensate)
+    finally:
+        torch.set_num_threads(n_threads)
+
+
+def _compensated_surface_layers(model, L, dev, D, skips, multires, c, n, seed, compensate):
     with torch.no_grad():
         Wf = [_fold(l.weight_g.detach().cpu(), l.weight_v.detach().cpu()) for l in L]
         bf = [l.bias.detach().cpu().double() for l in L]
