@@ -572,8 +572,8 @@ def main():
                                 "(F_sdf per point) / launch time / 2,500 TFLOP/s, comparable across modes; the sustained rate is set by the package "
                                 "power cap (joules per product: profiles/r05n power probes), which is why fewer MFMAs per product buy time" +
                                 ("; calibrated sampler: ONE v_mfma_f32_16x16x32_f16 per product over error-compensated one-term weights (csrc/mlp_chain_f16x1.hip, "
-                                 "nerfart_amd/calibrate.py) - with one MFMA per item the kernel is bound by its fragment reads, LDS-DMA pieces and epilogue VALU, not by "
-                                 "the matrix pipe (DESIGN.md 4.1e / 4.1f)" if calibrated else ""))
+                                 "nerfart_amd/calibrate.py) - with one MFMA per item the kernel's time follows its fragment reads, LDS-DMA pieces and epilogue VALU, not the "
+                                 "matrix pipe; it still draws the package limit, at a 7 % higher clock (profiles/r12_power_k2.json; DESIGN.md 4.1e / 4.1f / 5)" if calibrated else ""))
         if args.precision == "bf16x3":
             # what the matrix pipe executes: MFMA_MAC_SDF multiply-adds per point, each as `mfma_per_product` bf16 MFMAs
             # (hi.hi + hi.lo + lo.hi), as a fraction of the dense bf16 peak
