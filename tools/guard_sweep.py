@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--size", default="480x270")
     ap.add_argument("--n-samples", type=int, default=128)
     ap.add_argument("--sampler", default="fp16x2", help="the sampler's arithmetic: fp16x2 (2 MFMAs per product, C-ABI precision 4) or fp16x1 (1 MFMA, precision 5)")
+    ap.add_argument("--seed", type=int, default=0, help="seed of the synthetic scene's weights (scene.build_model): another member of the scene family")
     ap.add_argument("--beta", type=float, default=0.01, help="the scene's beta (0.01: the benchmark scene; 0.002: the sharper surface of the G9 goldens)")
     ap.add_argument("--late", type=int, default=0, help="late_round of the guarded sampler: rays still active after that round are escalated too")
     ap.add_argument("--oracle-cache", default=None, help="npz of oracle outputs per (size, spp, pose, rays): read if present, written back (the oracle "
@@ -44,11 +45,11 @@ def main():
     guards = [float(g) for g in args.guards.split(",")]
     poses = [int(p) for p in args.poses.split(",")]
     angles = scene.spiral(90)
-    mb, rk, fb = scene.build_model("VolSDF", seed=0, beta=args.beta, device=dev, precision="bf16x3")
-    mm, _, fm = scene.build_model("VolSDF", seed=0, beta=args.beta, device=dev, precision="bf16x3")
+    mb, rk, fb = scene.build_model("VolSDF", seed=args.seed, beta=args.beta, device=dev, precision="bf16x3")
+    mm, _, fm = scene.build_model("VolSDF", seed=args.seed, beta=args.beta, device=dev, precision="bf16x3")
     kw = dict({k: v for k, v in rk.items() if k != "rayschunk"}, N_samples=args.n_samples)
     sd = {k: v.detach().cpu() for k, v in mb.state_dict().items()}
-    out = {"frame": f"{H}x{W}, {args.n_samples} + 64 spp, beta {args.beta:g}", "oracle_rays": args.rays, "sampler": args.sampler, "late_round": args.late, "csrc_sha256": hip.csrc_sha256(), "views": {}, "timing": {}}
+    out = {"frame": f"{H}x{W}, {args.n_samples} + 64 spp, beta {args.beta:g}, scene seed {args.seed}", "oracle_rays": args.rays, "sampler": args.sampler, "late_round": args.late, "csrc_sha256": hip.csrc_sha256(), "views": {}, "timing": {}}
 
     def frame(fn, o, d):
         rgb, _, ex = fn(o, d, require_nablas=True, calc_normal=True, detailed_output=True, **kw)
@@ -84,7 +85,7 @@ def main():
         o, d, _ = rend_util.get_rays(c2w[None].to(dev), K[None].to(dev), H, W)
         n = min(args.rays, H * W)
         sel = torch.arange(0, H * W, (H * W) // n)[:n]
-        key = f"{H}x{W}_{args.n_samples}_{pose}_{n}" + ("" if args.beta == 0.01 else f"_beta{args.beta:g}")
+        key = f"{H}x{W}_{args.n_samples}_{pose}_{n}" + ("" if args.beta == 0.01 else f"_beta{args.beta:g}") + ("" if args.seed == 0 else f"_seed{args.seed}")
         if key + "_rgb" in cache:
             ref, t_or = {"rgb": torch.from_numpy(cache[key + "_rgb"]), "iter_usage": torch.from_numpy(cache[key + "_iter_usage"])}, 0.0
         else:
